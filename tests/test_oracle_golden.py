@@ -1,0 +1,209 @@
+"""Pins the CPU oracle (oracle/niw_oracle.py) against the golden vectors captured from the
+imported reference by tests/golden/make_golden.py.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import niw_oracle as O
+from tests.util import golden, t, check_grad_summary
+
+ATOL = 2e-6
+
+
+def close(a, b, atol=ATOL, rtol=1e-5):
+    a = a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    torch.testing.assert_close(a.float(), t(b), atol=atol, rtol=rtol)
+
+
+def test_raygen():
+    g = golden("raygen")
+    H, W = int(g["H"]), int(g["W"])
+    intr, pose, idx = t(g["intr"]), t(g["pose"]), torch.from_numpy(g["ray_idx"])
+    c, gr = O.unwarped_center_and_grid(H, W, intr, idx)
+    close(c, g["center_unwarped"]); close(gr, g["grid_unwarped"])
+    c, gr = O.unwarped_center_and_grid(H, W, intr, idx, pose_init=pose)
+    close(c, g["center_unwarped_pose"]); close(gr, g["grid_unwarped_pose"])
+    c, r = O.center_and_ray(H, W, pose, intr)
+    close(c, g["center"]); close(r, g["ray"])
+    cn, rn = O.convert_ndc(c[:, idx] + torch.tensor([0., 0., 3.]), r[:, idx] + torch.tensor([0., 0., 2.]), intr)
+    close(cn, g["ndc_center"], atol=1e-5); close(rn, g["ndc_ray"], atol=1e-5)
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.3, 0.55, 1.0])
+def test_embedder_quirk(alpha):
+    g = golden("embedder")
+    close(O.warp_embed(t(g["x2"]), alpha), g[f"e2_a{alpha}"])
+    close(O.warp_embed(t(g["x1"]), alpha), g[f"e1_a{alpha}"])
+
+
+def test_embedder_flat_is_per_channel():
+    g = golden("embedder")
+    x = t(g["x2"]).reshape(-1, 2)
+    close(O.warp_embed(x, 0.3, reference_exact=False), g["e2_flat_a0.3"])
+
+
+@pytest.mark.parametrize("alpha", [0.3, 1.0])
+def test_warp_forward_inverse_grads(alpha):
+    g = golden("warp")
+    p = {k: v.requires_grad_(True) for k, v in O.make_warp_params(int(g["warp_seed"]), float(g["warp_perturb"])).items()}
+    code = O.make_latent(int(g["latent_seed"]), 3).requires_grad_(True)
+    pts = t(g["pts"])
+    y = O.warp_forward(p, code, pts, alpha)
+    close(y, g[f"fwd_a{alpha}"], atol=1e-4)  # 2^5*pi embedding amplifies fp32 roundoff ~100x per block
+    close(O.warp_inverse(p, code, y.detach(), alpha), g[f"inv_a{alpha}"], atol=1e-4)
+    close(O.warp_inverse(p, code, y.detach(), alpha), pts, atol=1e-4)          # round trip
+    (y * t(g[f"gw_a{alpha}"])).sum().backward()
+    for k, v in p.items():
+        check_grad_summary(v.grad, g, f"grad_a{alpha}.{k}", rtol=1e-2)
+    # forward roundoff (1e-5) times the 2^5*pi band derivative => ~1e-2 relative wobble in fp32 latent grads
+    gl = t(g[f"grad_a{alpha}.latent"])
+    assert (code.grad - gl).abs().max() <= 1e-2 * gl.abs().max()
+    assert float(g["identity_max_abs"]) == 0.0
+
+
+@pytest.mark.parametrize("alpha", [0.3, 1.0])
+def test_warp_fp64_semantics(alpha):
+    """Same computation in fp64 against the reference run in fp64: agreement to 1e-9 pins the
+    restatement's semantics independently of fp32 roundoff amplification."""
+    g = golden("warp")
+    p = {k: v.double().requires_grad_(True) for k, v in O.make_warp_params(int(g["warp_seed"]), float(g["warp_perturb"])).items()}
+    code = O.make_latent(int(g["latent_seed"]), 3).double().requires_grad_(True)
+    y = O.warp_forward(p, code, t(g["pts"]).double(), alpha)
+    assert np.abs(y.detach().numpy() - g[f"fwd64_a{alpha}"]).max() < 1e-9
+    (y * t(g[f"gw_a{alpha}"]).double()).sum().backward()
+    for k, ref in ((code.grad, g[f"grad64_a{alpha}.latent"]),
+                   (p["lin1_b_0.weight_v"].grad[::8, ::5], g[f"grad64_a{alpha}.lin1_b_0.weight_v"]),
+                   (p["lin2_a_0.weight_g"].grad, g[f"grad64_a{alpha}.lin2_a_0.weight_g"])):
+        assert np.abs(k.numpy() - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+def test_warp_identity_at_reference_init():
+    p = O.make_warp_params(3, perturb=0.0)
+    pts = torch.randn(2, 9, 1, 3)
+    assert (O.warp_forward(p, O.make_latent(1, 2), pts, 0.4) - pts).abs().max() == 0
+
+
+def test_nerf_mlp_and_pe():
+    g = golden("nerf_mlp")
+    p = O.make_nerf_params(int(g["nerf_seed"]))
+    pts, dirs = t(g["points"]), t(g["dirs"])
+    close(O.positional_encoding(pts, 10), g["pe_L10"])
+    rgb, den = O.nerf_forward(p, pts, dirs, density_activ="relu")
+    close(rgb, g["relu_rgb"], atol=1e-5); close(den, g["relu_density"], atol=2e-5, rtol=1e-4)
+    for prog in (0.0, 0.22, 0.8):
+        w3, wv = O.c2f_weights(prog, (0.1, 0.5), 10), O.c2f_weights(prog, (0.1, 0.5), 4)
+        close(O.positional_encoding(pts, 10, w3), g[f"c2f{prog}_pe10"])
+        rgb, den = O.nerf_forward(p, pts, dirs, w3d=w3, wview=wv)
+        close(rgb, g[f"c2f{prog}_rgb"], atol=1e-5); close(den, g[f"c2f{prog}_density"], atol=2e-5, rtol=1e-4)
+
+
+def test_nerf_mlp_grads():
+    g = golden("nerf_mlp")
+    p = {k: v.requires_grad_(True) for k, v in O.make_nerf_params(int(g["nerf_seed"])).items()}
+    pts, dirs = t(g["points"]).requires_grad_(True), t(g["dirs"]).requires_grad_(True)
+    w3, wv = O.c2f_weights(0.22, (0.1, 0.5), 10), O.c2f_weights(0.22, (0.1, 0.5), 4)
+    rgb, den = O.nerf_forward(p, pts, dirs, w3d=w3, wview=wv)
+    ((rgb * t(g["g_rgb"])).sum() + (den * t(g["g_den"])).sum()).backward()
+    for k, v in p.items():
+        check_grad_summary(v.grad, g, f"grad.{k}")
+    # d/dpoints is dominated by 2^9*pi trig derivatives of a 6e4-magnitude argument: compare relatively
+    gp = t(g["grad_points"])
+    assert (pts.grad - gp).abs().max() <= 1e-4 * gp.abs().max()
+    close(dirs.grad, g["grad_dirs"], atol=1e-4, rtol=1e-3)
+
+
+def test_composite_and_grads():
+    g = golden("composite")
+    ray, rgb_s, sig_s = (t(g[k]).requires_grad_(True) for k in ("ray", "rgb_s", "sig_s"))
+    rgb, dep, opa, prob = O.composite(ray, rgb_s, sig_s, t(g["depth_s"]))
+    close(rgb, g["rgb"]); close(dep, g["depth"], atol=1e-5); close(opa, g["opacity"]); close(prob, g["prob"])
+    (sum((a * t(g[k])).sum() for a, k in ((rgb, "g_rgb"), (dep, "g_depth"), (opa, "g_opacity"), (prob, "g_prob")))).backward()
+    close(ray.grad, g["grad_ray"], atol=1e-4, rtol=1e-4)
+    close(rgb_s.grad, g["grad_rgb_s"]); close(sig_s.grad, g["grad_sig_s"], atol=1e-4, rtol=1e-4)
+
+
+def test_sampling():
+    g = golden("sampling")
+    u, pdf = t(g["u"]), t(g["pdf"])
+    dm = O.sample_depth(u, 16, (0, 1), "metric")
+    di = O.sample_depth(u, 16, (1, 0), "inverse")
+    close(dm, g["depth_metric"]); close(di, g["depth_inverse"], rtol=1e-6)
+    fm = O.sample_depth_from_pdf(pdf, 16, 32, (0, 1))
+    fi = O.sample_depth_from_pdf(pdf, 16, 32, (1, 0))
+    close(fm, g["fine_metric"]); close(fi, g["fine_inverse"])
+    close(O.merge_depth(dm, fm), g["merged_metric"]); close(O.merge_depth(di, fi), g["merged_inverse"], rtol=1e-6)
+    # known answers: zero pdf clamps to the far bound, uniform pdf -> bin mid-points
+    assert torch.all(fm[0, 0] == 1.0)
+    want = (torch.arange(32, dtype=torch.float32) + 0.5) / 32
+    assert (fm[0, 1, :, 0] - want).abs().max() < 1e-6
+
+
+def test_render_cfg1():
+    g = golden("render_cfg1")
+    H, W, S, Sf = (int(g[k]) for k in ("H", "W", "S", "Sf"))
+    pc = {k: v.requires_grad_(True) for k, v in O.make_nerf_params(int(g["seed_coarse"])).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.make_nerf_params(int(g["seed_fine"])).items()}
+    idx = torch.from_numpy(g["ray_idx"])
+    center, ray = O.center_and_ray(H, W, t(g["pose"]), t(g["intr"]))
+    out = O.render_rays(pc, center[:, idx], ray[:, idx], t(g["u"]), S, (0, 1), "metric", p_fine=pf, Sf=Sf,
+                        density_activ="relu")
+    for k in ("rgb", "depth", "opacity", "rgb_fine", "depth_fine", "opacity_fine"):
+        close(out[k], g[k], atol=1e-5, rtol=1e-4)
+    target = O.gather_pixels(t(g["image"]), idx)
+    l0, l1 = O.mse_loss(out["rgb"], target), O.mse_loss(out["rgb_fine"], target)
+    close(l0, g["loss_render"]); close(l1, g["loss_render_fine"])
+    (l0 + l1).backward()
+    for k, v in pc.items():
+        check_grad_summary(v.grad, g, f"grad.nerf.{k}")
+    for k, v in pf.items():
+        check_grad_summary(v.grad, g, f"grad.nerf_fine.{k}")
+
+
+@pytest.mark.parametrize("tag", ["cfg3", "cfg2"])
+def test_inn_train_step(tag):
+    g = golden(f"inn_step_{tag}")
+    H, W, S, Sf, R = (int(g[k]) for k in ("H", "W", "S", "Sf", "R"))
+    fine = Sf > 0
+    pc = {k: v.requires_grad_(True) for k, v in O.make_nerf_params(int(g["seed_coarse"])).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.make_nerf_params(int(g["seed_fine"])).items()} if fine else None
+    wp = {k: v.requires_grad_(True) for k, v in O.make_warp_params(int(g["seed_warp"]), float(g["warp_perturb"])).items()}
+    lat = O.make_latent(int(g["seed_latent"]), 3).requires_grad_(True)
+    alpha = max(min(int(g["it"]) / int(g["max_pe_iter"]), 1), 0)
+    assert abs(alpha - float(g["alpha_ratio"])) < 1e-12
+    prog = float(g["progress"])
+    w3, wv = O.c2f_weights(prog, (0.1, 0.5), 10), O.c2f_weights(prog, (0.1, 0.5), 4)
+    idx = torch.from_numpy(g["ray_idx"])
+    out = O.inn_train_step(pc, wp, lat, t(g["image"]), t(g["intr"]), idx, t(g["u"]), H, W, S, (1, 0), "inverse",
+                           alpha, nerf_fine_p=pf, Sf=Sf, w3d=w3, wview=wv)
+    for k in ("ray", "center", "grid_3D"):
+        close(out[k], g[k], atol=1e-5)
+    keys = ["rgb", "opacity"] + (["rgb_fine", "opacity_fine"] if fine else [])
+    for k in keys:
+        close(out[k], g[k], atol=2e-5, rtol=1e-4)
+    # composited depth with inverse-depth sampling sums terms up to 1e5: relative check
+    for k in ["depth"] + (["depth_fine"] if fine else []):
+        assert (out[k] - t(g[k])).abs().max() <= 1e-4 * t(g[k]).abs().max()
+    close(out["loss_render"], g["loss_render"], atol=1e-6)
+    out["loss"].backward()
+    for k, v in pc.items():
+        check_grad_summary(v.grad, g, f"grad.nerf.{k}", rtol=2e-3)
+    if fine:
+        for k, v in pf.items():
+            check_grad_summary(v.grad, g, f"grad.nerf_fine.{k}", rtol=2e-3)
+    for k, v in wp.items():
+        check_grad_summary(v.grad, g, f"grad.warp_mlp.{k}", rtol=5e-3)
+    check_grad_summary(lat.grad, g, "grad.warp_latent.weight", rtol=5e-3)
+
+
+def test_kabsch_recovers_known_rigid_motion():
+    # parity unpinned (roma absent); analytic known answer instead
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 50, 3, generator=gen)
+    ang = 0.3
+    Rz = torch.tensor([[math.cos(ang), -math.sin(ang), 0.], [math.sin(ang), math.cos(ang), 0.], [0., 0., 1.]])
+    tt = torch.tensor([0.1, -0.2, 0.3])
+    y = x @ Rz.T + tt
+    Rm, tm = O.rigid_registration(x, y)
+    assert (Rm - Rz).abs().max() < 1e-5 and (tm - tt).abs().max() < 1e-5
