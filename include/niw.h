@@ -1,0 +1,186 @@
+/*
+ * niw.h -- C ABI of libniw_hip.so: the MI355X (gfx950) implementation of the volumetric
+ * rendering hot path of sfchng/neural_invertible_warp.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to caller-allocated, contiguous memory (fp32 unless
+ *     stated; int64 for pixel indices); the library never allocates persistent memory and
+ *     never synchronises; workspaces are sized with the *_floats() queries and passed in;
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream);
+ *   - return value 0 = success, negative = niw_status; the message of the last failure on
+ *     the calling thread is returned by niw_last_error_string(); nothing throws;
+ *   - outputs are fully overwritten unless the parameter is documented as "accumulated".
+ *
+ * Each declaration names the reference interface (file:line in the reference repository)
+ * whose arithmetic it replaces.  The Python mirror of the reference's classes lives in
+ * neural_invertible_warp_amd/ and binds these symbols with ctypes.
+ */
+#ifndef NIW_H_
+#define NIW_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* niw_stream_t;
+
+enum niw_status {
+    NIW_OK = 0,
+    NIW_ERR_INVALID_ARG = -1,   /* shape / enum / null-pointer check failed on the host */
+    NIW_ERR_UNSUPPORTED = -2,   /* architecture constant outside what the kernels are built for */
+    NIW_ERR_LAUNCH = -3         /* hipGetLastError() after a launch */
+};
+
+int niw_version(void);
+const char* niw_last_error_string(void);
+
+/* ------------------------------------------------------------------ field MLP constants
+ * The kernels are specialised for the architecture used by all reference configs
+ * (options/nerf_llff_repr.yaml:3-10, options/nerf_inn_llff.yaml:3-10):
+ *   8 x 256 feature layers, skip at layer 4, 128-wide colour layer, L_3D = 10, L_view = 4. */
+#define NIW_L3D 10
+#define NIW_LVIEW 4
+#define NIW_ENC_SLOTS 64          /* 3 + 6*L_3D = 63 input features, padded, in MFMA slot order */
+#define NIW_VENC_SLOTS 32         /* 3 + 6*L_view = 27 */
+#define NIW_NERF_PARAM_FLOATS 530052   /* 527,872 weights + 2,180 biases, state-dict order */
+
+/* rows of the saved-activation / saved-gradient workspaces (feature-major, [rows][Mpad]) */
+#define NIW_SAVE_ROWS 2274        /* enc 64 | h1..h7 7*256 | feat 256 | venc 32 | hr 128 | sigma_raw 1 | rgb(unused) 1 */
+#define NIW_GRAD_ROWS 2240        /* dY0..dY6 7*256 | dY7 288 (row 256 = d sigma_raw) | dYrgb0 128 | dYrgb1 32 */
+
+enum niw_density_activ { NIW_ACT_RELU = 0, NIW_ACT_SOFTPLUS = 1 };
+
+/* Mpad: number of (ray,sample) rows rounded up to the 128-row workgroup tile. */
+int64_t niw_mlp_padded_rows(int64_t n_rays, int n_samples);
+/* floats of the packed-weight buffer written by niw_mlp_pack_weights */
+int64_t niw_mlp_packed_floats(void);
+/* floats of the split-M partial-sum workspace used by niw_mlp_bwd */
+int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples);
+
+/* Re-orders the nn.Linear weights of NeRF (model/nerf.py:373-400; `params` = the 20 tensors
+ * mlp_feat.{0..7}.{weight,bias}, mlp_rgb.{0,1}.{weight,bias} concatenated in that order,
+ * NIW_NERF_PARAM_FLOATS floats) into MFMA A-fragment order for the forward and the
+ * transposed order for the backward.  Call after every optimizer step. */
+int niw_mlp_pack_weights(const float* params, float* packed, niw_stream_t stream);
+
+/* NeRF.forward_samples (model/nerf.py:449-456) = get_3D_points_from_depth (camera.py:517-521)
+ * + F.normalize + NeRF.forward (model/nerf.py:416-447) incl. positional_encoding
+ * (model/nerf.py:476-483) with the BARF c2f band weights (model/barf_inn_llff.py:427-442).
+ *   center, ray  [n_rays,3]; depth [n_rays,n_samples]; band_w3d[10], band_wview[4] host arrays
+ *   noise        [n_rays*n_samples] or NULL (density_noise_reg * randn, nerf.py:428-429)
+ *   rgb [n_rays,n_samples,3], sigma [n_rays,n_samples]  (outputs)
+ *   save         [NIW_SAVE_ROWS, Mpad] or NULL; non-NULL = training mode (activations kept
+ *                for niw_mlp_bwd). */
+int niw_mlp_fwd(const float* packed, const float* params, const float* center, const float* ray,
+                const float* depth, const float* noise, int64_t n_rays, int n_samples,
+                const float* band_w3d, const float* band_wview, int density_activ,
+                float* rgb, float* sigma, float* save, niw_stream_t stream);
+
+/* Backward of niw_mlp_fwd (autograd of model/nerf.py:416-456).
+ *   d_rgb [n_rays,n_samples,3], d_sigma [n_rays,n_samples]: incoming gradients
+ *   save: the buffer niw_mlp_fwd filled; gradws [NIW_GRAD_ROWS, Mpad] scratch;
+ *   partial: niw_mlp_bwd_workspace_floats() scratch
+ *   d_params [NIW_NERF_PARAM_FLOATS]: OVERWRITTEN with dL/dparams (state-dict order)
+ *   d_center, d_ray [n_rays,3] or both NULL: ACCUMULATED (+=) gradients w.r.t. the rays
+ *   (three routes of SURVEY section 8a: sample points and view directions; the ray-length
+ *   route belongs to niw_composite_bwd). */
+int niw_mlp_bwd(const float* packed, const float* params, const float* center, const float* ray,
+                const float* depth, int64_t n_rays, int n_samples,
+                const float* band_w3d, const float* band_wview, int density_activ,
+                const float* rgb, const float* d_rgb, const float* d_sigma,
+                const float* save, float* gradws, float* partial,
+                float* d_params, float* d_center, float* d_ray, niw_stream_t stream);
+
+/* ------------------------------------------------------------------ compositing
+ * NeRF.composite (model/nerf.py:458-474).  ray [n_rays,3], rgb_s [n_rays,S,3],
+ * sigma_s, depth_s [n_rays,S] -> rgb [n_rays,3], depth, opacity [n_rays], prob [n_rays,S]
+ * (prob may be NULL).  bg: background colour added as bg*(1-opacity) when has_bg != 0
+ * (opt.nerf.setbg_opaque, nerf.py:472-473). */
+int niw_composite_fwd(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s,
+                      int64_t n_rays, int n_samples, int has_bg, float bg,
+                      float* rgb, float* depth, float* opacity, float* prob, niw_stream_t stream);
+
+/* Closed-form backward.  d_prob may be NULL.  Outputs: d_rgb_s
+ * [n_rays,S,3], d_sigma_s [n_rays,S], d_ray [n_rays,3] (all overwritten). */
+int niw_composite_bwd(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s,
+                      int64_t n_rays, int n_samples, int has_bg, float bg,
+                      const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_prob,
+                      float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream);
+
+/* ------------------------------------------------------------------ sampling
+ * Graph.sample_depth (model/nerf.py:334-344).  u [n_rays,S] stratified draws or NULL (0.5). */
+int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, float depth_min, float depth_max,
+                          int inverse, float* depth, niw_stream_t stream);
+
+/* Graph.sample_depth_from_pdf (model/nerf.py:346-365) followed by the cat + ascending sort of
+ * Graph.render (model/nerf.py:313-315).  pdf [n_rays,S], depth_coarse [n_rays,S];
+ * unif [Sf] = mid-points of linspace(0,1,Sf+1) (nerf.py:352-353) and bins [S+1] =
+ * linspace(depth_min,depth_max,S+1) (nerf.py:356) are the two per-config constant tables, built
+ * once by the host mirror with the same torch.linspace calls as the reference.
+ * Outputs: depth_fine [n_rays,Sf] (may be NULL), depth_merged [n_rays,S+Sf] ascending.
+ * S+Sf <= 1024. */
+int niw_sample_pdf_merge(const float* pdf, const float* depth_coarse, const float* unif, const float* bins,
+                         int64_t n_rays, int n_samples, int n_fine,
+                         float* depth_fine, float* depth_merged, niw_stream_t stream);
+
+/* ------------------------------------------------------------------ ray generation
+ * mode 0: camera.get_unwarped_center_and_ray (camera.py:359-390): out_a = center (zeros, or
+ *         the camera centre under pose_init), out_b = grid point K^-1 [x+.5, y+.5, 1] (moved to
+ *         world by pose_init when given).
+ * mode 1: camera.get_center_and_ray (camera.py:419-443): out_a = centre, out_b = ray
+ *         (pose is world->camera and is inverted as camera.py:89-95 does).
+ * intr [B,3,3]; pose [B,3,4] or NULL; ray_idx [R] int64 pixel ids (y*W+x) or NULL (= all H*W);
+ * outputs [B,R,3]. */
+int niw_raygen(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, int64_t n_rays_per_view,
+               int H, int W, int mode, float* out_a, float* out_b, niw_stream_t stream);
+
+/* camera.convert_NDC (camera.py:523-540); center, ray [B,R,3] in/out buffers distinct. */
+int niw_convert_ndc(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view,
+                    float near, float* center_ndc, float* ray_ndc, niw_stream_t stream);
+
+/* ------------------------------------------------------------------ NVP invertible warp
+ * DeformNetwork.forward / .inverse (model/nvp/nvp_ndr.py:365-468, 471-567), per-point part.
+ * The per-view / per-parameter preprocessing (weight norm g*v/|v| nvp_ndr.py:291-292, code
+ * projection lin_c(code)+code :381, and the latent half of the first layers) is folded by the
+ * host mirror into:
+ *   w_emb   [3 blocks][ part a: 128x26 | part b: 128x13 ]   effective first-layer weights (embedding columns)
+ *   view_b  [n_views][3][2][128]                            W[:,emb:] . code_b + bias   (per view)
+ *   w_head  [3][ a: 1x128 + 1 | b: 3x128 + 3 ]              second-layer weights and biases
+ * pts [n_views, n_pts, 3]; chan_w[6] per-band window, pt_scale [n_pts] per-point scale (the
+ * dim-1 slicing of model/nvp/embedder.py:47) or NULL.
+ * inverse != 0 evaluates .inverse.  xin_save [n_views,n_pts,3,3] (block inputs) may be NULL. */
+#define NIW_WARP_WEMB_FLOATS (3 * (128 * 26 + 128 * 13))
+#define NIW_WARP_WHEAD_FLOATS (3 * (128 + 1 + 3 * 128 + 3))
+int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                 int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
+                 int inverse, float* out, niw_stream_t stream);
+
+/* Backward of the forward warp.  d_out [n_views,n_pts,3] -> d_w_emb, d_view_b, d_w_head (same
+ * shapes as the inputs, overwritten) and d_pts [n_views,n_pts,3] (may be NULL).
+ * workspace: niw_warp_bwd_workspace_floats() floats of scratch.  n_views <= 64 per call. */
+int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts);
+int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                 int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
+                 const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                 niw_stream_t stream);
+
+/* ------------------------------------------------------------------ loss and optimizer
+ * Graph.compute_loss photometric part + MSE_loss (model/nerf_inn_llff.py:548-559,
+ * model/base.py:209-211): gathers image[b,:,ray_idx] ([B,3,H*W] layout), writes
+ * loss[0] = mean((rgb - image)^2) * 1 and d_rgb = scale * 2 (rgb - image) / (3*B*R_norm).
+ * n_norm: element count used for the mean (= 3*B*R of the GLOBAL batch under ray sharding).
+ * loss is ACCUMULATED (caller zeroes). */
+int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx, int n_views,
+                    int64_t n_rays_per_view, int64_t hw, double n_norm, float grad_scale,
+                    float* loss, float* d_rgb, niw_stream_t stream);
+
+/* torch.optim.Adam step (model/nerf.py:34-38 uses it with default betas/eps) on a flat buffer. */
+int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int step, niw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIW_H_ */

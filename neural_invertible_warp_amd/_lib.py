@@ -1,0 +1,69 @@
+"""ctypes binding of libniw_hip.so (the C ABI declared in include/niw.h).
+
+There is no CPU fallback: if the shared library is missing the import of any op fails loudly
+with instructions to build it (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C neural_invertible_warp_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libniw_hip.so")
+
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/niw.h one to one
+SIGNATURES = {
+    "niw_version": (_i, []),
+    "niw_last_error_string": (ctypes.c_char_p, []),
+    "niw_mlp_padded_rows": (_i64, [_i64, _i]),
+    "niw_mlp_packed_floats": (_i64, []),
+    "niw_mlp_bwd_workspace_floats": (_i64, [_i64, _i]),
+    "niw_mlp_pack_weights": (_i, [_vp, _vp, _vp]),
+    "niw_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "niw_mlp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "niw_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_sample_stratified": (_i, [_vp, _i64, _i, _f, _f, _i, _vp, _vp]),
+    "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "niw_raygen": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "niw_convert_ndc": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
+    "niw_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp]),
+    "niw_warp_bwd_workspace_floats": (_i64, [_i, _i64]),
+    "niw_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _d, _f, _vp, _vp, _vp]),
+    "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+class NiwError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises NiwError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NiwError(
+            f"{LIB_PATH} not found: the HIP library is not built. Run "
+            "`make -C neural_invertible_warp_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the render path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise NiwError(niw_last_error_string()) on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise NiwError(f"{name} failed ({rc}): {lib.niw_last_error_string().decode()}")
+    return rc

@@ -1,0 +1,126 @@
+// Shared host/device helpers for libniw_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "niw.h"
+
+void niw_set_error(const char* fmt, ...);
+
+#define NIW_REQUIRE(cond, ...)                       \
+    do {                                             \
+        if (!(cond)) {                               \
+            niw_set_error(__VA_ARGS__);              \
+            return NIW_ERR_INVALID_ARG;              \
+        }                                            \
+    } while (0)
+
+#define NIW_LAUNCH_CHECK(name)                                                       \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            niw_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));     \
+            return NIW_ERR_LAUNCH;                                                   \
+        }                                                                            \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------------------
+// Field-MLP geometry (model/nerf.py:373-400 with the arch block of every reference yaml)
+// ----------------------------------------------------------------------------------------
+namespace niw {
+
+constexpr int kLayers = 10;                       // mlp_feat.0..7, mlp_rgb.0, mlp_rgb.1
+constexpr int kWidth = 256;
+constexpr int kIn3D = 3 + 6 * NIW_L3D;            // 63
+constexpr int kInView = 3 + 6 * NIW_LVIEW;        // 27
+
+__host__ __device__ constexpr int layer_k(int l) {   // reference in_features
+    return l == 0 ? kIn3D : l == 4 ? kWidth + kIn3D : l == 8 ? kWidth + kInView : l == 9 ? 128 : kWidth;
+}
+__host__ __device__ constexpr int layer_n(int l) {   // reference out_features
+    return l == 7 ? kWidth + 1 : l == 8 ? 128 : l == 9 ? 3 : kWidth;
+}
+__host__ __device__ constexpr int weight_off(int l) {   // offset of layer l's weight in the flat parameter vector
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += layer_n(i) * layer_k(i) + layer_n(i);
+    return o;
+}
+__host__ __device__ constexpr int bias_off(int l) { return weight_off(l) + layer_n(l) * layer_k(l); }
+static_assert(bias_off(9) + 3 == NIW_NERF_PARAM_FLOATS, "parameter count");
+
+// MFMA-order geometry.  Forward:  out[n][m] = sum_k W[n][k] act[k][m]   (A = W, B = act)
+// slots: k index as consumed by the kernel; 8 slots per k-block (2 lane halves x 4 regs).
+__host__ __device__ constexpr int fwd_kb(int l) {       // k-blocks of 8 slots
+    return l == 0 ? 8 : l == 4 ? 40 : l == 8 ? 36 : l == 9 ? 16 : 32;
+}
+__host__ __device__ constexpr int fwd_nb(int l) {       // 32-row output blocks
+    return l == 7 ? 9 : l == 8 ? 4 : l == 9 ? 1 : 8;
+}
+// Backward: dX[k][m] = sum_n W[n][k] dY[n][m]   (A = W^T, B = dY)
+__host__ __device__ constexpr int bwd_rb(int l) {       // reduction k-blocks (over n)
+    return l == 7 ? 33 : l == 8 ? 16 : l == 9 ? 1 : 32;
+}
+__host__ __device__ constexpr int bwd_ob(int l) {       // 32-row output blocks (over input slots)
+    return l == 0 ? 2 : l == 4 ? 10 : l == 8 ? 9 : l == 9 ? 4 : 8;
+}
+__host__ __device__ constexpr int fwd_pack_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += fwd_kb(i) * fwd_nb(i) * 256;
+    return o;
+}
+constexpr int kFwdPackFloats = fwd_pack_off(kLayers);
+__host__ __device__ constexpr int bwd_pack_off(int l) {
+    int o = kFwdPackFloats;
+    for (int i = 0; i < l; ++i) o += bwd_rb(i) * bwd_ob(i) * 256;
+    return o;
+}
+constexpr int kBiasPackOff = bwd_pack_off(kLayers);
+__host__ __device__ constexpr int bias_pack_off(int l) {     // [nb][h][16] floats per layer
+    int o = kBiasPackOff;
+    for (int i = 0; i < l; ++i) o += fwd_nb(i) * 32;
+    return o;
+}
+constexpr int kPackedFloats = bias_pack_off(kLayers);
+
+// reference column of an encoding slot (see DESIGN.md "encoding slot order"); -1 = zero pad.
+// slot = 8q + 4h + t; combo g = 2q + h; g == 0 -> raw xyz; else sincos pairs 2(g-1), 2(g-1)+1.
+__host__ __device__ constexpr int enc_slot_col(int slot, int L) {
+    int q = slot >> 3, h = (slot >> 2) & 1, t = slot & 3, g = 2 * q + h;
+    if (g == 0) return t < 3 ? t : -1;
+    int pair = 2 * (g - 1) + (t >> 1);
+    if (pair >= 3 * L) return -1;
+    int c = pair / L, k = pair % L;
+    return 3 + c * 2 * L + ((t & 1) ? L : 0) + k;
+}
+// reference input column of forward slot s of layer l (-1 = pad)
+__host__ __device__ constexpr int fwd_slot_col(int l, int s) {
+    if (l == 0) return enc_slot_col(s, NIW_L3D);
+    if (l == 4) return s < kWidth ? s : (enc_slot_col(s - kWidth, NIW_L3D) < 0 ? -1 : kWidth + enc_slot_col(s - kWidth, NIW_L3D));
+    if (l == 8) return s < kWidth ? s : (enc_slot_col(s - kWidth, NIW_LVIEW) < 0 ? -1 : kWidth + enc_slot_col(s - kWidth, NIW_LVIEW));
+    return s < layer_k(l) ? s : -1;
+}
+// reference output row of kernel row n of layer l (-1 = pad).  Layer 7: kernel rows 0..255 are
+// the feature rows (reference rows 1..256) and kernel row 256 is the density row (reference 0).
+__host__ __device__ constexpr int out_row(int l, int n) {
+    if (l == 7) return n < kWidth ? n + 1 : (n == kWidth ? 0 : -1);
+    return n < layer_n(l) ? n : -1;
+}
+
+// rows of the activation / gradient workspaces
+constexpr int kSaveEnc = 0, kSaveH1 = 64, kSaveFeat = 64 + 7 * 256, kSaveVenc = kSaveFeat + 256,
+              kSaveHr = kSaveVenc + 32, kSaveSigma = kSaveHr + 128;
+static_assert(kSaveSigma + 2 == NIW_SAVE_ROWS, "save rows");
+__host__ __device__ constexpr int save_h(int l) { return kSaveH1 + (l - 1) * 256; }   // output of layer l-1, l = 1..7
+constexpr int kGradY7 = 7 * 256, kGradRgb0 = kGradY7 + 288, kGradRgb1 = kGradRgb0 + 128;
+static_assert(kGradRgb1 + 32 == NIW_GRAD_ROWS, "grad rows");
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// feature row (within its 32-block) held by accumulator register r of lane half h
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+}  // namespace niw

@@ -1,0 +1,265 @@
+// Field MLP backward, pass 2: weight and bias gradients.
+//     dW[n][k] = sum_m dY[n][m] * X[k][m]
+// dY and X are the feature-major tensors written by pass 1 / the forward ([rows][Mpad], sample
+// index contiguous), i.e. both operands are "row = output index, contiguous = reduction
+// index": an NT GEMM with a tiny output (<= 256 x 256) and a huge reduction (all samples).
+// Decomposition: split-M.  Every workgroup owns one contiguous range of samples, stages
+// 32-sample slices of both operands through LDS (double-buffered, rows padded by 4 floats so
+// that ds_read_b128 fragment reads are conflict free), accumulates the whole output tile in
+// registers with v_mfma_f32_32x32x2_f32, and writes ONE partial tile at the end.  A second
+// kernel sums the partial tiles in a fixed order (deterministic; no float atomics) and
+// scatters the result into the state-dict layout of d_params.
+#include "niw_common.h"
+
+using namespace niw;
+
+int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
+                          int64_t n_rays, int n_samples, int density_activ, const float* rgb, const float* d_rgb,
+                          const float* d_sigma, const float* save, float* gradws, float* d_center, float* d_ray,
+                          hipStream_t stream);
+
+// C[n][k] = sum_m A[n][m] B[k][m] per batch; tile 256x256 (wide) or 256x64; partial tiles
+// [batch][nsplit][TN*TK + 256] (the trailing 256 floats are row sums of A (bias_side 1) or B (2)).
+int niw_launch_nt_gemm(int wide, const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB,
+                       long long mpad, int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st);
+
+namespace {
+
+constexpr int kLdsStride = 36;   // 32 samples + 4 pad floats per row
+
+// WN x WK waves; each wave owns NBW x KBW blocks of 32x32 outputs.
+template <int WN, int WK, int NBW, int KBW>
+__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(const float* __restrict__ A, int rowsA, long long strideA,
+                                                               const float* __restrict__ B, int rowsB, long long strideB,
+                                                               long long mpad, int steps_total, int steps_per_wg,
+                                                               float* __restrict__ partial, int bias_side) {
+    A += (long long)blockIdx.y * strideA;
+    B += (long long)blockIdx.y * strideB;
+    constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
+    constexpr int ROWS = TN + TK;
+    constexpr int LOADS = ROWS * 8 / NT;                  // float4 loads per thread per 32-sample step
+    static_assert(ROWS * 8 % NT == 0, "tile must divide over the threads");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WK, wk = wave % WK;
+    const int i = lane & 31, h = lane >> 5;
+    const int step0 = blockIdx.x * steps_per_wg;
+    const int nsteps = min(steps_per_wg, steps_total - step0);
+
+    f32x16 acc[NBW][KBW];
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    float bsum = 0.f;
+
+    f32x4 stage[LOADS];
+    auto gload = [&](int step) {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
+            const bool isA = row < TN;
+            const int rr = isA ? row : row - TN;
+            const bool ok = isA ? rr < rowsA : rr < rowsB;
+            const float* src = (isA ? A : B) + (long long)rr * mpad + (long long)step * 32 + c4 * 4;
+            stage[k] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<f32x4*>(lds + (buf * ROWS + row) * kLdsStride + c4 * 4) = stage[k];
+        }
+    };
+
+    if (nsteps > 0) {
+        gload(step0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(step0 + s + 1);
+        const float* As = lds + buf * ROWS * kLdsStride;
+        const float* Bs = As + TN * kLdsStride;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 af[NBW], bf[KBW];
+#pragma unroll
+            for (int x = 0; x < NBW; ++x)
+                af[x] = *reinterpret_cast<const f32x4*>(As + ((wn * NBW + x) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+#pragma unroll
+            for (int y = 0; y < KBW; ++y)
+                bf[y] = *reinterpret_cast<const f32x4*>(Bs + ((wk * KBW + y) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+#pragma unroll
+            for (int x = 0; x < NBW; ++x)
+#pragma unroll
+                for (int y = 0; y < KBW; ++y)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[x][y] = mfma32(af[x][t], bf[y][t], acc[x][y]);
+        }
+        if (bias_side) {
+            // row sums of the dY operand: thread t < rows sums its row of the staged slice
+            const int nrows = bias_side == 1 ? TN : TK;
+            if (tid < nrows) {
+                const float* rowp = (bias_side == 1 ? As : Bs) + tid * kLdsStride;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + c * 4);
+                    bsum += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+            }
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
+    float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[((wn * NBW + x) * 32 + acc_row(r, h)) * TK + (wk * KBW + y) * 32 + i] = acc[x][y][r];
+    if (tid < 256) out[TN * TK + tid] = bsum;
+}
+
+// Deterministic reduction of the partial tiles + scatter into the flat parameter gradient.
+struct ReduceArgs {
+    const float* partial;
+    float* d_params;
+    int nsplit, TN, TK;
+    int layer;        // 0..9
+    int n_off;        // kernel-row offset of tile row 0 (dY side)
+    int k_off;        // slot offset of tile column 0 (X side)
+    int transposed;   // tile is [slot][row] instead of [row][slot]
+    int bias;         // 0: none, 1: bias sums indexed by the dY row
+};
+
+__global__ void dw_reduce_kernel(ReduceArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tile = a.TN * a.TK;
+    const int stride = tile + 256;
+    if (idx < tile) {
+        const int tr = idx / a.TK, tc = idx % a.TK;
+        const int n = a.n_off + (a.transposed ? tc : tr), s = a.k_off + (a.transposed ? tr : tc);
+        const int row = out_row(a.layer, n), col = fwd_slot_col(a.layer, s);
+        if (row < 0 || col < 0) return;
+        float sum = 0.f;
+        for (int w = 0; w < a.nsplit; ++w) sum += a.partial[(long long)w * stride + idx];
+        a.d_params[weight_off(a.layer) + row * layer_k(a.layer) + col] = sum;
+    } else if (a.bias && idx < tile + 256) {
+        const int b = idx - tile;
+        const int row = out_row(a.layer, a.n_off + b);
+        if (row < 0 || b >= (a.transposed ? a.TK : a.TN)) return;
+        float sum = 0.f;
+        for (int w = 0; w < a.nsplit; ++w) sum += a.partial[(long long)w * stride + idx];
+        a.d_params[bias_off(a.layer) + row] = sum;
+    }
+}
+
+struct Piece {
+    int layer;
+    int a_row, a_rows;   // dY-side operand: first row in gradws / valid rows   (X side when transposed)
+    int b_row, b_rows;   // X-side operand: first row in save / valid rows
+    int n_off, k_off, transposed, bias, wide;   // wide: 256x256 tile, else 256x64
+};
+
+template <int WN, int WK, int NBW, int KBW>
+int launch_gemm(const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB, long long mpad,
+                int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st) {
+    constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
+    const int steps_total = (int)(mpad / 32);
+    // at least 8 slices per workgroup, at most one workgroup per CU
+    int nsplit = (steps_total + 7) / 8;
+    nsplit = nsplit < 1 ? 1 : (nsplit > 256 ? 256 : nsplit);
+    const int per = (steps_total + nsplit - 1) / nsplit;
+    nsplit = (steps_total + per - 1) / per;
+    const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
+    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(A, rowsA, strideA, B, rowsB, strideB, mpad, steps_total, per, partial, bias_side);
+    NIW_LAUNCH_CHECK("NT GEMM");
+    *nsplit_out = nsplit;
+    return NIW_OK;
+}
+
+int launch_piece(const Piece& p, const float* A, const float* B, long long mpad, float* partial, float* d_params, hipStream_t st) {
+    const int bias_side = p.bias ? (p.transposed ? 2 : 1) : 0;
+    int nsplit = 0;
+    int rc = niw_launch_nt_gemm(p.wide, A, p.a_rows, 0, B, p.b_rows, 0, mpad, 1, partial, bias_side, &nsplit, st);
+    if (rc != NIW_OK) return rc;
+    ReduceArgs r;
+    r.partial = partial; r.d_params = d_params; r.nsplit = nsplit; r.TN = 256; r.TK = p.wide ? 256 : 64; r.layer = p.layer;
+    r.n_off = p.n_off; r.k_off = p.k_off; r.transposed = p.transposed; r.bias = p.bias;
+    dw_reduce_kernel<<<(r.TN * r.TK + 256 + 255) / 256, 256, 0, st>>>(r);
+    NIW_LAUNCH_CHECK("niw_mlp_bwd (dW reduce)");
+    return NIW_OK;
+}
+
+}  // namespace
+
+int niw_launch_nt_gemm(int wide, const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB,
+                       long long mpad, int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st) {
+    return wide ? launch_gemm<4, 2, 2, 4>(A, rowsA, strideA, B, rowsB, strideB, mpad, batches, partial, bias_side, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2>(A, rowsA, strideA, B, rowsB, strideB, mpad, batches, partial, bias_side, nsplit_out, st);
+}
+
+extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
+    (void)n_rays; (void)n_samples;
+    return 256ll * (256 * 256 + 256);
+}
+
+extern "C" int niw_mlp_bwd(const float* packed, const float* params, const float* center, const float* ray,
+                           const float* depth, int64_t n_rays, int n_samples,
+                           const float* band_w3d, const float* band_wview, int density_activ,
+                           const float* rgb, const float* d_rgb, const float* d_sigma,
+                           const float* save, float* gradws, float* partial,
+                           float* d_params, float* d_center, float* d_ray, niw_stream_t stream) {
+    (void)params; (void)band_w3d; (void)band_wview;
+    NIW_REQUIRE(packed && center && ray && depth && rgb && d_rgb && d_sigma && save && gradws && partial && d_params,
+                "niw_mlp_bwd: null pointer");
+    NIW_REQUIRE((d_center == nullptr) == (d_ray == nullptr), "niw_mlp_bwd: d_center and d_ray must both be given or both be NULL");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd: empty input");
+    NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_bwd: unknown density activation %d", density_activ);
+    const long long mpad = niw_mlp_padded_rows(n_rays, n_samples);
+    NIW_REQUIRE(mpad < (1ll << 27), "niw_mlp_bwd: too many samples per call");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = niw_launch_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
+                                   d_center, d_ray, st);
+    if (rc != NIW_OK) return rc;
+
+    // dW pieces.  Non-transposed: tile rows = dY rows (gradws), tile columns = X slots (save).
+    // Transposed (skinny dY: the density row, the 3 colour rows): tile rows = X slots, columns = dY rows.
+    const Piece pieces[] = {
+        // layer, a_row, a_rows, b_row, b_rows, n_off, k_off, transposed, bias, wide
+        {0, 0 * 256, 256, kSaveEnc, 64, 0, 0, 0, 1, 0},
+        {1, 1 * 256, 256, save_h(1), 256, 0, 0, 0, 1, 1},
+        {2, 2 * 256, 256, save_h(2), 256, 0, 0, 0, 1, 1},
+        {3, 3 * 256, 256, save_h(3), 256, 0, 0, 0, 1, 1},
+        {4, 4 * 256, 256, save_h(4), 256, 0, 0, 0, 1, 1},
+        {4, 4 * 256, 256, kSaveEnc, 64, 0, 256, 0, 0, 0},
+        {5, 5 * 256, 256, save_h(5), 256, 0, 0, 0, 1, 1},
+        {6, 6 * 256, 256, save_h(6), 256, 0, 0, 0, 1, 1},
+        {7, kGradY7, 256, save_h(7), 256, 0, 0, 0, 1, 1},
+        {7, save_h(7), 256, kGradY7 + 256, 1, 256, 0, 1, 1, 0},          // density row (transposed)
+        {8, kGradRgb0, 128, kSaveFeat, 256, 0, 0, 0, 1, 1},
+        {8, kGradRgb0, 128, kSaveVenc, 32, 0, 256, 0, 0, 0},
+        {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0},                  // colour rows (transposed)
+    };
+    for (const Piece& p : pieces) {
+        const float* A = (p.transposed ? save : gradws) + (long long)p.a_row * mpad;
+        const float* B = (p.transposed ? gradws : save) + (long long)p.b_row * mpad;
+        rc = launch_piece(p, A, B, mpad, partial, d_params, st);
+        if (rc != NIW_OK) return rc;
+    }
+    return NIW_OK;
+}

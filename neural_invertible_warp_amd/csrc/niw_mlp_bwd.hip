@@ -1,0 +1,247 @@
+// Field MLP backward, pass 1: the dX chain (autograd of reference model/nerf.py:416-456).
+// Same register-chained structure as the forward: every wave owns 32 samples; for a layer
+//     dX[k][m] = sum_n W[n][k] * dY[n][m]        (A operand = W^T fragments, B operand = dY)
+// whose C/D fragment, after the ReLU mask (read from the activations the forward saved), is
+// register for register the B operand of the next (earlier) layer.  Every dY is also stored
+// feature-major for pass 2 (niw_dw_gemm.hip: dW = dY . X^T over all samples).
+// The chain ends in d(points), d(view dirs) -> d_center / d_ray (gradient routes (i) and (ii)
+// of SURVEY section 8a; route (iii), the ray length, is niw_composite_bwd's).
+#include "niw_common.h"
+#include "niw_mlp_device.h"
+
+using namespace niw;
+
+struct MlpBwdArgs {
+    const float* packed;
+    const float* center;
+    const float* ray;
+    const float* depth;
+    const float* rgb;
+    const float* d_rgb;
+    const float* d_sigma;
+    const float* save;
+    float* grad;
+    float* d_center;
+    float* d_ray;
+    long long M, Mpad;
+    int S, act, ray_grad;
+};
+
+template <int NB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+}
+
+// dy = acc masked by (saved activation > 0); stored feature-major at grad_row0
+template <int NB>
+__device__ __forceinline__ void mask_store(const f32x16 (&acc)[NB], float (&dy)[16 * NB], const float* __restrict__ act_row0,
+                                           float* __restrict__ grad_row0, long long mpad, unsigned voff, bool valid) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad;
+            const float a = (act_row0 + row)[voff];
+            const float g = (valid && a > 0.f) ? acc[nb][r] : 0.f;
+            dy[nb * 16 + r] = g;
+            (grad_row0 + row)[voff] = g;
+        }
+    }
+}
+
+// d(point)/d(unit dir) from the gradient of the encoding slots and the saved encoding values:
+// d/dx [w sin(f x)] = f * (w cos(f x)),  d/dx [w cos(f x)] = -f * (w sin(f x)).
+template <int L, int NQ>
+__device__ __forceinline__ void enc_backward(const float (&de)[4 * NQ], const float* __restrict__ enc_row0, long long mpad,
+                                             unsigned voff, int h, float (&dp)[3]) {
+    dp[0] = dp[1] = dp[2] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = (enc_row0 + (long long)(8 * q + t) * mpad)[voff];
+        if (q == 0) {
+            // half 0: raw coordinates; half 1: pairs 0 and 1
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dp[c] += h ? 0.f : de[c];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int pair = pr;
+                if (pair < 3 * L) {
+                    const float v = band_freq(pair % L) * (de[2 * pr] * e[2 * pr + 1] - de[2 * pr + 1] * e[2 * pr]);
+                    dp[pair / L] += h ? v : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int pair0 = 2 * (2 * q - 1) + pr, pair1 = 4 * q + pr;   // half 0 / half 1
+                const float core = de[4 * q + 2 * pr] * e[2 * pr + 1] - de[4 * q + 2 * pr + 1] * e[2 * pr];
+                if (pair0 < 3 * L) dp[pair0 / L] += h ? 0.f : band_freq(pair0 % L) * core;
+                if (pair1 < 3 * L) dp[pair1 / L] += h ? band_freq(pair1 % L) * core : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool valid = m < a.M;
+    const long long mc = valid ? m : a.M - 1;
+    const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
+    const long long P = a.Mpad;
+
+    float dy[128];
+    f32x16 acc[10];
+
+    // ---- colour head: sigmoid' and W_rgb1^T
+    float dy9[4];
+    {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float g = 0.f;
+            if (h == 0 && t < 3 && valid) {
+                const float o = a.rgb[mc * 3 + t];
+                g = a.d_rgb[mc * 3 + t] * o * (1.f - o);
+            }
+            dy9[t] = g;
+            (a.grad + (long long)(kGradRgb1 + t) * P)[voff] = g;     // rows 4h+t of the 8-row slot block
+        }
+    }
+    float dyr[64];
+    {
+        f32x16(&acc4)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
+        zero_acc<4>(acc4);
+        gemm_regs<1, 4>(wp + bwd_pack_off(9) / 4, lane, dy9, acc4);
+        mask_store<4>(acc4, dyr, a.save + (long long)kSaveHr * P, a.grad + (long long)kGradRgb0 * P, P, voff, valid);
+    }
+    // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots)
+    float dvenc[16];
+    {
+        f32x16(&acc9)[9] = reinterpret_cast<f32x16(&)[9]>(acc);
+        zero_acc<9>(acc9);
+        gemm_regs<16, 9>(wp + bwd_pack_off(8) / 4, lane, dyr, acc9);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dvenc[r] = acc9[8][r];
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        mask_store<8>(acc8, dy, a.save + (long long)kSaveFeat * P, a.grad + (long long)kGradY7 * P, P, voff, valid);
+    }
+    // ---- density head: d sigma_raw (kernel row 256 of layer 7)
+    float dsig[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        float g = 0.f;
+        if (h == 0 && valid) {
+            const float raw = (a.save + (long long)kSaveSigma * P)[voff];
+            const float dact = a.act == NIW_ACT_RELU ? (raw > 0.f ? 1.f : 0.f) : (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
+            g = a.d_sigma[mc] * dact;
+        }
+        dsig[0] = g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) (a.grad + (long long)(kGradY7 + 256 + t) * P)[voff] = dsig[t];
+    }
+    // ---- layer 7 transposed (257 -> 256), mask with h7
+    {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        zero_acc<8>(acc8);
+        gemm_regs<32, 8>(wp + bwd_pack_off(7) / 4, lane, dy, acc8);
+        gemm_regs<1, 8>(wp + bwd_pack_off(7) / 4 + 32 * 8 * 64, lane, dsig, acc8);
+        mask_store<8>(acc8, dy, a.save + (long long)save_h(7) * P, a.grad + 6ll * 256 * P, P, voff, valid);
+    }
+    // ---- layers 6, 5 transposed: produce dY5, dY4
+#pragma unroll 1
+    for (int l = 6; l >= 5; --l) {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        zero_acc<8>(acc8);
+        gemm_regs<32, 8>(wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, dy, acc8);
+        mask_store<8>(acc8, dy, a.save + (long long)save_h(l) * P, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid);
+    }
+    // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots)
+    float denc[32];
+    {
+        zero_acc<10>(acc);
+        gemm_regs<32, 10>(wp + bwd_pack_off(4) / 4, lane, dy, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { denc[r] = acc[8][r]; denc[16 + r] = acc[9][r]; }
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        mask_store<8>(acc8, dy, a.save + (long long)save_h(4) * P, a.grad + 3ll * 256 * P, P, voff, valid);
+    }
+    // ---- layers 3, 2, 1 transposed: produce dY2, dY1, dY0
+#pragma unroll 1
+    for (int l = 3; l >= 1; --l) {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        zero_acc<8>(acc8);
+        gemm_regs<32, 8>(wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, dy, acc8);
+        mask_store<8>(acc8, dy, a.save + (long long)save_h(l) * P, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid);
+    }
+    if (!a.ray_grad) return;
+    // ---- layer 0 transposed: 256 -> 64 encoding slots
+    {
+        f32x16(&acc2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
+        zero_acc<2>(acc2);
+        gemm_regs<32, 2>(wp + bwd_pack_off(0) / 4, lane, dy, acc2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { denc[r] += acc2[0][r]; denc[16 + r] += acc2[1][r]; }
+    }
+    // ---- encodings -> point / direction -> ray gradients
+    float dp[3], du[3];
+    enc_backward<NIW_L3D, 8>(denc, a.save + (long long)kSaveEnc * P, P, voff, h, dp);
+    enc_backward<NIW_LVIEW, 4>(dvenc, a.save + (long long)kSaveVenc * P, P, voff, h, du);
+    const long long ri = mc / a.S;
+    const float d = a.depth[mc];
+    const float rx = a.ray[ri * 3], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];
+    const float nrm = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+    const float ux = rx / nrm, uy = ry / nrm, uz = rz / nrm;
+    const float dot = ux * du[0] + uy * du[1] + uz * du[2];
+    float gc[3] = {dp[0], dp[1], dp[2]};
+    float gr[3] = {dp[0] * d + (du[0] - ux * dot) / nrm, dp[1] * d + (du[1] - uy * dot) / nrm, dp[2] * d + (du[2] - uz * dot) / nrm};
+    if (!valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gc[c] = gr[c] = 0.f;
+    }
+    if (a.S % 32 == 0) {
+        // all 32 samples of the wave lie on one ray: reduce over the 32 lanes of a half first
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                gc[c] += __shfl_xor(gc[c], o);
+                gr[c] += __shfl_xor(gr[c], o);
+            }
+        }
+        if (lane == 0 && valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                atomicAdd(a.d_center + ri * 3 + c, gc[c]);
+                atomicAdd(a.d_ray + ri * 3 + c, gr[c]);
+            }
+        }
+    } else if (h == 0 && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicAdd(a.d_center + ri * 3 + c, gc[c]);
+            atomicAdd(a.d_ray + ri * 3 + c, gr[c]);
+        }
+    }
+}
+
+int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
+                          int64_t n_rays, int n_samples, int density_activ, const float* rgb, const float* d_rgb,
+                          const float* d_sigma, const float* save, float* gradws, float* d_center, float* d_ray,
+                          hipStream_t stream) {
+    MlpBwdArgs a;
+    a.packed = packed; a.center = center; a.ray = ray; a.depth = depth; a.rgb = rgb; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
+    a.save = save; a.grad = gradws; a.d_center = d_center; a.d_ray = d_ray;
+    a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
+    a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
+    mlp_bwd_dx_kernel<<<(int)(a.Mpad / 128), 256, 0, stream>>>(a);
+    NIW_LAUNCH_CHECK("niw_mlp_bwd (dX chain)");
+    return NIW_OK;
+}

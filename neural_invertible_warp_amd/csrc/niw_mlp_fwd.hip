@@ -1,0 +1,304 @@
+// Field MLP forward (points -> positional encoding -> 8x256 MLP -> density, colour) and the
+// weight re-packing kernel.  Replaces NeRF.forward_samples / NeRF.forward /
+// NeRF.positional_encoding (reference model/nerf.py:416-456, 476-483; c2f mask
+// model/barf_inn_llff.py:427-442) and camera.get_3D_points_from_depth (camera.py:517-521).
+//
+// Design (gfx950): every wave owns 32 samples and carries them through the whole network with
+// the activations held in registers.  The GEMM of a layer is computed transposed,
+//     out[n][m] = sum_k W[n][k] * act[k][m]       (A operand = W, B operand = act)
+// with v_mfma_f32_32x32x2_f32 (exact fp32).  The C/D fragment of that product (column m on the
+// lane, rows n in the 16 registers, rows (r&3)+8(r>>2)+4h) is, register for register, the B
+// fragment the next layer needs (k-slot 8q+4h+t <-> register 4q+t), so no LDS, no transposes
+// and no barriers are needed between layers.  Weights are pre-packed (niw_mlp_pack_weights)
+// into A-fragment order so that every weight load is one coalesced 1 KiB wave access served
+// from L2 (2.1 MB total, resident in every XCD's 4 MiB L2).
+#include "niw_common.h"
+#include "niw_mlp_device.h"
+
+using namespace niw;
+
+// ---------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ packed) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kPackedFloats) return;
+    float val = 0.f;
+    if (idx < kFwdPackFloats) {
+        int l = 0;
+        while (l + 1 < kLayers && idx >= fwd_pack_off(l + 1)) ++l;
+        int local = idx - fwd_pack_off(l);
+        int t = local & 3, lane = (local >> 2) & 63, blk = local >> 8;
+        int nb = blk % fwd_nb(l), q = blk / fwd_nb(l);
+        int i = lane & 31, h = lane >> 5;
+        int row = out_row(l, nb * 32 + i), col = fwd_slot_col(l, 8 * q + 4 * h + t);
+        if (row >= 0 && col >= 0) val = params[weight_off(l) + row * layer_k(l) + col];
+    } else if (idx < kBiasPackOff) {
+        int l = 0;
+        while (l + 1 < kLayers && idx >= bwd_pack_off(l + 1)) ++l;
+        int local = idx - bwd_pack_off(l);
+        int t = local & 3, lane = (local >> 2) & 63, blk = local >> 8;
+        int ob = blk % bwd_ob(l), rb = blk / bwd_ob(l);
+        int i = lane & 31, h = lane >> 5;
+        int row = out_row(l, rb * 8 + 4 * h + t), col = fwd_slot_col(l, ob * 32 + i);
+        if (row >= 0 && col >= 0) val = params[weight_off(l) + row * layer_k(l) + col];
+    } else {
+        int l = 0;
+        while (l + 1 < kLayers && idx >= bias_pack_off(l + 1)) ++l;
+        int local = idx - bias_pack_off(l);
+        int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
+        int row = out_row(l, nb * 32 + acc_row(r, h));
+        if (row >= 0) val = params[bias_off(l) + row];
+    }
+    packed[idx] = val;
+}
+
+// ---------------------------------------------------------------------------------------
+// positional encoding in MFMA slot order
+// ---------------------------------------------------------------------------------------
+// band frequency 2^k * fp32(pi)  (reference: 2**arange(L) * np.pi evaluated in fp32)
+
+// One sincos pair (compile-time pair index per lane half, selected by h).
+template <int L>
+__device__ __forceinline__ void enc_pair(const float (&p)[3], const float* __restrict__ w, int h, int pair0, int pair1,
+                                         float& s_out, float& c_out) {
+    // pair index -> (coordinate, band); pairs >= 3L are zero padding
+    const bool valid0 = pair0 < 3 * L, valid1 = pair1 < 3 * L;
+    const int c0 = valid0 ? pair0 / L : 0, k0 = valid0 ? pair0 % L : 0;
+    const int c1 = valid1 ? pair1 / L : 0, k1 = valid1 ? pair1 % L : 0;
+    const float x = h ? p[c1] : p[c0];
+    const float f = h ? band_freq(k1) : band_freq(k0);
+    const float wk = h ? w[k1] : w[k0];
+    const float arg = __fmul_rn(x, f);          // separate fp32 rounding of x*freq, as the reference
+    float s, c;
+    sincosf(arg, &s, &c);
+    const bool valid = h ? valid1 : valid0;
+    s_out = valid ? s * wk : 0.f;
+    c_out = valid ? c * wk : 0.f;
+}
+
+// enc[4q+t] = feature of slot 8q+4h+t for this lane's half h
+template <int L, int NQ>
+__device__ __forceinline__ void encode_slots(const float (&p)[3], const float* __restrict__ w, int h, float (&enc)[4 * NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        // combo g = 2q + h; g == 0: raw coordinates; else pairs 2(g-1), 2(g-1)+1
+        const int pa0 = 2 * (2 * q - 1), pa1 = 2 * (2 * q);      // first pair for h = 0 / h = 1
+        float s0, c0, s1, c1;
+        if (q == 0) {
+            enc_pair<L>(p, w, 1, 0, 0, s0, c0);                   // only h = 1 lanes use these
+            enc_pair<L>(p, w, 1, 1, 1, s1, c1);
+            enc[0] = h ? s0 : p[0];
+            enc[1] = h ? c0 : p[1];
+            enc[2] = h ? s1 : p[2];
+            enc[3] = h ? c1 : 0.f;
+        } else {
+            enc_pair<L>(p, w, h, pa0, pa1, s0, c0);
+            enc_pair<L>(p, w, h, pa0 + 1, pa1 + 1, s1, c1);
+            enc[4 * q + 0] = s0;
+            enc[4 * q + 1] = c0;
+            enc[4 * q + 2] = s1;
+            enc[4 * q + 3] = c1;
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_bias(const float* __restrict__ bp, int h, f32x16 (&acc)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(bp + (nb * 2 + h) * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = src[g];
+            acc[nb][4 * g + 0] = v[0];
+            acc[nb][4 * g + 1] = v[1];
+            acc[nb][4 * g + 2] = v[2];
+            acc[nb][4 * g + 3] = v[3];
+        }
+    }
+}
+
+// Saved tensors are feature-major [rows][Mpad].  Row of (nb, r, h) = nb*32 + (r&3) + 8(r>>2) + 4h:
+// the lane-dependent part (4h rows + sample m) is folded into ONE 32-bit element offset `voff`
+// so that every store is scalar-base + vector-offset (no per-store 64-bit address registers).
+template <int NB, bool SAVE>
+__device__ __forceinline__ void relu_store(const f32x16 (&acc)[NB], float (&act)[16 * NB], float* __restrict__ save_row0,
+                                           long long mpad, unsigned voff) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = fmaxf(acc[nb][r], 0.f);
+            act[nb * 16 + r] = v;
+            if (SAVE) {
+                float* __restrict__ rowp = save_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad;
+                rowp[voff] = v;
+            }
+        }
+    }
+}
+
+struct MlpFwdArgs {
+    const float* packed;
+    const float* center;
+    const float* ray;
+    const float* depth;
+    const float* noise;
+    float* rgb;
+    float* sigma;
+    float* save;
+    long long M, Mpad;
+    int S, act;
+    float w3d[NIW_L3D];
+    float wview[NIW_LVIEW];
+};
+
+__device__ __forceinline__ float density_act(float x, int kind) {
+    if (kind == NIW_ACT_RELU) return fmaxf(x, 0.f);
+    return x > 20.f ? x : log1pf(expf(x));      // F.softplus(beta=1, threshold=20)
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool valid = m < a.M;
+    const long long mc = valid ? m : a.M - 1;
+    const long long ri = mc / a.S;
+
+    // ---- sample point and unit view direction (camera.py:517-521, nerf.py:452)
+    float p[3], u[3];
+    {
+        const float d = a.depth[mc];
+        const float rx = a.ray[ri * 3 + 0], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];
+        p[0] = __fadd_rn(a.center[ri * 3 + 0], __fmul_rn(rx, d));
+        p[1] = __fadd_rn(a.center[ri * 3 + 1], __fmul_rn(ry, d));
+        p[2] = __fadd_rn(a.center[ri * 3 + 2], __fmul_rn(rz, d));
+        const float nrm = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+        u[0] = rx / nrm; u[1] = ry / nrm; u[2] = rz / nrm;
+    }
+    float enc[32], venc[16];
+    encode_slots<NIW_L3D, 8>(p, a.w3d, h, enc);
+    encode_slots<NIW_LVIEW, 4>(u, a.wview, h, venc);
+    const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);     // host guarantees 5*Mpad < 2^30
+    if (SAVE) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) (a.save + (long long)(kSaveEnc + 8 * (i >> 2) + (i & 3)) * a.Mpad)[voff] = enc[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) (a.save + (long long)(kSaveVenc + 8 * (i >> 2) + (i & 3)) * a.Mpad)[voff] = venc[i];
+    }
+
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
+    float act[128];
+    f32x16 acc[9];
+
+    // ---- layer 0: 63 -> 256
+    {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        load_bias<8>(a.packed + bias_pack_off(0), h, acc8);
+        gemm_regs<8, 8>(wp + fwd_pack_off(0) / 4, lane, enc, acc8);
+        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(1) * a.Mpad : nullptr, a.Mpad, voff);
+    }
+    // ---- layers 1..3
+#pragma unroll 1
+    for (int l = 1; l <= 3; ++l) {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        load_bias<8>(a.packed + bias_pack_off(1) + (l - 1) * 256, h, acc8);
+        gemm_regs<32, 8>(wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, act, acc8);
+        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(l + 1) * a.Mpad : nullptr, a.Mpad, voff);
+    }
+    // ---- layer 4: cat[feat, points_enc] (319) -> 256
+    {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        load_bias<8>(a.packed + bias_pack_off(4), h, acc8);
+        gemm_regs<32, 8>(wp + fwd_pack_off(4) / 4, lane, act, acc8);
+        gemm_regs<8, 8>(wp + fwd_pack_off(4) / 4 + 32 * 8 * 64, lane, enc, acc8);
+        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(5) * a.Mpad : nullptr, a.Mpad, voff);
+    }
+    // ---- layers 5, 6
+#pragma unroll 1
+    for (int l = 5; l <= 6; ++l) {
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        load_bias<8>(a.packed + bias_pack_off(5) + (l - 5) * 256, h, acc8);
+        gemm_regs<32, 8>(wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, act, acc8);
+        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(l + 1) * a.Mpad : nullptr, a.Mpad, voff);
+    }
+    // ---- layer 7: 256 -> 256 features (+ density row 256)
+    float sig_raw;
+    {
+        load_bias<9>(a.packed + bias_pack_off(7), h, acc);
+        gemm_regs<32, 9>(wp + fwd_pack_off(7) / 4, lane, act, acc);
+        sig_raw = acc[8][0];                                   // kernel row 256: register 0 of half 0
+        if (a.noise != nullptr) sig_raw += a.noise[mc];
+        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)kSaveFeat * a.Mpad : nullptr, a.Mpad, voff);
+        if (h == 0) {
+            if (SAVE) (a.save + (long long)kSaveSigma * a.Mpad)[voff] = sig_raw;
+            if (valid) a.sigma[m] = density_act(sig_raw, a.act);
+        }
+    }
+    // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
+    float hr[64];
+    {
+        f32x16(&acc4)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
+        load_bias<4>(a.packed + bias_pack_off(8), h, acc4);
+        gemm_regs<32, 4>(wp + fwd_pack_off(8) / 4, lane, act, acc4);
+        gemm_regs<4, 4>(wp + fwd_pack_off(8) / 4 + 32 * 4 * 64, lane, venc, acc4);
+        relu_store<4, SAVE>(acc4, hr, SAVE ? a.save + (long long)kSaveHr * a.Mpad : nullptr, a.Mpad, voff);
+    }
+    // ---- colour layer 1: 128 -> 3, sigmoid
+    {
+        f32x16(&acc1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
+        load_bias<1>(a.packed + bias_pack_off(9), h, acc1);
+        gemm_regs<16, 1>(wp + fwd_pack_off(9) / 4, lane, hr, acc1);
+        if (h == 0 && valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-acc1[0][c]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" int64_t niw_mlp_padded_rows(int64_t n_rays, int n_samples) {
+    int64_t m = n_rays * (int64_t)n_samples;
+    return (m + 127) / 128 * 128;
+}
+
+extern "C" int64_t niw_mlp_packed_floats(void) { return kPackedFloats; }
+
+extern "C" int niw_mlp_pack_weights(const float* params, float* packed, niw_stream_t stream) {
+    NIW_REQUIRE(params && packed, "niw_mlp_pack_weights: null pointer");
+    const int threads = 256, blocks = (kPackedFloats + threads - 1) / threads;
+    pack_weights_kernel<<<blocks, threads, 0, (hipStream_t)stream>>>(params, packed);
+    NIW_LAUNCH_CHECK("niw_mlp_pack_weights");
+    return NIW_OK;
+}
+
+extern "C" int niw_mlp_fwd(const float* packed, const float* params, const float* center, const float* ray,
+                           const float* depth, const float* noise, int64_t n_rays, int n_samples,
+                           const float* band_w3d, const float* band_wview, int density_activ,
+                           float* rgb, float* sigma, float* save, niw_stream_t stream) {
+    (void)params;
+    NIW_REQUIRE(packed && center && ray && depth && rgb && sigma, "niw_mlp_fwd: null pointer");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_fwd: n_rays=%lld n_samples=%d must be positive", (long long)n_rays, n_samples);
+    NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 27), "niw_mlp_fwd: too many samples per call (%lld)", (long long)(n_rays * n_samples));
+    NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_fwd: unknown density activation %d", density_activ);
+    MlpFwdArgs a;
+    a.packed = packed; a.center = center; a.ray = ray; a.depth = depth; a.noise = noise;
+    a.rgb = rgb; a.sigma = sigma; a.save = save;
+    a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
+    a.S = n_samples; a.act = density_activ;
+    for (int i = 0; i < NIW_L3D; ++i) a.w3d[i] = band_w3d ? band_w3d[i] : 1.f;
+    for (int i = 0; i < NIW_LVIEW; ++i) a.wview[i] = band_wview ? band_wview[i] : 1.f;
+    const int blocks = (int)(a.Mpad / 128);
+    if (save)
+        mlp_fwd_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    else
+        mlp_fwd_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    NIW_LAUNCH_CHECK("niw_mlp_fwd");
+    return NIW_OK;
+}

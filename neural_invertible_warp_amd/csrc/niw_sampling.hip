@@ -1,0 +1,234 @@
+// Depth sampling (stratified + inverse-CDF resampling + merge), ray generation, photometric
+// loss and the Adam update.  All are tiny next to the field MLP; they exist so that the whole
+// step stays on the device without host round trips.
+#include "niw_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- S1: Graph.sample_depth (nerf.py:334-344)
+__global__ void sample_stratified_kernel(const float* __restrict__ u, long long n, int S, float dmin, float dmax, int inverse,
+                                         float* __restrict__ depth) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = (int)(i % S);
+    const float r = (u ? u[i] : 0.5f) + (float)s;
+    // rand_samples / S * (max - min) + min, each op rounded on its own
+    float d = __fadd_rn(__fmul_rn(__fdiv_rn(r, (float)S), dmax - dmin), dmin);
+    if (inverse) d = __fdiv_rn(1.f, __fadd_rn(d, 1e-8f));
+    depth[i] = d;
+}
+
+// ---------------------------------------------------------------- H1 + H2: nerf.py:346-365, 313-315
+// One wave per ray.  cdf in LDS (accumulated sequentially in fp64 and rounded per element, the
+// arithmetic of the CPU reference's cumsum), Sf binary searches, then a rank sort of the S+Sf
+// depths (ties broken by position) which reproduces an ascending sort exactly.
+__global__ __launch_bounds__(256) void sample_pdf_merge_kernel(const float* __restrict__ pdf, const float* __restrict__ coarse,
+                                                               const float* __restrict__ unif, const float* __restrict__ bins,
+                                                               long long n_rays, int S, int Sf, float* __restrict__ fine_out,
+                                                               float* __restrict__ merged) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 4 + wv;
+    const int n = S + Sf;
+    float* cdf = smem + wv * (S + 1 + n);
+    float* val = cdf + S + 1;
+    if (r >= n_rays) return;
+    if (lane == 0) {
+        double acc = 0.0;
+        cdf[0] = 0.f;
+        for (int i = 0; i < S; ++i) {
+            acc += (double)pdf[r * S + i];
+            cdf[i + 1] = (float)acc;
+        }
+    }
+    for (int i = lane; i < S; i += 64) val[i] = coarse[r * S + i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int jf = lane; jf < Sf; jf += 64) {
+        const float uu = unif[jf];
+        // searchsorted(cdf, u, right=True): first index with cdf[idx] > u, in [0, S+1]
+        int lo = 0, hi = S + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > uu) hi = mid; else lo = mid + 1;
+        }
+        const int il = max(lo - 1, 0), ih = min(lo, S);
+        const float cl = cdf[il], ch = cdf[ih], dl = bins[il], dh = bins[ih];
+        const float t = __fdiv_rn(uu - cl, __fadd_rn(ch - cl, 1e-8f));
+        const float d = __fadd_rn(dl, __fmul_rn(t, dh - dl));
+        val[S + jf] = d;
+        if (fine_out) fine_out[r * Sf + jf] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int e = lane; e < n; e += 64) {
+        const float v = val[e];
+        int rank = 0;
+        for (int k = 0; k < n; ++k) {
+            const float o = val[k];
+            rank += (o < v) || (o == v && k < e);
+        }
+        merged[r * n + rank] = v;
+    }
+}
+
+// ---------------------------------------------------------------- R1 / R2: camera.py:359-390, 419-443
+__device__ __forceinline__ void inv3x3(const float* __restrict__ K, float (&o)[9]) {
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C, id = 1.0 / det;
+    o[0] = (float)(A * id); o[1] = (float)(-(b * i - c * h) * id); o[2] = (float)((b * f - c * e) * id);
+    o[3] = (float)(B * id); o[4] = (float)((a * i - c * g) * id);  o[5] = (float)(-(a * f - c * d) * id);
+    o[6] = (float)(C * id); o[7] = (float)(-(a * h - b * g) * id); o[8] = (float)((a * e - b * d) * id);
+}
+
+__global__ void raygen_kernel(const float* __restrict__ intr, const float* __restrict__ pose, const int64_t* __restrict__ ray_idx,
+                              int B, long long R, int H, int W, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * R) return;
+    const int b = (int)(i / R);
+    const long long r = i % R;
+    const long long pix = ray_idx ? ray_idx[r] : r;
+    const float x = (float)(pix % W) + 0.5f, y = (float)(pix / W) + 0.5f;
+    float Ki[9];
+    inv3x3(intr + b * 9, Ki);
+    float g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = Ki[k * 3] * x + Ki[k * 3 + 1] * y + Ki[k * 3 + 2];
+    float c[3] = {0.f, 0.f, 0.f};
+    if (pose) {
+        // cam2world: X_hom @ [R^T | -R^T t]^T  (pose is world->camera, camera.py:89-95, 343-346)
+        const float* P = pose + b * 12;
+        float gw[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float tk = -(P[0 * 4 + k] * P[3] + P[1 * 4 + k] * P[7] + P[2 * 4 + k] * P[11]);
+            gw[k] = P[0 * 4 + k] * g[0] + P[1 * 4 + k] * g[1] + P[2 * 4 + k] * g[2] + tk;
+            c[k] = tk;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = gw[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out_a[i * 3 + k] = c[k];
+        out_b[i * 3 + k] = mode == 1 ? g[k] - c[k] : g[k];
+    }
+}
+
+// ---------------------------------------------------------------- R3: camera.convert_NDC (camera.py:523-540)
+__global__ void ndc_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ intr,
+                           int B, long long R, float near, float* __restrict__ oc, float* __restrict__ orr) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * R) return;
+    const int b = (int)(i / R);
+    const float rx = ray[i * 3], ry = ray[i * 3 + 1], rz = ray[i * 3 + 2];
+    const float t = (near - center[i * 3 + 2]) / rz;
+    const float cx = center[i * 3] + t * rx, cy = center[i * 3 + 1] + t * ry, cz = center[i * 3 + 2] + t * rz;
+    const float sx = intr[b * 9 + 0] / intr[b * 9 + 2], sy = intr[b * 9 + 4] / intr[b * 9 + 5];
+    oc[i * 3] = sx * (cx / cz); oc[i * 3 + 1] = sy * (cy / cz); oc[i * 3 + 2] = 1.f - 2.f * near / cz;
+    orr[i * 3] = sx * (rx / rz - cx / cz); orr[i * 3 + 1] = sy * (ry / rz - cy / cz); orr[i * 3 + 2] = 2.f * near / cz;
+}
+
+// ---------------------------------------------------------------- L1: MSE (base.py:209-211) + gather (nerf.py:279-281)
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ image,
+                                                  const int64_t* __restrict__ ray_idx, int B, long long R, long long hw,
+                                                  double n_norm, float grad_scale, float* __restrict__ loss, float* __restrict__ d_rgb) {
+    __shared__ float red[4];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float sq = 0.f;
+    if (i < (long long)B * R * 3) {
+        const int c = (int)(i % 3);
+        const long long br = i / 3, b = br / R, r = br % R;
+        const long long pix = ray_idx ? ray_idx[r] : r;
+        const float diff = rgb[i] - image[(b * 3 + c) * hw + pix];
+        sq = diff * diff;
+        if (d_rgb) d_rgb[i] = (float)((double)grad_scale * 2.0 * (double)diff / n_norm);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (float)((double)(red[0] + red[1] + red[2] + red[3]) / n_norm));
+}
+
+// ---------------------------------------------------------------- torch.optim.Adam (single tensor, no amsgrad / weight decay)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;        // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+extern "C" int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, float depth_min, float depth_max,
+                                     int inverse, float* depth, niw_stream_t stream) {
+    NIW_REQUIRE(depth, "niw_sample_stratified: null output");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_sample_stratified: empty input");
+    const long long n = n_rays * (long long)n_samples;
+    sample_stratified_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, n, n_samples, depth_min, depth_max, inverse, depth);
+    NIW_LAUNCH_CHECK("niw_sample_stratified");
+    return NIW_OK;
+}
+
+extern "C" int niw_sample_pdf_merge(const float* pdf, const float* depth_coarse, const float* unif, const float* bins,
+                                    int64_t n_rays, int n_samples, int n_fine, float* depth_fine, float* depth_merged,
+                                    niw_stream_t stream) {
+    NIW_REQUIRE(pdf && depth_coarse && unif && bins && depth_merged, "niw_sample_pdf_merge: null pointer");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0 && n_fine > 0, "niw_sample_pdf_merge: empty input");
+    NIW_REQUIRE(n_samples + n_fine <= 1024, "niw_sample_pdf_merge: S+Sf=%d exceeds 1024", n_samples + n_fine);
+    const size_t lds = 4 * (size_t)(n_samples + 1 + n_samples + n_fine) * sizeof(float);
+    sample_pdf_merge_kernel<<<(int)((n_rays + 3) / 4), 256, lds, (hipStream_t)stream>>>(pdf, depth_coarse, unif, bins, n_rays, n_samples,
+                                                                                       n_fine, depth_fine, depth_merged);
+    NIW_LAUNCH_CHECK("niw_sample_pdf_merge");
+    return NIW_OK;
+}
+
+extern "C" int niw_raygen(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, int64_t n_rays_per_view,
+                          int H, int W, int mode, float* out_a, float* out_b, niw_stream_t stream) {
+    NIW_REQUIRE(intr && out_a && out_b, "niw_raygen: null pointer");
+    NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && H > 0 && W > 0, "niw_raygen: empty input");
+    NIW_REQUIRE(mode == 0 || (mode == 1 && pose), "niw_raygen: mode %d needs a pose", mode);
+    NIW_REQUIRE(ray_idx || n_rays_per_view == (int64_t)H * W, "niw_raygen: without ray_idx the ray count must be H*W");
+    const long long n = (long long)n_views * n_rays_per_view;
+    raygen_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(intr, pose, ray_idx, n_views, n_rays_per_view, H, W, mode, out_a, out_b);
+    NIW_LAUNCH_CHECK("niw_raygen");
+    return NIW_OK;
+}
+
+extern "C" int niw_convert_ndc(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view,
+                               float near, float* center_ndc, float* ray_ndc, niw_stream_t stream) {
+    NIW_REQUIRE(center && ray && intr && center_ndc && ray_ndc, "niw_convert_ndc: null pointer");
+    NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0, "niw_convert_ndc: empty input");
+    const long long n = (long long)n_views * n_rays_per_view;
+    ndc_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(center, ray, intr, n_views, n_rays_per_view, near, center_ndc, ray_ndc);
+    NIW_LAUNCH_CHECK("niw_convert_ndc");
+    return NIW_OK;
+}
+
+extern "C" int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx, int n_views,
+                               int64_t n_rays_per_view, int64_t hw, double n_norm, float grad_scale,
+                               float* loss, float* d_rgb, niw_stream_t stream) {
+    NIW_REQUIRE(rgb && image && loss, "niw_mse_fwd_bwd: null pointer");
+    NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && hw > 0 && n_norm > 0, "niw_mse_fwd_bwd: empty input");
+    const long long n = (long long)n_views * n_rays_per_view * 3;
+    mse_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(rgb, image, ray_idx, n_views, n_rays_per_view, hw, n_norm, grad_scale, loss, d_rgb);
+    NIW_LAUNCH_CHECK("niw_mse_fwd_bwd");
+    return NIW_OK;
+}
+
+extern "C" int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, int step, niw_stream_t stream) {
+    NIW_REQUIRE(param && grad && exp_avg && exp_avg_sq, "niw_adam_step: null pointer");
+    NIW_REQUIRE(n > 0 && step >= 1, "niw_adam_step: n=%lld step=%d", (long long)n, step);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    adam_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+    NIW_LAUNCH_CHECK("niw_adam_step");
+    return NIW_OK;
+}

@@ -1,0 +1,394 @@
+// NVP invertible warp: per-point part of DeformNetwork.forward / .inverse (reference
+// model/nvp/nvp_ndr.py:365-468, 471-567) with the annealed embedder (model/nvp/embedder.py:41-50).
+//
+// Three coupling blocks, form 0, focus axis z, y, x (nvp_ndr.py:389-399).  Per block:
+//   part a:  focus' = focus - head_a( softplus100( W_a . emb26(other) + view_bias_a ) )
+//   part b:  (theta, t) = head_b( softplus100( W_b . emb13(focus') + view_bias_b ) )
+//            other' = [[cos, sin], [-sin, cos]] (other - t)                 (euler2rot_2dinv, :166-174)
+// The 128 latent columns of the first layers are per-view constants and arrive folded into
+// `view_b` (computed by the host mirror together with weight-norm), so a point costs
+// 3 * 128 * (26 + 13) MACs instead of 3 * 128 * (154 + 141).
+//
+// Forward / inverse: one thread per point, one view per blockIdx.y, first-layer weights of all
+// blocks staged once in LDS (69 KB) and read as broadcasts.
+// Backward: the same thread-per-point kernel walks the blocks in reverse for d(points) and
+// writes, feature-major, the per-point factors of every parameter gradient (pre-activation
+// gradients, embeddings, hidden activations, head gradients, view indicator rows); the
+// parameter gradients themselves are then three batched NT GEMMs over the points on the
+// fp32 MFMA path (niw_dw_gemm.hip) -- no atomics, deterministic.
+#include "niw_common.h"
+
+int niw_launch_nt_gemm(int wide, const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB,
+                       long long mpad, int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st);
+
+namespace {
+
+constexpr int kHid = 128, kEa = 26, kEb = 13, kNF = 6;
+constexpr int kWembBlock = kHid * (kEa + kEb);          // 4992 floats per coupling block
+constexpr int kHeadBlock = kHid + 1 + 3 * kHid + 3;      // 516
+constexpr float kPi32 = 3.14159274101257324f;            // fp32(pi): the band table is an fp32 tensor (embedder.py:26)
+
+// workspace rows per coupling block (feature-major [rows][Ppad], Ppad = all views' points)
+constexpr int kRowGa = 0, kRowGb = 128;                  // A1: pre-activation gradients, parts a / b
+constexpr int kRowEa = 256, kRowEb = 288, kRowInd = 320; // B1: embeddings (26 of 32, 13 of 32) and 64 view indicator rows
+constexpr int kRowHa = 384, kRowHb = 512;                // A2: hidden activations
+constexpr int kRowGo = 640;                              // B2: head gradients (d delta, d theta, d t0, d t1)
+constexpr int kRowsPerBlock = 644;
+
+__device__ __forceinline__ float softplus100(float x) {
+    const float z = 100.f * x;
+    return z > 20.f ? x : log1pf(expf(z)) / 100.f;
+}
+__device__ __forceinline__ float dsoftplus100(float x) {
+    const float z = 100.f * x;
+    return z > 20.f ? 1.f : 1.f / (1.f + expf(-z));
+}
+
+// embedding of D inputs: [x (D), then per band sin(D), cos(D)], times ps * cw[band]
+template <int D>
+__device__ __forceinline__ void embed(const float (&x)[D], const float* __restrict__ cw, float ps, float (&e)[D * (1 + 2 * kNF)]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) e[d] = ps * x[d];
+#pragma unroll
+    for (int i = 0; i < kNF; ++i) {
+        const float f = kPi32 * (float)(1 << i), w = ps * cw[i];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float s, c;
+            sincosf(__fmul_rn(x[d], f), &s, &c);
+            e[D * (1 + 2 * i) + d] = w * s;
+            e[D * (2 + 2 * i) + d] = w * c;
+        }
+    }
+}
+// gradient of the embedding w.r.t. its inputs given d(e); uses the embedding values themselves
+template <int D>
+__device__ __forceinline__ void embed_bwd(const float (&e)[D * (1 + 2 * kNF)], const float (&ge)[D * (1 + 2 * kNF)], float ps,
+                                          float (&gx)[D]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) gx[d] = ps * ge[d];
+#pragma unroll
+    for (int i = 0; i < kNF; ++i) {
+        const float f = kPi32 * (float)(1 << i);
+#pragma unroll
+        for (int d = 0; d < D; ++d)   // d(w sin)/dx = f (w cos),  d(w cos)/dx = -f (w sin)
+            gx[d] += f * (ge[D * (1 + 2 * i) + d] * e[D * (2 + 2 * i) + d] - ge[D * (2 + 2 * i) + d] * e[D * (1 + 2 * i) + d]);
+    }
+}
+
+template <int E>
+__device__ __forceinline__ float dot_row(const float* __restrict__ w, const float (&e)[E]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < E; ++c) s += w[c] * e[c];
+    return s;
+}
+
+struct WarpArgs {
+    const float* w_emb;
+    const float* view_b;
+    const float* w_head;
+    const float* pts;
+    const float* ps_a;
+    const float* ps_b;
+    const float* d_out;
+    float* out;
+    float* d_pts;
+    float* ws;
+    long long n_pts, ppad;
+    int n_views, inverse;
+    float cw[kNF];
+};
+
+__device__ __forceinline__ void stage_weights(const WarpArgs& a, float* lw, float* lh, float* lv, int view) {
+    for (int i = threadIdx.x; i < 3 * kWembBlock; i += blockDim.x) lw[i] = a.w_emb[i];
+    for (int i = threadIdx.x; i < 3 * kHeadBlock; i += blockDim.x) lh[i] = a.w_head[i];
+    for (int i = threadIdx.x; i < 3 * 2 * kHid; i += blockDim.x) lv[i] = a.view_b[(long long)view * 3 * 2 * kHid + i];
+    __syncthreads();
+}
+
+// part a: delta = head_a(softplus(W_a e + v_a))
+__device__ __forceinline__ float part_a(const float* lw, const float* lh, const float* lv, int b, const float (&ea)[kEa]) {
+    const float* W = lw + b * kWembBlock;
+    const float* hd = lh + b * kHeadBlock;
+    const float* vb = lv + (b * 2 + 0) * kHid;
+    float delta = hd[kHid];
+    for (int u = 0; u < kHid; ++u) delta += hd[u] * softplus100(vb[u] + dot_row<kEa>(W + u * kEa, ea));
+    return delta;
+}
+// part b: (theta, t0, t1) = head_b(softplus(W_b e + v_b))
+__device__ __forceinline__ void part_b(const float* lw, const float* lh, const float* lv, int b, const float (&eb)[kEb], float (&o)[3]) {
+    const float* W = lw + b * kWembBlock + kHid * kEa;
+    const float* hd = lh + b * kHeadBlock + kHid + 1;
+    const float* vb = lv + (b * 2 + 1) * kHid;
+    o[0] = hd[3 * kHid]; o[1] = hd[3 * kHid + 1]; o[2] = hd[3 * kHid + 2];
+    for (int u = 0; u < kHid; ++u) {
+        const float hh = softplus100(vb[u] + dot_row<kEb>(W + u * kEb, eb));
+        o[0] += hd[u] * hh; o[1] += hd[kHid + u] * hh; o[2] += hd[2 * kHid + u] * hh;
+    }
+}
+
+__device__ __forceinline__ void axes(int b, int& f, int& o0, int& o1) {
+    f = 2 - b;                        // focus z, y, x
+    o0 = b == 2 ? 1 : 0;
+    o1 = b == 0 ? 1 : 2;
+}
+
+__device__ __forceinline__ void block_fwd(const float* lw, const float* lh, const float* lv, const float* cw, float psa, float psb,
+                                          int b, float (&x)[3]) {
+    int f, o0, o1;
+    axes(b, f, o0, o1);
+    const float oth[2] = {x[o0], x[o1]};
+    float ea[kEa];
+    embed<2>(oth, cw, psa, ea);
+    const float foc[1] = {x[f] - part_a(lw, lh, lv, b, ea)};
+    float eb[kEb], o[3];
+    embed<1>(foc, cw, psb, eb);
+    part_b(lw, lh, lv, b, eb, o);
+    float s, c;
+    sincosf(o[0], &s, &c);
+    const float d0 = oth[0] - o[1], d1 = oth[1] - o[2];
+    x[f] = foc[0];
+    x[o0] = c * d0 + s * d1;
+    x[o1] = -s * d0 + c * d1;
+}
+
+__device__ __forceinline__ void block_inv(const float* lw, const float* lh, const float* lv, const float* cw, float psa, float psb,
+                                          int b, float (&x)[3]) {
+    int f, o0, o1;
+    axes(b, f, o0, o1);
+    const float single[1] = {x[f]};
+    float eb[kEb], o[3];
+    embed<1>(single, cw, psb, eb);
+    part_b(lw, lh, lv, b, eb, o);
+    float s, c;
+    sincosf(o[0], &s, &c);                            // euler2rot_2d: [[cos, -sin], [sin, cos]]
+    const float pr[2] = {c * x[o0] - s * x[o1] + o[1], s * x[o0] + c * x[o1] + o[2]};
+    float ea[kEa];
+    embed<2>(pr, cw, psa, ea);
+    x[f] = single[0] + part_a(lw, lh, lv, b, ea);
+    x[o0] = pr[0];
+    x[o1] = pr[1];
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lw = lds;
+    float* lh = lw + 3 * kWembBlock;
+    float* lv = lh + 3 * kHeadBlock;
+    const int view = blockIdx.y;
+    stage_weights(a, lw, lh, lv, view);
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pts) return;
+    const long long gi = (long long)view * a.n_pts + p;
+    float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
+    const float psa = a.ps_a ? a.ps_a[p] : 1.f, psb = a.ps_b ? a.ps_b[p] : 1.f;
+    if (!a.inverse) {
+        for (int b = 0; b < 3; ++b) block_fwd(lw, lh, lv, a.cw, psa, psb, b, x);
+    } else {
+        for (int b = 2; b >= 0; --b) block_inv(lw, lh, lv, a.cw, psa, psb, b, x);
+    }
+    a.out[gi * 3] = x[0]; a.out[gi * 3 + 1] = x[1]; a.out[gi * 3 + 2] = x[2];
+}
+
+__global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lw = lds;
+    float* lh = lw + 3 * kWembBlock;
+    float* lv = lh + 3 * kHeadBlock;
+    const int view = blockIdx.y;
+    stage_weights(a, lw, lh, lv, view);
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pts) return;
+    const long long gi = (long long)view * a.n_pts + p;
+    const float psa = a.ps_a ? a.ps_a[p] : 1.f, psb = a.ps_b ? a.ps_b[p] : 1.f;
+    float xin[3][3];
+    {
+        float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
+        for (int b = 0; b < 3; ++b) {
+            xin[b][0] = x[0]; xin[b][1] = x[1]; xin[b][2] = x[2];
+            block_fwd(lw, lh, lv, a.cw, psa, psb, b, x);
+        }
+    }
+    float gx[3] = {a.d_out[gi * 3], a.d_out[gi * 3 + 1], a.d_out[gi * 3 + 2]};
+    for (int b = 2; b >= 0; --b) {
+        int f, o0, o1;
+        axes(b, f, o0, o1);
+        float* ws = a.ws + (long long)b * kRowsPerBlock * a.ppad + gi;     // column gi of this block's rows
+        const long long P = a.ppad;
+        const float* Wa = lw + b * kWembBlock;
+        const float* Wb = Wa + kHid * kEa;
+        const float* hda = lh + b * kHeadBlock;
+        const float* hdb = hda + kHid + 1;
+        const float* va = lv + (b * 2 + 0) * kHid;
+        const float* vb = lv + (b * 2 + 1) * kHid;
+        // ---- recompute the block forward
+        const float oth[2] = {xin[b][o0], xin[b][o1]};
+        float ea[kEa], eb[kEb], o[3];
+        embed<2>(oth, a.cw, psa, ea);
+        const float foc[1] = {xin[b][f] - part_a(lw, lh, lv, b, ea)};
+        embed<1>(foc, a.cw, psb, eb);
+        part_b(lw, lh, lv, b, eb, o);
+        float s, c;
+        sincosf(o[0], &s, &c);
+        const float d0 = oth[0] - o[1], d1 = oth[1] - o[2];
+        const float n0 = c * d0 + s * d1, n1 = -s * d0 + c * d1;
+        // ---- rotation / translation
+        const float g_n0 = gx[o0], g_n1 = gx[o1];
+        const float g_d0 = c * g_n0 - s * g_n1, g_d1 = s * g_n0 + c * g_n1;
+        const float go[3] = {g_n0 * n1 - g_n1 * n0, -g_d0, -g_d1};          // d theta, d t0, d t1
+        // ---- part b backward
+        float geb[kEb];
+#pragma unroll
+        for (int k = 0; k < kEb; ++k) geb[k] = 0.f;
+        for (int u = 0; u < kHid; ++u) {
+            const float pre = vb[u] + dot_row<kEb>(Wb + u * kEb, eb);
+            const float gh = hdb[u] * go[0] + hdb[kHid + u] * go[1] + hdb[2 * kHid + u] * go[2];
+            const float gp = gh * dsoftplus100(pre);
+            ws[(long long)(kRowGb + u) * P] = gp;
+            ws[(long long)(kRowHb + u) * P] = softplus100(pre);
+#pragma unroll
+            for (int k = 0; k < kEb; ++k) geb[k] += Wb[u * kEb + k] * gp;
+        }
+        float gfoc[1];
+        embed_bwd<1>(eb, geb, psb, gfoc);
+        const float g_foc = gx[f] + gfoc[0];          // d focus'
+        const float g_delta = -g_foc;
+        // ---- part a backward
+        float gea[kEa];
+#pragma unroll
+        for (int k = 0; k < kEa; ++k) gea[k] = 0.f;
+        for (int u = 0; u < kHid; ++u) {
+            const float pre = va[u] + dot_row<kEa>(Wa + u * kEa, ea);
+            const float gp = g_delta * hda[u] * dsoftplus100(pre);
+            ws[(long long)(kRowGa + u) * P] = gp;
+            ws[(long long)(kRowHa + u) * P] = softplus100(pre);
+#pragma unroll
+            for (int k = 0; k < kEa; ++k) gea[k] += Wa[u * kEa + k] * gp;
+        }
+        float goth[2];
+        embed_bwd<2>(ea, gea, psa, goth);
+        // ---- per-point factors of the parameter gradients
+#pragma unroll
+        for (int k = 0; k < 32; ++k) ws[(long long)(kRowEa + k) * P] = k < kEa ? ea[k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) ws[(long long)(kRowEb + k) * P] = k < kEb ? eb[k] : 0.f;
+        for (int v = 0; v < 64; ++v) ws[(long long)(kRowInd + v) * P] = v == view ? 1.f : 0.f;
+        ws[(long long)(kRowGo + 0) * P] = g_delta;
+        ws[(long long)(kRowGo + 1) * P] = go[0];
+        ws[(long long)(kRowGo + 2) * P] = go[1];
+        ws[(long long)(kRowGo + 3) * P] = go[2];
+        gx[f] = g_foc;
+        gx[o0] = g_d0 + goth[0];
+        gx[o1] = g_d1 + goth[1];
+    }
+    if (a.d_pts) { a.d_pts[gi * 3] = gx[0]; a.d_pts[gi * 3 + 1] = gx[1]; a.d_pts[gi * 3 + 2] = gx[2]; }
+}
+
+// reduce the partial tiles of the two GEMM families and scatter into d_w_emb / d_view_b / d_w_head
+__global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, const float* __restrict__ p2, int nsplit2,
+                                   int n_views, float* __restrict__ d_w_emb, float* __restrict__ d_view_b, float* __restrict__ d_w_head) {
+    const int b = blockIdx.y;                                   // coupling block
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int T1 = 256 * 256 + 256, T2 = 256 * 64 + 256;
+    if (idx < 256 * 256) {
+        const int r = idx >> 8, c = idx & 255;                  // r: [ga 0..127 | gb 128..255], c: [ea 0..31 | eb 32..63 | views 64..127]
+        const int part = r >> 7, u = r & 127;
+        float* dst = nullptr;
+        if (part == 0 && c < kEa) dst = d_w_emb + b * kWembBlock + u * kEa + c;
+        else if (part == 1 && c >= 32 && c < 32 + kEb) dst = d_w_emb + b * kWembBlock + kHid * kEa + u * kEb + (c - 32);
+        else if (c >= 64 && c < 64 + n_views) dst = d_view_b + ((long long)(c - 64) * 3 + b) * 2 * kHid + part * kHid + u;
+        if (!dst) return;
+        float s = 0.f;
+        const float* src = p1 + (long long)b * nsplit1 * T1 + idx;
+        for (int w = 0; w < nsplit1; ++w) s += src[(long long)w * T1];
+        *dst = s;
+    } else if (idx < 256 * 256 + 256 * 64 + 256) {
+        const int j = idx - 256 * 256;                          // tile 2: [ha 0..127 | hb 128..255] x [d delta, d theta, d t0, d t1, ...]
+        float* dst = nullptr;
+        if (j < 256 * 64) {
+            const int r = j >> 6, c = j & 63, u = r & 127;
+            if (r < 128 && c == 0) dst = d_w_head + b * kHeadBlock + u;
+            else if (r >= 128 && c >= 1 && c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + (c - 1) * kHid + u;
+        } else {
+            const int c = j - 256 * 64;                         // row sums of the head gradients = bias gradients
+            if (c == 0) dst = d_w_head + b * kHeadBlock + kHid;
+            else if (c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + 3 * kHid + (c - 1);
+        }
+        if (!dst) return;
+        float s = 0.f;
+        const float* src = p2 + (long long)b * nsplit2 * T2 + j;
+        for (int w = 0; w < nsplit2; ++w) s += src[(long long)w * T2];
+        *dst = s;
+    }
+}
+
+constexpr size_t kWarpLds = (3 * kWembBlock + 3 * kHeadBlock + 3 * 2 * kHid) * sizeof(float);
+
+int fill_args(WarpArgs& a, const float* w_emb, const float* view_b, const float* w_head, const float* pts, int n_views,
+              int64_t n_pts, const float* chan_w, const float* ps_a, const float* ps_b) {
+    NIW_REQUIRE(w_emb && view_b && w_head && pts, "niw_warp: null pointer");
+    NIW_REQUIRE(n_views > 0 && n_pts > 0, "niw_warp: empty input (views=%d, points=%lld)", n_views, (long long)n_pts);
+    a.w_emb = w_emb; a.view_b = view_b; a.w_head = w_head; a.pts = pts; a.ps_a = ps_a; a.ps_b = ps_b;
+    a.n_pts = n_pts; a.n_views = n_views;
+    for (int i = 0; i < kNF; ++i) a.cw[i] = chan_w ? chan_w[i] : 1.f;
+    return NIW_OK;
+}
+
+long long warp_ppad(int n_views, int64_t n_pts) { return ((long long)n_views * n_pts + 31) / 32 * 32; }
+
+}  // namespace
+
+static_assert(NIW_WARP_WEMB_FLOATS == 3 * kWembBlock && NIW_WARP_WHEAD_FLOATS == 3 * kHeadBlock, "header constants");
+
+extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                            int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
+                            int inverse, float* out, niw_stream_t stream) {
+    WarpArgs a{};
+    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, pt_scale_a, pt_scale_b);
+    if (rc != NIW_OK) return rc;
+    NIW_REQUIRE(out, "niw_warp_fwd: null output");
+    a.out = out; a.inverse = inverse;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(warp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
+    warp_fwd_kernel<<<dim3((unsigned)((n_pts + 255) / 256), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
+    NIW_LAUNCH_CHECK("niw_warp_fwd");
+    return NIW_OK;
+}
+
+extern "C" int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts) {
+    const long long ppad = warp_ppad(n_views, n_pts);
+    return 3ll * kRowsPerBlock * ppad + 3ll * 256 * (256 * 256 + 256) + 3ll * 256 * (256 * 64 + 256);
+}
+
+extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                            int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
+                            const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                            niw_stream_t stream) {
+    WarpArgs a{};
+    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, pt_scale_a, pt_scale_b);
+    if (rc != NIW_OK) return rc;
+    NIW_REQUIRE(d_out && workspace && d_w_emb && d_view_b && d_w_head, "niw_warp_bwd: null pointer");
+    NIW_REQUIRE(n_views <= 64, "niw_warp_bwd: at most 64 views per call (got %d)", n_views);
+    hipStream_t st = (hipStream_t)stream;
+    const long long ppad = warp_ppad(n_views, n_pts);
+    a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad;
+    // padded columns of the factor rows must be zero
+    if (ppad != (long long)n_views * n_pts)
+        hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(warp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
+    warp_bwd_kernel<<<dim3((unsigned)((n_pts + 255) / 256), n_views), 256, kWarpLds, st>>>(a);
+    NIW_LAUNCH_CHECK("niw_warp_bwd");
+    float* p1 = workspace + 3ll * kRowsPerBlock * ppad;
+    float* p2 = p1 + 3ll * 256 * (256 * 256 + 256);
+    const long long stride = (long long)kRowsPerBlock * ppad;
+    int ns1 = 0, ns2 = 0;
+    rc = niw_launch_nt_gemm(1, workspace + kRowGa * ppad, 256, stride, workspace + kRowEa * ppad, 128, stride, ppad, 3, p1, 0, &ns1, st);
+    if (rc != NIW_OK) return rc;
+    rc = niw_launch_nt_gemm(0, workspace + kRowHa * ppad, 256, stride, workspace + kRowGo * ppad, 4, stride, ppad, 3, p2, 2, &ns2, st);
+    if (rc != NIW_OK) return rc;
+    warp_reduce_kernel<<<dim3((256 * 256 + 256 * 64 + 256 + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, n_views, d_w_emb, d_view_b, d_w_head);
+    NIW_LAUNCH_CHECK("niw_warp_bwd (reduce)");
+    return NIW_OK;
+}

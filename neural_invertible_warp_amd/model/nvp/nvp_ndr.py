@@ -1,0 +1,122 @@
+"""Mirror of the reference's DeformNetwork (model/nvp/nvp_ndr.py:229-572) as constructed by
+the INN models (model/barf_inn_llff.py:54-55, model/pose_models/inn.py:23-27): same
+constructor arguments, parameter names (lin{b}_a_0.weight_g/.weight_v/.bias, lin{b}_a_1.*,
+lin{b}_b_0.*, lin{b}_b_1.*, lin{b}_c.*), initialisation and forward / inverse signatures.
+
+Split of the work: the per-parameter / per-view preprocessing (weight norm, code projection,
+latent half of the first layers: O(parameters), [B,128]-sized tensors) is expressed with torch
+ops so autograd delivers d weight_g / d weight_v / d lin_c / d latent; everything per point
+(embedding, coupling blocks, rotations; forward, inverse and backward) runs in niw_warp_*.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ... import ops
+from ..._lib import NiwError
+
+_HID, _LAT, _NF = 128, 128, 6
+
+
+class _WNLinear(torch.nn.Module):
+    """Linear layer under old-style nn.utils.weight_norm (dim=0): parameters weight_g [out,1],
+    weight_v [out,in], bias [out] (reference nvp_ndr.py:291-292)."""
+
+    def __init__(self, k_in, k_out, ori_in):
+        super().__init__()
+        v = torch.zeros(k_out, k_in)
+        torch.nn.init.normal_(v[:, :ori_in], 0.0, np.sqrt(2) / np.sqrt(k_out))      # nvp_ndr.py:278-282
+        self.weight_g = torch.nn.Parameter(v.norm(dim=1, keepdim=True))
+        self.weight_v = torch.nn.Parameter(v)
+        self.bias = torch.nn.Parameter(torch.zeros(k_out))
+
+    def weight(self):
+        return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
+
+
+def _zero_linear(k_in, k_out):
+    lin = torch.nn.Linear(k_in, k_out)
+    torch.nn.init.constant_(lin.bias, 0.0)
+    torch.nn.init.constant_(lin.weight, 0.0)
+    return lin
+
+
+def anneal_window(alpha_ratio, n_freq=_NF):
+    """reference model/nvp/embedder.py:47-49"""
+    return [(1.0 - math.cos(math.pi * max(min(alpha_ratio * n_freq - i, 1.0), 0.0))) * 0.5 for i in range(n_freq)]
+
+
+class DeformNetwork(torch.nn.Module):
+
+    def __init__(self, d_feature, d_in, d_out_1, d_out_2, n_blocks, d_hidden, n_layers, skip_in=(4,), multires=0,
+                 weight_norm=True, actfn="softplus", reference_exact=True):
+        super().__init__()
+        if not (d_feature == _LAT and d_in == 3 and d_out_1 == 1 and d_out_2 == 3 and n_blocks == 3 and d_hidden == _HID
+                and n_layers == 1 and len(skip_in) == 0 and multires == _NF and weight_norm and actfn == "softplus"):
+            raise NiwError("DeformNetwork: libniw_hip.so implements the configuration the reference models build "
+                           "(d_feature=128, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3, d_hidden=128, n_layers=1, skip_in=[], "
+                           "multires=6, weight_norm=True, actfn='softplus')")
+        self.n_blocks, self.skip_in = n_blocks, skip_in
+        self.reference_exact = reference_exact        # reproduce the dim-1 slicing of embedder.py:47
+        ea, eb = 2 * (1 + 2 * multires), 1 + 2 * multires
+        for b in range(n_blocks):
+            setattr(self, f"lin{b}_a_0", _WNLinear(ea + d_feature, d_hidden, ori_in=2))
+            setattr(self, f"lin{b}_a_1", _zero_linear(d_hidden, d_out_1))
+        for b in range(n_blocks):
+            setattr(self, f"lin{b}_b_0", _WNLinear(eb + d_feature, d_hidden, ori_in=1))
+            setattr(self, f"lin{b}_b_1", _zero_linear(d_hidden, d_out_2))
+        for b in range(n_blocks):
+            setattr(self, f"lin{b}_c", _zero_linear(d_feature, d_feature))
+        self._ea, self._eb = ea, eb
+
+    # ------------------------------------------------------------------ operand preparation
+    def _operands(self, code):
+        """-> w_emb [3*(128*26+128*13)], view_b [B,3,2,128], w_head [3*516] (layout of include/niw.h)."""
+        w_emb, view_b, w_head = [], [], []
+        for b in range(self.n_blocks):
+            lin_c = getattr(self, f"lin{b}_c")
+            code_b = F.linear(code, lin_c.weight, lin_c.bias) + code            # nvp_ndr.py:381
+            vb = []
+            for part, e in (("a", self._ea), ("b", self._eb)):
+                l0 = getattr(self, f"lin{b}_{part}_0")
+                w = l0.weight()
+                w_emb.append(w[:, :e].reshape(-1))
+                vb.append(F.linear(code_b, w[:, e:], l0.bias))                 # latent columns folded per view
+            view_b.append(torch.stack(vb, dim=1))
+            a1, b1 = getattr(self, f"lin{b}_a_1"), getattr(self, f"lin{b}_b_1")
+            w_head += [a1.weight.reshape(-1), a1.bias, b1.weight.reshape(-1), b1.bias]
+        return torch.cat(w_emb), torch.stack(view_b, dim=1).contiguous(), torch.cat(w_head)
+
+    def _anneal(self, n_pts, alpha_ratio, device):
+        """-> (chan_w[6], pt_scale_a [P] | None, pt_scale_b [P] | None).  reference_exact: the
+        window multiplies whole points (2i+1)d..(2i+3)d-1 along dim 1 (embedder.py:47 on 4-D input)."""
+        w = anneal_window(alpha_ratio)
+        if not self.reference_exact:
+            return w, None, None
+        sa, sb = np.ones(n_pts, np.float32), np.ones(n_pts, np.float32)
+        for i in range(_NF):
+            sa[(2 * i + 1) * 2:(2 * i + 3) * 2] *= w[i]
+            sb[(2 * i + 1):(2 * i + 3)] *= w[i]
+        return [1.0] * _NF, torch.from_numpy(sa).to(device), torch.from_numpy(sb).to(device)
+
+    def _apply_warp(self, deformation_code, input_pts, alpha_ratio, inverse):
+        if input_pts.dim() != 4 or input_pts.shape[2] != 1 or input_pts.shape[3] != 3:
+            raise NiwError(f"DeformNetwork: input_pts must be [B,N,1,3], got {tuple(input_pts.shape)}")
+        B, P = input_pts.shape[:2]
+        if deformation_code.shape != (B, _LAT):
+            raise NiwError(f"DeformNetwork: deformation_code must be [{B},{_LAT}], got {tuple(deformation_code.shape)}")
+        w_emb, view_b, w_head = self._operands(deformation_code)
+        chan_w, ps_a, ps_b = self._anneal(P, float(alpha_ratio), input_pts.device)
+        out = ops.warp_points(w_emb, view_b, w_head, input_pts.reshape(B, P, 3), chan_w, ps_a, ps_b, inverse)
+        return out.view(B, P, 1, 3)
+
+    def forward(self, deformation_code, input_pts, alpha_ratio=0):
+        """reference nvp_ndr.py:365-468: code [B,128], input_pts [B,N,1,3] -> [B,N,1,3]"""
+        return self._apply_warp(deformation_code, input_pts, alpha_ratio, inverse=False)
+
+    def inverse(self, deformation_code, input_pts, alpha_ratio):
+        """reference nvp_ndr.py:471-567 (gradient-free: only debug helpers call it)"""
+        with torch.no_grad():
+            return self._apply_warp(deformation_code, input_pts, alpha_ratio, inverse=True)

@@ -1,0 +1,292 @@
+"""Torch-facing wrappers of the C ABI: plain functions for the gradient-free stages and
+`torch.autograd.Function`s for the differentiable ones.  PyTorch only provides device memory,
+streams and the autograd tape here; every number is produced by libniw_hip.so.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+NERF_PARAM_FLOATS = 530052
+SAVE_ROWS = 2274
+GRAD_ROWS = 2240
+L3D, LVIEW = 10, 4
+ACT = {"relu": 0, "softplus": 1}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise _lib.NiwError(f"{name}: expected a float32 CUDA/HIP tensor, got {type(t).__name__} "
+                            f"{getattr(t, 'dtype', None)} on {getattr(t, 'device', None)}")
+    return t.contiguous()
+
+
+def _farr(vals, n):
+    vals = [float(v) for v in vals]
+    assert len(vals) == n
+    return (ctypes.c_float * n)(*vals)
+
+
+# ------------------------------------------------------------------------------------------
+# gradient-free stages
+# ------------------------------------------------------------------------------------------
+
+def raygen(intr, pose, ray_idx, H, W, mode):
+    """mode 0: (center, grid) of camera.get_unwarped_center_and_ray; mode 1: (center, ray) of
+    camera.get_center_and_ray.  Returns two [B,R,3] tensors."""
+    intr = _f32(intr, "intr")
+    B = intr.shape[0]
+    pose = None if pose is None else _f32(pose, "pose")
+    if ray_idx is not None:
+        ray_idx = ray_idx.to(device=intr.device, dtype=torch.int64).contiguous()
+    R = H * W if ray_idx is None else ray_idx.numel()
+    a = torch.empty(B, R, 3, device=intr.device, dtype=torch.float32)
+    b = torch.empty_like(a)
+    _lib.call("niw_raygen", _p(intr), _p(pose), _p(ray_idx), B, R, H, W, mode, _p(a), _p(b), _stream())
+    return a, b
+
+
+def convert_ndc(center, ray, intr, near=1.0):
+    center, ray, intr = _f32(center, "center"), _f32(ray, "ray"), _f32(intr, "intr")
+    oc, orr = torch.empty_like(center), torch.empty_like(ray)
+    _lib.call("niw_convert_ndc", _p(center), _p(ray), _p(intr), center.shape[0], center.shape[1], float(near),
+              _p(oc), _p(orr), _stream())
+    return oc, orr
+
+
+def sample_stratified(u, n_rays, S, depth_range, param, device):
+    """Graph.sample_depth: u [n_rays,S] (or None for the 0.5 mid-points) -> depth [n_rays,S]."""
+    if param not in ("metric", "inverse"):
+        raise KeyError(param)
+    if u is not None:
+        u = _f32(u, "u")
+    out = torch.empty(n_rays, S, device=device, dtype=torch.float32)
+    _lib.call("niw_sample_stratified", _p(u), n_rays, S, float(depth_range[0]), float(depth_range[1]),
+              1 if param == "inverse" else 0, _p(out), _stream())
+    return out
+
+
+_table_cache = {}
+
+
+def _pdf_tables(S, Sf, depth_range, device):
+    key = (S, Sf, float(depth_range[0]), float(depth_range[1]), str(device))
+    if key not in _table_cache:
+        g = torch.linspace(0, 1, Sf + 1)                       # nerf.py:352
+        unif = 0.5 * (g[:-1] + g[1:])                          # nerf.py:353
+        bins = torch.linspace(depth_range[0], depth_range[1], S + 1)   # nerf.py:356
+        _table_cache[key] = (unif.to(device).contiguous(), bins.to(device).contiguous())
+    return _table_cache[key]
+
+
+def sample_pdf_merge(pdf, depth_coarse, Sf, depth_range):
+    """Returns (depth_fine [N,Sf], depth_merged [N,S+Sf] ascending)."""
+    pdf, depth_coarse = _f32(pdf, "pdf"), _f32(depth_coarse, "depth_coarse")
+    N, S = pdf.shape
+    unif, bins = _pdf_tables(S, Sf, depth_range, pdf.device)
+    fine = torch.empty(N, Sf, device=pdf.device, dtype=torch.float32)
+    merged = torch.empty(N, S + Sf, device=pdf.device, dtype=torch.float32)
+    _lib.call("niw_sample_pdf_merge", _p(pdf), _p(depth_coarse), _p(unif), _p(bins), N, S, Sf, _p(fine), _p(merged), _stream())
+    return fine, merged
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    _lib.call("niw_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), _stream())
+
+
+# ------------------------------------------------------------------------------------------
+# field MLP
+# ------------------------------------------------------------------------------------------
+
+class FieldState:
+    """Flat parameter storage of one NeRF MLP + the packed-weight cache."""
+
+    def __init__(self, flat):
+        assert flat.numel() == NERF_PARAM_FLOATS
+        self.flat = flat
+        self._packed = None
+        self._packed_version = None
+
+    def packed(self):
+        """Re-pack on every call: the parameters are views of `flat` updated in place by any
+        optimizer, which no version counter of `flat` observes; packing 2.4 M floats costs a few
+        microseconds next to a multi-millisecond MLP launch.  A fresh buffer is returned so that a
+        pending backward keeps the weights its forward used."""
+        n = _lib.load().niw_mlp_packed_floats()
+        packed = torch.empty(n, device=self.flat.device, dtype=torch.float32)
+        _lib.call("niw_mlp_pack_weights", _p(self.flat), _p(packed), _stream())
+        return packed
+
+
+class _FieldMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, band3d, bandview, activ, noise, center, ray, depth, *params):
+        center, ray, depth = _f32(center, "center"), _f32(ray, "ray"), _f32(depth, "depth_samples")
+        n_rays, S = depth.shape
+        if center.shape != (n_rays, 3) or ray.shape != (n_rays, 3):
+            raise _lib.NiwError(f"forward_samples: center {tuple(center.shape)} / ray {tuple(ray.shape)} do not match depth {tuple(depth.shape)}")
+        lib = _lib.load()
+        dev = center.device
+        packed = state.packed()
+        rgb = torch.empty(n_rays, S, 3, device=dev, dtype=torch.float32)
+        sigma = torch.empty(n_rays, S, device=dev, dtype=torch.float32)
+        need = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or center.requires_grad or ray.requires_grad)
+        mpad = lib.niw_mlp_padded_rows(n_rays, S)
+        save = torch.empty(SAVE_ROWS * mpad, device=dev, dtype=torch.float32) if need else None
+        b3, bv = _farr(band3d, L3D), _farr(bandview, LVIEW)
+        if noise is not None:
+            noise = _f32(noise, "noise")
+        _lib.call("niw_mlp_fwd", _p(packed), _p(state.flat), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
+                  b3, bv, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
+        ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
+        ctx.save_ws, ctx.packed = save, packed
+        ctx.param_shapes = [p.shape for p in params]
+        ctx.save_for_backward(center, ray, depth, rgb)
+        ctx.mark_non_differentiable()
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        center, ray, depth, rgb = ctx.saved_tensors
+        n_rays, S = depth.shape
+        dev = center.device
+        lib = _lib.load()
+        d_rgb = torch.zeros_like(rgb) if d_rgb is None else _f32(d_rgb, "d_rgb")
+        d_sigma = torch.zeros(n_rays, S, device=dev) if d_sigma is None else _f32(d_sigma, "d_sigma")
+        gradws = torch.empty(GRAD_ROWS * ctx.mpad, device=dev, dtype=torch.float32)
+        partial = torch.empty(lib.niw_mlp_bwd_workspace_floats(n_rays, S), device=dev, dtype=torch.float32)
+        d_params = torch.empty(NERF_PARAM_FLOATS, device=dev, dtype=torch.float32)
+        ray_grad = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        d_center = torch.zeros_like(center) if ray_grad else None
+        d_ray = torch.zeros_like(ray) if ray_grad else None
+        _lib.call("niw_mlp_bwd", _p(ctx.packed), _p(ctx.state.flat), _p(center), _p(ray), _p(depth), n_rays, S, ctx.b3, ctx.bv,
+                  ACT[ctx.activ], _p(rgb), _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(partial), _p(d_params),
+                  _p(d_center), _p(d_ray), _stream())
+        ctx.save_ws = None
+        grads, off = [], 0
+        for shp in ctx.param_shapes:
+            n = math.prod(shp)
+            grads.append(d_params[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, None, d_center, d_ray, None, *grads)
+
+
+def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None):
+    """NeRF.forward_samples on flattened rays: center, ray [N,3], depth [N,S] -> rgb [N,S,3], sigma [N,S]."""
+    return _FieldMLP.apply(state, band3d, bandview, activ, noise, center, ray, depth, *params)
+
+
+# ------------------------------------------------------------------------------------------
+# compositing
+# ------------------------------------------------------------------------------------------
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ray, rgb_s, sigma_s, depth_s, bg):
+        ray, rgb_s, sigma_s, depth_s = _f32(ray, "ray"), _f32(rgb_s, "rgb_samples"), _f32(sigma_s, "density_samples"), _f32(depth_s, "depth_samples")
+        N, S = sigma_s.shape
+        dev = ray.device
+        rgb = torch.empty(N, 3, device=dev)
+        depth = torch.empty(N, device=dev)
+        opacity = torch.empty(N, device=dev)
+        prob = torch.empty(N, S, device=dev)
+        _lib.call("niw_composite_fwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if bg is None else 1,
+                  0.0 if bg is None else float(bg), _p(rgb), _p(depth), _p(opacity), _p(prob), _stream())
+        ctx.save_for_backward(ray, rgb_s, sigma_s, depth_s)
+        ctx.bg = bg
+        return rgb, depth, opacity, prob
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opacity, g_prob):
+        ray, rgb_s, sigma_s, depth_s = ctx.saved_tensors
+        N, S = sigma_s.shape
+        g = [None if t is None else _f32(t, "grad") for t in (g_rgb, g_depth, g_opacity, g_prob)]
+        d_rgb_s, d_sigma_s, d_ray = torch.empty_like(rgb_s), torch.empty_like(sigma_s), torch.empty_like(ray)
+        _lib.call("niw_composite_bwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if ctx.bg is None else 1,
+                  0.0 if ctx.bg is None else float(ctx.bg), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]),
+                  _p(d_rgb_s), _p(d_sigma_s), _p(d_ray), _stream())
+        return d_ray, d_rgb_s, d_sigma_s, None, None
+
+
+def composite(ray, rgb_s, sigma_s, depth_s, bg=None):
+    """ray [N,3], rgb_s [N,S,3], sigma_s, depth_s [N,S] -> rgb [N,3], depth [N], opacity [N], prob [N,S]."""
+    return _Composite.apply(ray, rgb_s, sigma_s, depth_s, bg)
+
+
+# ------------------------------------------------------------------------------------------
+# NVP warp (per-point part)
+# ------------------------------------------------------------------------------------------
+
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_emb, view_b, w_head, pts, chan_w, ps_a, ps_b, inverse):
+        w_emb, view_b, w_head, pts = _f32(w_emb, "w_emb"), _f32(view_b, "view_b"), _f32(w_head, "w_head"), _f32(pts, "pts")
+        B, P = pts.shape[0], pts.shape[1]
+        out = torch.empty_like(pts)
+        cw = _farr(chan_w, 6)
+        _lib.call("niw_warp_fwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, cw, _p(ps_a), _p(ps_b), 1 if inverse else 0,
+                  _p(out), _stream())
+        ctx.save_for_backward(w_emb, view_b, w_head, pts, ps_a, ps_b)
+        ctx.cw, ctx.inverse = cw, inverse
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if ctx.inverse:
+            raise _lib.NiwError("DeformNetwork.inverse is gradient-free here (the reference only uses it in debug helpers)")
+        w_emb, view_b, w_head, pts, ps_a, ps_b = ctx.saved_tensors
+        B, P = pts.shape[0], pts.shape[1]
+        lib = _lib.load()
+        ws = torch.empty(lib.niw_warp_bwd_workspace_floats(B, P), device=pts.device, dtype=torch.float32)
+        d_w_emb, d_view_b, d_w_head = torch.zeros_like(w_emb), torch.zeros_like(view_b), torch.zeros_like(w_head)
+        d_pts = torch.empty_like(pts) if ctx.needs_input_grad[3] else None
+        _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, _p(ps_a), _p(ps_b),
+                  _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
+        return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None
+
+
+def warp_points(w_emb, view_b, w_head, pts, chan_w, ps_a=None, ps_b=None, inverse=False):
+    """pts [B,P,3] -> warped [B,P,3]; see include/niw.h niw_warp_fwd for the operand layout."""
+    return _Warp.apply(w_emb, view_b, w_head, pts, chan_w, ps_a, ps_b, inverse)
+
+
+# ------------------------------------------------------------------------------------------
+# photometric loss
+# ------------------------------------------------------------------------------------------
+
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, image, ray_idx, n_norm):
+        rgb, image = _f32(rgb, "rgb"), _f32(image, "image")
+        B, R = rgb.shape[0], rgb.shape[1]
+        hw = image.shape[-1] * image.shape[-2] if image.dim() == 4 else image.shape[-1]
+        if ray_idx is not None:
+            ray_idx = ray_idx.to(device=rgb.device, dtype=torch.int64).contiguous()
+        loss = torch.zeros(1, device=rgb.device)
+        d_rgb = torch.empty_like(rgb)
+        n = float(n_norm if n_norm is not None else rgb.numel())
+        _lib.call("niw_mse_fwd_bwd", _p(rgb), _p(image), _p(ray_idx), B, R, hw, n, 1.0, _p(loss), _p(d_rgb), _stream())
+        ctx.save_for_backward(d_rgb)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_rgb,) = ctx.saved_tensors
+        return d_rgb * g, None, None, None
+
+
+def mse_gather(rgb, image, ray_idx=None, n_norm=None):
+    """mean((rgb - image[:, :, ray_idx])^2) with image [B,3,H,W]; n_norm overrides the element count
+    of the mean (global batch under ray sharding)."""
+    return _MSE.apply(rgb, image, ray_idx, n_norm)

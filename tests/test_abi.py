@@ -1,0 +1,64 @@
+"""CPU-side checks of the C-ABI boundary: the library loads without a GPU, exports every symbol
+include/niw.h declares, the ctypes table matches the header, and host-side argument checks
+return error codes (no compute is launched)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "niw.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(niw_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = header_symbols()
+    for s in ("niw_mlp_fwd", "niw_mlp_bwd", "niw_composite_fwd", "niw_composite_bwd", "niw_warp_fwd", "niw_warp_bwd",
+              "niw_sample_stratified", "niw_sample_pdf_merge", "niw_raygen", "niw_mse_fwd_bwd", "niw_adam_step"):
+        assert s in syms
+
+
+def test_library_exports_every_header_symbol():
+    from neural_invertible_warp_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f"{_lib.LIB_PATH} missing: run __graft_entry__.build()")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in header_symbols():
+        assert hasattr(lib, s), f"{s} declared in niw.h but not exported"
+    assert sorted(_lib.SIGNATURES) == header_symbols(), "ctypes table and niw.h disagree"
+
+
+def test_argument_count_matches_header():
+    from neural_invertible_warp_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        body = m.group(1).strip()
+        n = 0 if body in ("", "void") else body.count(",") + 1
+        assert n == len(args), f"{name}: header has {n} parameters, ctypes table {len(args)}"
+
+
+def test_host_side_argument_checks_return_codes():
+    from neural_invertible_warp_amd import _lib
+    lib = _lib.load()
+    assert lib.niw_version() >= 100
+    assert lib.niw_mlp_padded_rows(10, 13) == 256
+    rc = lib.niw_composite_fwd(None, None, None, None, 4, 8, 0, 0.0, None, None, None, None, None)
+    assert rc == -1 and b"null pointer" in lib.niw_last_error_string()
+    with pytest.raises(_lib.NiwError):
+        _lib.call("niw_sample_pdf_merge", None, None, None, None, 1, 8, 8, None, None, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from neural_invertible_warp_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.NiwError, match="no CPU fallback"):
+        _lib.load()
