@@ -48,7 +48,7 @@ const char* niw_last_error_string(void);
 
 /* rows of the saved-activation / saved-gradient workspaces (feature-major, [rows][Mpad]) */
 #define NIW_SAVE_ROWS 2274        /* enc 64 | h1..h7 7*256 | feat 256 | venc 32 | hr 128 | sigma_raw 1 | rgb(unused) 1 */
-#define NIW_GRAD_ROWS 2240        /* dY0..dY6 7*256 | dY7 288 (row 256 = d sigma_raw) | dYrgb0 128 | dYrgb1 32 */
+#define NIW_GRAD_ROWS 2336        /* dY0..dY6 7*256 | dY7 288 (row 256 = d sigma_raw) | dYrgb0 128 | dYrgb1 32 | stash 64+32 */
 
 enum niw_density_activ { NIW_ACT_RELU = 0, NIW_ACT_SOFTPLUS = 1 };
 
@@ -92,6 +92,16 @@ int niw_mlp_bwd(const float* packed, const float* params, const float* center, c
                 const float* rgb, const float* d_rgb, const float* d_sigma,
                 const float* save, float* gradws, float* partial,
                 float* d_params, float* d_center, float* d_ray, niw_stream_t stream);
+
+/* The two passes of niw_mlp_bwd as separate entry points (niw_mlp_bwd = dx then dw):
+ *   niw_mlp_bwd_dx: the register-chained dX chain; writes every dY into gradws, accumulates d_center/d_ray;
+ *   niw_mlp_bwd_dw: dW = dY . X^T (split-M NT GEMMs on the fp32 MFMA path) + deterministic reduction. */
+int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
+                   int64_t n_rays, int n_samples, int density_activ,
+                   const float* rgb, const float* d_rgb, const float* d_sigma,
+                   const float* save, float* gradws, float* d_center, float* d_ray, niw_stream_t stream);
+int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_rays, int n_samples, float* partial,
+                   float* d_params, niw_stream_t stream);
 
 /* ------------------------------------------------------------------ compositing
  * NeRF.composite (model/nerf.py:458-474).  ray [n_rays,3], rgb_s [n_rays,S,3],

@@ -115,7 +115,10 @@ constexpr int kSaveEnc = 0, kSaveH1 = 64, kSaveFeat = 64 + 7 * 256, kSaveVenc = 
 static_assert(kSaveSigma + 2 == NIW_SAVE_ROWS, "save rows");
 __host__ __device__ constexpr int save_h(int l) { return kSaveH1 + (l - 1) * 256; }   // output of layer l-1, l = 1..7
 constexpr int kGradY7 = 7 * 256, kGradRgb0 = kGradY7 + 288, kGradRgb1 = kGradRgb0 + 128;
-static_assert(kGradRgb1 + 32 == NIW_GRAD_ROWS, "grad rows");
+// stash rows: d(encoding slots) from the layer-4 skip and d(view-encoding slots), parked in the
+// workspace between their producer and the end of the chain instead of occupying 48 registers
+constexpr int kGradStashEnc = kGradRgb1 + 32, kGradStashVenc = kGradStashEnc + 64;
+static_assert(kGradStashVenc + 32 == NIW_GRAD_ROWS, "grad rows");
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -183,7 +183,7 @@ int launch_gemm(const float* A, int rowsA, long long strideA, const float* B, in
     auto kern = dw_gemm_kernel<WN, WK, NBW, KBW>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(A, rowsA, strideA, B, rowsB, strideB, mpad, steps_total, per, partial, bias_side);
@@ -218,25 +218,25 @@ extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
     return 256ll * (256 * 256 + 256);
 }
 
-extern "C" int niw_mlp_bwd(const float* packed, const float* params, const float* center, const float* ray,
-                           const float* depth, int64_t n_rays, int n_samples,
-                           const float* band_w3d, const float* band_wview, int density_activ,
-                           const float* rgb, const float* d_rgb, const float* d_sigma,
-                           const float* save, float* gradws, float* partial,
-                           float* d_params, float* d_center, float* d_ray, niw_stream_t stream) {
-    (void)params; (void)band_w3d; (void)band_wview;
-    NIW_REQUIRE(packed && center && ray && depth && rgb && d_rgb && d_sigma && save && gradws && partial && d_params,
-                "niw_mlp_bwd: null pointer");
-    NIW_REQUIRE((d_center == nullptr) == (d_ray == nullptr), "niw_mlp_bwd: d_center and d_ray must both be given or both be NULL");
-    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd: empty input");
-    NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_bwd: unknown density activation %d", density_activ);
-    const long long mpad = niw_mlp_padded_rows(n_rays, n_samples);
-    NIW_REQUIRE(mpad < (1ll << 27), "niw_mlp_bwd: too many samples per call");
-    hipStream_t st = (hipStream_t)stream;
-    int rc = niw_launch_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
-                                   d_center, d_ray, st);
-    if (rc != NIW_OK) return rc;
+extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
+                              int64_t n_rays, int n_samples, int density_activ,
+                              const float* rgb, const float* d_rgb, const float* d_sigma,
+                              const float* save, float* gradws, float* d_center, float* d_ray, niw_stream_t stream) {
+    NIW_REQUIRE(packed && center && ray && depth && rgb && d_rgb && d_sigma && save && gradws, "niw_mlp_bwd_dx: null pointer");
+    NIW_REQUIRE((d_center == nullptr) == (d_ray == nullptr), "niw_mlp_bwd_dx: d_center and d_ray must both be given or both be NULL");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd_dx: empty input");
+    NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_bwd_dx: unknown density activation %d", density_activ);
+    NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 27), "niw_mlp_bwd_dx: too many samples per call");
+    return niw_launch_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
+                                 d_center, d_ray, (hipStream_t)stream);
+}
 
+extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_rays, int n_samples, float* partial,
+                              float* d_params, niw_stream_t stream) {
+    NIW_REQUIRE(save && gradws && partial && d_params, "niw_mlp_bwd_dw: null pointer");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd_dw: empty input");
+    const long long mpad = niw_mlp_padded_rows(n_rays, n_samples);
+    hipStream_t st = (hipStream_t)stream;
     // dW pieces.  Non-transposed: tile rows = dY rows (gradws), tile columns = X slots (save).
     // Transposed (skinny dY: the density row, the 3 colour rows): tile rows = X slots, columns = dY rows.
     const Piece pieces[] = {
@@ -258,8 +258,21 @@ extern "C" int niw_mlp_bwd(const float* packed, const float* params, const float
     for (const Piece& p : pieces) {
         const float* A = (p.transposed ? save : gradws) + (long long)p.a_row * mpad;
         const float* B = (p.transposed ? gradws : save) + (long long)p.b_row * mpad;
-        rc = launch_piece(p, A, B, mpad, partial, d_params, st);
+        int rc = launch_piece(p, A, B, mpad, partial, d_params, st);
         if (rc != NIW_OK) return rc;
     }
     return NIW_OK;
+}
+
+extern "C" int niw_mlp_bwd(const float* packed, const float* params, const float* center, const float* ray,
+                           const float* depth, int64_t n_rays, int n_samples,
+                           const float* band_w3d, const float* band_wview, int density_activ,
+                           const float* rgb, const float* d_rgb, const float* d_sigma,
+                           const float* save, float* gradws, float* partial,
+                           float* d_params, float* d_center, float* d_ray, niw_stream_t stream) {
+    (void)params; (void)band_w3d; (void)band_wview;
+    int rc = niw_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
+                            d_center, d_ray, stream);
+    if (rc != NIW_OK) return rc;
+    return niw_mlp_bwd_dw(save, gradws, n_rays, n_samples, partial, d_params, stream);
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     const long long P = a.Mpad;
 
     float dy[128];
-    f32x16 acc[10];
+    f32x16 acc[8];
 
     // ---- colour head: sigmoid' and W_rgb1^T
     float dy9[4];
@@ -124,14 +124,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         mask_store<4>(acc4, dyr, a.save + (long long)kSaveHr * P, a.grad + (long long)kGradRgb0 * P, P, voff, valid);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots)
-    float dvenc[16];
-    {
-        f32x16(&acc9)[9] = reinterpret_cast<f32x16(&)[9]>(acc);
-        zero_acc<9>(acc9);
-        gemm_regs<16, 9>(wp + bwd_pack_off(8) / 4, lane, dyr, acc9);
+    if (a.ray_grad) {      // view-encoding slots (row block 8 of 9): parked in the workspace until the tail
+        f32x16(&acc1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
+        zero_acc<1>(acc1);
+        gemm_regs<16, 1, 9>(wp + bwd_pack_off(8) / 4 + 8 * 64, lane, dyr, acc1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dvenc[r] = acc9[8][r];
+        for (int r = 0; r < 16; ++r) (a.grad + (long long)(kGradStashVenc + 8 * (r >> 2) + (r & 3)) * P)[voff] = acc1[0][r];
+    }
+    {
         f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        zero_acc<8>(acc8);
+        gemm_regs<16, 8, 9>(wp + bwd_pack_off(8) / 4, lane, dyr, acc8);
         mask_store<8>(acc8, dy, a.save + (long long)kSaveFeat * P, a.grad + (long long)kGradY7 * P, P, voff, valid);
     }
     // ---- density head: d sigma_raw (kernel row 256 of layer 7)
@@ -164,13 +167,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         mask_store<8>(acc8, dy, a.save + (long long)save_h(l) * P, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid);
     }
     // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots)
-    float denc[32];
-    {
-        zero_acc<10>(acc);
-        gemm_regs<32, 10>(wp + bwd_pack_off(4) / 4, lane, dy, acc);
+    if (a.ray_grad) {      // skip-connection encoding slots (row blocks 8, 9 of 10): parked in the workspace
+        f32x16(&acc2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
+        zero_acc<2>(acc2);
+        gemm_regs<32, 2, 10>(wp + bwd_pack_off(4) / 4 + 8 * 64, lane, dy, acc2);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { denc[r] = acc[8][r]; denc[16 + r] = acc[9][r]; }
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                (a.grad + (long long)(kGradStashEnc + nb * 32 + 8 * (r >> 2) + (r & 3)) * P)[voff] = acc2[nb][r];
+    }
+    {
         f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        zero_acc<8>(acc8);
+        gemm_regs<32, 8, 10>(wp + bwd_pack_off(4) / 4, lane, dy, acc8);
         mask_store<8>(acc8, dy, a.save + (long long)save_h(4) * P, a.grad + 3ll * 256 * P, P, voff, valid);
     }
     // ---- layers 3, 2, 1 transposed: produce dY2, dY1, dY0
@@ -182,13 +192,19 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         mask_store<8>(acc8, dy, a.save + (long long)save_h(l) * P, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid);
     }
     if (!a.ray_grad) return;
-    // ---- layer 0 transposed: 256 -> 64 encoding slots
+    // ---- layer 0 transposed: 256 -> 64 encoding slots (+ the parked skip-connection part)
+    float denc[32], dvenc[16];
     {
         f32x16(&acc2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
         zero_acc<2>(acc2);
         gemm_regs<32, 2>(wp + bwd_pack_off(0) / 4, lane, dy, acc2);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { denc[r] += acc2[0][r]; denc[16 + r] += acc2[1][r]; }
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                denc[nb * 16 + r] = acc2[nb][r] + (a.grad + (long long)(kGradStashEnc + nb * 32 + 8 * (r >> 2) + (r & 3)) * P)[voff];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dvenc[r] = (a.grad + (long long)(kGradStashVenc + 8 * (r >> 2) + (r & 3)) * P)[voff];
     }
     // ---- encodings -> point / direction -> ray gradients
     float dp[3], du[3];

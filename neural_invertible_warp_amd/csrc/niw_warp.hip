@@ -350,7 +350,7 @@ extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float
     NIW_REQUIRE(out, "niw_warp_fwd: null output");
     a.out = out; a.inverse = inverse;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(warp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
     warp_fwd_kernel<<<dim3((unsigned)((n_pts + 255) / 256), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_fwd");
     return NIW_OK;
@@ -375,9 +375,9 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
     a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad;
     // padded columns of the factor rows must be zero
     if (ppad != (long long)n_views * n_pts)
-        hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
+        (void)hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(warp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
     warp_bwd_kernel<<<dim3((unsigned)((n_pts + 255) / 256), n_views), 256, kWarpLds, st>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_bwd");
     float* p1 = workspace + 3ll * kRowsPerBlock * ppad;

@@ -11,7 +11,7 @@ from . import _lib
 
 NERF_PARAM_FLOATS = 530052
 SAVE_ROWS = 2274
-GRAD_ROWS = 2240
+GRAD_ROWS = 2336
 L3D, LVIEW = 10, 4
 ACT = {"relu": 0, "softplus": 1}
 
@@ -29,6 +29,47 @@ def _f32(t, name):
         raise _lib.NiwError(f"{name}: expected a float32 CUDA/HIP tensor, got {type(t).__name__} "
                             f"{getattr(t, 'dtype', None)} on {getattr(t, 'device', None)}")
     return t.contiguous()
+
+
+class _Timing:
+    """Optional per-launch timing with device events on the launch stream (bench.py turns it on).
+    records[name] = list of (start_event, end_event, units)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        """-> {name: (launches, mean_ms, units_per_launch)}; call after a device synchronize."""
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = (len(ms), sum(ms) / len(ms), sum(u for _, _, u in recs) / len(recs))
+        return out
+
+
+TIMING = _Timing()
+
+
+class timed:
+    def __init__(self, name, units):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        if TIMING.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()          # torch's current stream == the stream handed to the C ABI
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING.enabled:
+            self.b.record()
+            TIMING.records.setdefault(self.name, []).append((self.a, self.b, self.units))
+        return False
 
 
 def _farr(vals, n):
@@ -141,14 +182,15 @@ class _FieldMLP(torch.autograd.Function):
         packed = state.packed()
         rgb = torch.empty(n_rays, S, 3, device=dev, dtype=torch.float32)
         sigma = torch.empty(n_rays, S, device=dev, dtype=torch.float32)
-        need = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or center.requires_grad or ray.requires_grad)
+        need = any(ctx.needs_input_grad)      # (grad mode itself is always off inside Function.forward)
         mpad = lib.niw_mlp_padded_rows(n_rays, S)
         save = torch.empty(SAVE_ROWS * mpad, device=dev, dtype=torch.float32) if need else None
         b3, bv = _farr(band3d, L3D), _farr(bandview, LVIEW)
         if noise is not None:
             noise = _f32(noise, "noise")
-        _lib.call("niw_mlp_fwd", _p(packed), _p(state.flat), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
-                  b3, bv, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
+        with timed("mlp_fwd_train" if need else "mlp_fwd", n_rays * S):
+            _lib.call("niw_mlp_fwd", _p(packed), _p(state.flat), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
+                      b3, bv, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
         ctx.save_ws, ctx.packed = save, packed
         ctx.param_shapes = [p.shape for p in params]
@@ -170,9 +212,11 @@ class _FieldMLP(torch.autograd.Function):
         ray_grad = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
         d_center = torch.zeros_like(center) if ray_grad else None
         d_ray = torch.zeros_like(ray) if ray_grad else None
-        _lib.call("niw_mlp_bwd", _p(ctx.packed), _p(ctx.state.flat), _p(center), _p(ray), _p(depth), n_rays, S, ctx.b3, ctx.bv,
-                  ACT[ctx.activ], _p(rgb), _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(partial), _p(d_params),
-                  _p(d_center), _p(d_ray), _stream())
+        with timed("mlp_bwd_dx", n_rays * S):
+            _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], _p(rgb),
+                      _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(d_center), _p(d_ray), _stream())
+        with timed("mlp_bwd_dw", n_rays * S):
+            _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, _p(partial), _p(d_params), _stream())
         ctx.save_ws = None
         grads, off = [], 0
         for shp in ctx.param_shapes:
@@ -201,8 +245,9 @@ class _Composite(torch.autograd.Function):
         depth = torch.empty(N, device=dev)
         opacity = torch.empty(N, device=dev)
         prob = torch.empty(N, S, device=dev)
-        _lib.call("niw_composite_fwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if bg is None else 1,
-                  0.0 if bg is None else float(bg), _p(rgb), _p(depth), _p(opacity), _p(prob), _stream())
+        with timed("composite_fwd", N * S):
+            _lib.call("niw_composite_fwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if bg is None else 1,
+                      0.0 if bg is None else float(bg), _p(rgb), _p(depth), _p(opacity), _p(prob), _stream())
         ctx.save_for_backward(ray, rgb_s, sigma_s, depth_s)
         ctx.bg = bg
         return rgb, depth, opacity, prob
@@ -213,9 +258,10 @@ class _Composite(torch.autograd.Function):
         N, S = sigma_s.shape
         g = [None if t is None else _f32(t, "grad") for t in (g_rgb, g_depth, g_opacity, g_prob)]
         d_rgb_s, d_sigma_s, d_ray = torch.empty_like(rgb_s), torch.empty_like(sigma_s), torch.empty_like(ray)
-        _lib.call("niw_composite_bwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if ctx.bg is None else 1,
-                  0.0 if ctx.bg is None else float(ctx.bg), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]),
-                  _p(d_rgb_s), _p(d_sigma_s), _p(d_ray), _stream())
+        with timed("composite_bwd", N * S):
+            _lib.call("niw_composite_bwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if ctx.bg is None else 1,
+                      0.0 if ctx.bg is None else float(ctx.bg), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]),
+                      _p(d_rgb_s), _p(d_sigma_s), _p(d_ray), _stream())
         return d_ray, d_rgb_s, d_sigma_s, None, None
 
 

