@@ -24,6 +24,15 @@ void niw_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// Operand of the NT GEMM (niw_dw_gemm.hip): rows of samples, possibly blocked along the sample axis.
+struct NiwGemmOperand {
+    const float* p;
+    int rows;                 // valid rows (rows beyond are read as zero)
+    long long batch_stride;   // floats between batches (blockIdx.y)
+    long long row_stride;     // floats between rows inside a block
+    long long blk_stride;     // floats between sample blocks (0 when the layout is a single block)
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -20,8 +20,10 @@ int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float*
 
 // C[n][k] = sum_m A[n][m] B[k][m] per batch; tile 256x256 (wide) or 256x64; partial tiles
 // [batch][nsplit][TN*TK + 256] (the trailing 256 floats are row sums of A (bias_side 1) or B (2)).
-int niw_launch_nt_gemm(int wide, const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB,
-                       long long mpad, int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st);
+// Operand addressing (NiwGemmOperand, niw_common.h): 32-sample slice `s` of row r sits at
+//   p + batch*batch_stride + (s / spb)*blk_stride + r*row_stride + (s % spb)*32.
+int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
+                       int bias_side, int* nsplit_out, hipStream_t st);
 
 namespace {
 
@@ -29,12 +31,12 @@ constexpr int kLdsStride = 36;   // 32 samples + 4 pad floats per row
 
 // WN x WK waves; each wave owns NBW x KBW blocks of 32x32 outputs.
 template <int WN, int WK, int NBW, int KBW>
-__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(const float* __restrict__ A, int rowsA, long long strideA,
-                                                               const float* __restrict__ B, int rowsB, long long strideB,
-                                                               long long mpad, int steps_total, int steps_per_wg,
+__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(NiwGemmOperand opA, NiwGemmOperand opB, int spb,
+                                                               int steps_total, int steps_per_wg,
                                                                float* __restrict__ partial, int bias_side) {
-    A += (long long)blockIdx.y * strideA;
-    B += (long long)blockIdx.y * strideB;
+    const float* __restrict__ A = opA.p + (long long)blockIdx.y * opA.batch_stride;
+    const float* __restrict__ B = opB.p + (long long)blockIdx.y * opB.batch_stride;
+    const int rowsA = opA.rows, rowsB = opB.rows;
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
     constexpr int ROWS = TN + TK;
     constexpr int LOADS = ROWS * 8 / NT;                  // float4 loads per thread per 32-sample step
@@ -57,13 +59,18 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(const float* __re
 
     f32x4 stage[LOADS];
     auto gload = [&](int step) {
+        // 32-sample slice `step` of a row lives at  block(step / spb) * blk_stride + row * row_stride + (step % spb) * 32
+        const long long blk = step / spb;
+        const int within = (step % spb) * 32;
+        const float* Ab = A + blk * opA.blk_stride + within;
+        const float* Bb = B + blk * opB.blk_stride + within;
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
             const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
             const bool isA = row < TN;
             const int rr = isA ? row : row - TN;
             const bool ok = isA ? rr < rowsA : rr < rowsB;
-            const float* src = (isA ? A : B) + (long long)rr * mpad + (long long)step * 32 + c4 * 4;
+            const float* src = (isA ? Ab + (long long)rr * opA.row_stride : Bb + (long long)rr * opB.row_stride) + c4 * 4;
             stage[k] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -140,6 +147,19 @@ struct ReduceArgs {
     int bias;         // 0: none, 1: bias sums indexed by the dY row
 };
 
+// fixed-order sum over the split-M partial tiles with 8 independent accumulators (8 loads in flight
+// per thread instead of a 256-long dependent chain); the order does not depend on timing.
+__device__ __forceinline__ float sum_partials(const float* __restrict__ p, long long stride, int n) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 8 <= n; w += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += p[(long long)(w + k) * stride];
+    }
+    for (; w < n; ++w) s[0] += p[(long long)w * stride];
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
 __global__ void dw_reduce_kernel(ReduceArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int tile = a.TN * a.TK;
@@ -149,16 +169,12 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
         const int n = a.n_off + (a.transposed ? tc : tr), s = a.k_off + (a.transposed ? tr : tc);
         const int row = out_row(a.layer, n), col = fwd_slot_col(a.layer, s);
         if (row < 0 || col < 0) return;
-        float sum = 0.f;
-        for (int w = 0; w < a.nsplit; ++w) sum += a.partial[(long long)w * stride + idx];
-        a.d_params[weight_off(a.layer) + row * layer_k(a.layer) + col] = sum;
+        a.d_params[weight_off(a.layer) + row * layer_k(a.layer) + col] = sum_partials(a.partial + idx, stride, a.nsplit);
     } else if (a.bias && idx < tile + 256) {
         const int b = idx - tile;
         const int row = out_row(a.layer, a.n_off + b);
         if (row < 0 || b >= (a.transposed ? a.TK : a.TN)) return;
-        float sum = 0.f;
-        for (int w = 0; w < a.nsplit; ++w) sum += a.partial[(long long)w * stride + idx];
-        a.d_params[bias_off(a.layer) + row] = sum;
+        a.d_params[bias_off(a.layer) + row] = sum_partials(a.partial + idx, stride, a.nsplit);
     }
 }
 
@@ -170,8 +186,8 @@ struct Piece {
 };
 
 template <int WN, int WK, int NBW, int KBW>
-int launch_gemm(const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB, long long mpad,
-                int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st) {
+int launch_gemm(NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial, int bias_side,
+                int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
     // at least 8 slices per workgroup, at most one workgroup per CU
@@ -186,16 +202,16 @@ int launch_gemm(const float* A, int rowsA, long long strideA, const float* B, in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(A, rowsA, strideA, B, rowsB, strideB, mpad, steps_total, per, partial, bias_side);
+    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(A, B, spb, steps_total, per, partial, bias_side);
     NIW_LAUNCH_CHECK("NT GEMM");
     *nsplit_out = nsplit;
     return NIW_OK;
 }
 
-int launch_piece(const Piece& p, const float* A, const float* B, long long mpad, float* partial, float* d_params, hipStream_t st) {
+int launch_piece(const Piece& p, NiwGemmOperand A, NiwGemmOperand B, long long mpad, float* partial, float* d_params, hipStream_t st) {
     const int bias_side = p.bias ? (p.transposed ? 2 : 1) : 0;
     int nsplit = 0;
-    int rc = niw_launch_nt_gemm(p.wide, A, p.a_rows, 0, B, p.b_rows, 0, mpad, 1, partial, bias_side, &nsplit, st);
+    int rc = niw_launch_nt_gemm(p.wide, A, B, (int)(mpad / 32), mpad, 1, partial, bias_side, &nsplit, st);
     if (rc != NIW_OK) return rc;
     ReduceArgs r;
     r.partial = partial; r.d_params = d_params; r.nsplit = nsplit; r.TN = 256; r.TK = p.wide ? 256 : 64; r.layer = p.layer;
@@ -207,10 +223,10 @@ int launch_piece(const Piece& p, const float* A, const float* B, long long mpad,
 
 }  // namespace
 
-int niw_launch_nt_gemm(int wide, const float* A, int rowsA, long long strideA, const float* B, int rowsB, long long strideB,
-                       long long mpad, int batches, float* partial, int bias_side, int* nsplit_out, hipStream_t st) {
-    return wide ? launch_gemm<4, 2, 2, 4>(A, rowsA, strideA, B, rowsB, strideB, mpad, batches, partial, bias_side, nsplit_out, st)
-                : launch_gemm<8, 1, 1, 2>(A, rowsA, strideA, B, rowsB, strideB, mpad, batches, partial, bias_side, nsplit_out, st);
+int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
+                       int bias_side, int* nsplit_out, hipStream_t st) {
+    return wide ? launch_gemm<4, 2, 2, 4>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st);
 }
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
@@ -256,8 +272,9 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0},                  // colour rows (transposed)
     };
     for (const Piece& p : pieces) {
-        const float* A = (p.transposed ? save : gradws) + (long long)p.a_row * mpad;
-        const float* B = (p.transposed ? gradws : save) + (long long)p.b_row * mpad;
+        // workspaces are plain feature-major [row][Mpad]: row pitch Mpad, a single sample block
+        const NiwGemmOperand A{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad, 0};
+        const NiwGemmOperand B{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad, 0};
         int rc = launch_piece(p, A, B, mpad, partial, d_params, st);
         if (rc != NIW_OK) return rc;
     }

@@ -27,30 +27,50 @@ struct MlpBwdArgs {
     int S, act, ray_grad;
 };
 
-template <int NB>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NB]) {
+// Epilogue policies for stream_layer() (niw_mlp_device.h).
+// ReLU mask + hand-over + store: the mask source (the activation the forward saved for this layer's
+// input) is fetched one row block ahead; dY is stored feature-major for the dW pass.
+template <int NBOUT>
+struct MaskEpilogue {
+    const float* __restrict__ act_row0;
+    float (&out)[16 * NBOUT];
+    float* __restrict__ grad_row0;
+    long long mpad;
+    unsigned voff;
+    bool valid;
+    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-}
-
-// dy = acc masked by (saved activation > 0); stored feature-major at grad_row0
-template <int NB>
-__device__ __forceinline__ void mask_store(const f32x16 (&acc)[NB], float (&dy)[16 * NB], const float* __restrict__ act_row0,
-                                           float* __restrict__ grad_row0, long long mpad, unsigned voff, bool valid) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long row = (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad;
-            const float a = (act_row0 + row)[voff];
-            const float g = (valid && a > 0.f) ? acc[nb][r] : 0.f;
-            dy[nb * 16 + r] = g;
-            (grad_row0 + row)[voff] = g;
-        }
+        for (int r = 0; r < 16; ++r) buf[r] = (act_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff];
     }
-}
+    __device__ __forceinline__ void epi(int nb, int r, float a, float p) {
+        const float g = (valid && p > 0.f) ? a : 0.f;
+        out[nb * 16 + r] = g;
+        (grad_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff] = g;
+    }
+};
+// park a result in the workspace (d encoding slots of the skip connection, d view-encoding slots)
+struct StashEpilogue {
+    float* __restrict__ row0;
+    long long mpad;
+    unsigned voff;
+    __device__ __forceinline__ void pre(int, float (&)[16]) const {}
+    __device__ __forceinline__ void epi(int nb, int r, float a, float) {
+        (row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff] = a;
+    }
+};
+// add a parked result and keep the sum in registers
+template <int NBOUT>
+struct AddStashEpilogue {
+    const float* __restrict__ row0;
+    float (&out)[16 * NBOUT];
+    long long mpad;
+    unsigned voff;
+    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[r] = (row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff];
+    }
+    __device__ __forceinline__ void epi(int nb, int r, float a, float p) { out[nb * 16 + r] = a + p; }
+};
 
 // d(point)/d(unit dir) from the gradient of the encoding slots and the saved encoding values:
 // d/dx [w sin(f x)] = f * (w cos(f x)),  d/dx [w cos(f x)] = -f * (w sin(f x)).
@@ -95,47 +115,42 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
     const bool valid = m < a.M;
     const long long mc = valid ? m : a.M - 1;
-    const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);
+    const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);     // plain feature-major [row][Mpad] (see niw_mlp_fwd.hip)
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
     const long long P = a.Mpad;
+    const float none[4] = {0.f, 0.f, 0.f, 0.f};
 
-    float dy[128];
-    f32x16 acc[8];
+    float dy[128], nxt[128];
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 128; ++i) dy[i] = nxt[i];
+    };
 
     // ---- colour head: sigmoid' and W_rgb1^T
     float dy9[4];
-    {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float g = 0.f;
-            if (h == 0 && t < 3 && valid) {
-                const float o = a.rgb[mc * 3 + t];
-                g = a.d_rgb[mc * 3 + t] * o * (1.f - o);
-            }
-            dy9[t] = g;
-            (a.grad + (long long)(kGradRgb1 + t) * P)[voff] = g;     // rows 4h+t of the 8-row slot block
+    for (int t = 0; t < 4; ++t) {
+        float g = 0.f;
+        if (h == 0 && t < 3 && valid) {
+            const float o = a.rgb[mc * 3 + t];
+            g = a.d_rgb[mc * 3 + t] * o * (1.f - o);
         }
+        dy9[t] = g;
+        (a.grad + (long long)(kGradRgb1 + t) * P)[voff] = g;     // rows 4h+t of the 8-row slot block
     }
     float dyr[64];
     {
-        f32x16(&acc4)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
-        zero_acc<4>(acc4);
-        gemm_regs<1, 4>(wp + bwd_pack_off(9) / 4, lane, dy9, acc4);
-        mask_store<4>(acc4, dyr, a.save + (long long)kSaveHr * P, a.grad + (long long)kGradRgb0 * P, P, voff, valid);
+        MaskEpilogue<4> ep{a.save + (long long)kSaveHr * P, dyr, a.grad + (long long)kGradRgb0 * P, P, voff, valid};
+        stream_layer<1, 0, 4, 4>(wp + bwd_pack_off(9) / 4, lane, dy9, none, ep);
     }
-    // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots)
-    if (a.ray_grad) {      // view-encoding slots (row block 8 of 9): parked in the workspace until the tail
-        f32x16(&acc1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
-        zero_acc<1>(acc1);
-        gemm_regs<16, 1, 9>(wp + bwd_pack_off(8) / 4 + 8 * 64, lane, dyr, acc1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) (a.grad + (long long)(kGradStashVenc + 8 * (r >> 2) + (r & 3)) * P)[voff] = acc1[0][r];
+    // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = row block 8 of 9)
+    if (a.ray_grad) {
+        StashEpilogue ep{a.grad + (long long)kGradStashVenc * P, P, voff};
+        stream_layer<16, 0, 1, 9>(wp + bwd_pack_off(8) / 4 + 8 * 64, lane, dyr, none, ep);
     }
     {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        zero_acc<8>(acc8);
-        gemm_regs<16, 8, 9>(wp + bwd_pack_off(8) / 4, lane, dyr, acc8);
-        mask_store<8>(acc8, dy, a.save + (long long)kSaveFeat * P, a.grad + (long long)kGradY7 * P, P, voff, valid);
+        MaskEpilogue<8> ep{a.save + (long long)kSaveFeat * P, dy, a.grad + (long long)kGradY7 * P, P, voff, valid};
+        stream_layer<16, 0, 8, 9>(wp + bwd_pack_off(8) / 4, lane, dyr, none, ep);
     }
     // ---- density head: d sigma_raw (kernel row 256 of layer 7)
     float dsig[4] = {0.f, 0.f, 0.f, 0.f};
@@ -152,57 +167,40 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        zero_acc<8>(acc8);
-        gemm_regs<32, 8>(wp + bwd_pack_off(7) / 4, lane, dy, acc8);
-        gemm_regs<1, 8>(wp + bwd_pack_off(7) / 4 + 32 * 8 * 64, lane, dsig, acc8);
-        mask_store<8>(acc8, dy, a.save + (long long)save_h(7) * P, a.grad + 6ll * 256 * P, P, voff, valid);
+        MaskEpilogue<8> ep{a.save + (long long)save_h(7) * P, nxt, a.grad + 6ll * 256 * P, P, voff, valid};
+        stream_layer<32, 1, 8, 8>(wp + bwd_pack_off(7) / 4, lane, dy, dsig, ep);
+        advance();
     }
     // ---- layers 6, 5 transposed: produce dY5, dY4
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        zero_acc<8>(acc8);
-        gemm_regs<32, 8>(wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, dy, acc8);
-        mask_store<8>(acc8, dy, a.save + (long long)save_h(l) * P, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid);
+        MaskEpilogue<8> ep{a.save + (long long)save_h(l) * P, nxt, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid};
+        stream_layer<32, 0, 8, 8>(wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, dy, none, ep);
+        advance();
     }
-    // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots)
-    if (a.ray_grad) {      // skip-connection encoding slots (row blocks 8, 9 of 10): parked in the workspace
-        f32x16(&acc2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
-        zero_acc<2>(acc2);
-        gemm_regs<32, 2, 10>(wp + bwd_pack_off(4) / 4 + 8 * 64, lane, dy, acc2);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                (a.grad + (long long)(kGradStashEnc + nb * 32 + 8 * (r >> 2) + (r & 3)) * P)[voff] = acc2[nb][r];
+    // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots = row blocks 8, 9 of 10)
+    if (a.ray_grad) {
+        StashEpilogue ep{a.grad + (long long)kGradStashEnc * P, P, voff};
+        stream_layer<32, 0, 2, 10>(wp + bwd_pack_off(4) / 4 + 8 * 64, lane, dy, none, ep);
     }
     {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        zero_acc<8>(acc8);
-        gemm_regs<32, 8, 10>(wp + bwd_pack_off(4) / 4, lane, dy, acc8);
-        mask_store<8>(acc8, dy, a.save + (long long)save_h(4) * P, a.grad + 3ll * 256 * P, P, voff, valid);
+        MaskEpilogue<8> ep{a.save + (long long)save_h(4) * P, nxt, a.grad + 3ll * 256 * P, P, voff, valid};
+        stream_layer<32, 0, 8, 10>(wp + bwd_pack_off(4) / 4, lane, dy, none, ep);
+        advance();
     }
     // ---- layers 3, 2, 1 transposed: produce dY2, dY1, dY0
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        zero_acc<8>(acc8);
-        gemm_regs<32, 8>(wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, dy, acc8);
-        mask_store<8>(acc8, dy, a.save + (long long)save_h(l) * P, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid);
+        MaskEpilogue<8> ep{a.save + (long long)save_h(l) * P, nxt, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid};
+        stream_layer<32, 0, 8, 8>(wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, dy, none, ep);
+        advance();
     }
     if (!a.ray_grad) return;
     // ---- layer 0 transposed: 256 -> 64 encoding slots (+ the parked skip-connection part)
     float denc[32], dvenc[16];
     {
-        f32x16(&acc2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
-        zero_acc<2>(acc2);
-        gemm_regs<32, 2>(wp + bwd_pack_off(0) / 4, lane, dy, acc2);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                denc[nb * 16 + r] = acc2[nb][r] + (a.grad + (long long)(kGradStashEnc + nb * 32 + 8 * (r >> 2) + (r & 3)) * P)[voff];
+        AddStashEpilogue<2> ep{a.grad + (long long)kGradStashEnc * P, denc, P, voff};
+        stream_layer<32, 0, 2, 2>(wp + bwd_pack_off(0) / 4, lane, dy, none, ep);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dvenc[r] = (a.grad + (long long)(kGradStashVenc + 8 * (r >> 2) + (r & 3)) * P)[voff];
     }

@@ -103,41 +103,37 @@ __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* _
     }
 }
 
-template <int NB>
-__device__ __forceinline__ void load_bias(const float* __restrict__ bp, int h, f32x16 (&acc)[NB]) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(bp + (nb * 2 + h) * 16);
+// Epilogue policy of one forward layer for stream_layer(): bias add, ReLU, hand the value to the next
+// layer's operand registers and (training) store it feature-major [row][Mpad].  Row of (nb, r, h) =
+// nb*32 + (r&3) + 8(r>>2) + 4h; the lane-dependent part (4h rows + sample m) is folded into ONE 32-bit
+// element offset `voff`, so every store is scalar-base + vector-offset.
+template <int NBOUT, bool RELU, bool SAVE>
+struct FwdEpilogue {
+    const float* __restrict__ bias;      // packed bias of the layer, already offset by h*16
+    float (&out)[16 * NBOUT];
+    float* __restrict__ save_row0;
+    long long mpad;
+    unsigned voff;
+    float sig_raw;                       // kernel row 256 of layer 7 (row block NBOUT, register 0, half 0)
+
+    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
+        const f32x4* src = reinterpret_cast<const f32x4*>(bias + nb * 32);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 v = src[g];
-            acc[nb][4 * g + 0] = v[0];
-            acc[nb][4 * g + 1] = v[1];
-            acc[nb][4 * g + 2] = v[2];
-            acc[nb][4 * g + 3] = v[3];
+            const f32x4 v = src[g];
+            buf[4 * g] = v[0]; buf[4 * g + 1] = v[1]; buf[4 * g + 2] = v[2]; buf[4 * g + 3] = v[3];
         }
     }
-}
-
-// Saved tensors are feature-major [rows][Mpad].  Row of (nb, r, h) = nb*32 + (r&3) + 8(r>>2) + 4h:
-// the lane-dependent part (4h rows + sample m) is folded into ONE 32-bit element offset `voff`
-// so that every store is scalar-base + vector-offset (no per-store 64-bit address registers).
-template <int NB, bool SAVE>
-__device__ __forceinline__ void relu_store(const f32x16 (&acc)[NB], float (&act)[16 * NB], float* __restrict__ save_row0,
-                                           long long mpad, unsigned voff) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = fmaxf(acc[nb][r], 0.f);
-            act[nb * 16 + r] = v;
-            if (SAVE) {
-                float* __restrict__ rowp = save_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad;
-                rowp[voff] = v;
-            }
+    __device__ __forceinline__ void epi(int nb, int r, float a, float p) {
+        if (nb < NBOUT) {
+            const float v = RELU ? fmaxf(a + p, 0.f) : a + p;
+            out[nb * 16 + r] = v;
+            if (SAVE) (save_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff] = v;
+        } else if (r == 0) {
+            sig_raw = a + p;
         }
     }
-}
+};
 
 struct MlpFwdArgs {
     const float* packed;
@@ -182,6 +178,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     float enc[32], venc[16];
     encode_slots<NIW_L3D, 8>(p, a.w3d, h, enc);
     encode_slots<NIW_LVIEW, 4>(u, a.wview, h, venc);
+    // Workspace layout: plain feature-major [row][Mpad].  (A blocked [128-sample block][row][128]
+    // image was measured 10-14 % slower for this kernel and the dX chain on MI355X.)
     const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);     // host guarantees 5*Mpad < 2^30
     if (SAVE) {
 #pragma unroll
@@ -191,49 +189,47 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
 
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
-    float act[128];
-    f32x16 acc[9];
+    const float none[4] = {0.f, 0.f, 0.f, 0.f};
+    float act[128], nxt[128];
+    auto row = [&](int r) { return SAVE ? a.save + (long long)r * a.Mpad : nullptr; };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 128; ++i) act[i] = nxt[i];
+    };
 
     // ---- layer 0: 63 -> 256
     {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        load_bias<8>(a.packed + bias_pack_off(0), h, acc8);
-        gemm_regs<8, 8>(wp + fwd_pack_off(0) / 4, lane, enc, acc8);
-        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(1) * a.Mpad : nullptr, a.Mpad, voff);
+        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(0) + h * 16, nxt, row(save_h(1)), a.Mpad, voff, 0.f};
+        stream_layer<8, 0, 8, 8>(wp + fwd_pack_off(0) / 4, lane, enc, none, ep);
+        advance();
     }
     // ---- layers 1..3
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        load_bias<8>(a.packed + bias_pack_off(1) + (l - 1) * 256, h, acc8);
-        gemm_regs<32, 8>(wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, act, acc8);
-        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(l + 1) * a.Mpad : nullptr, a.Mpad, voff);
+        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(1) + (l - 1) * 256 + h * 16, nxt, row(save_h(l + 1)), a.Mpad, voff, 0.f};
+        stream_layer<32, 0, 8, 8>(wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, act, none, ep);
+        advance();
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        load_bias<8>(a.packed + bias_pack_off(4), h, acc8);
-        gemm_regs<32, 8>(wp + fwd_pack_off(4) / 4, lane, act, acc8);
-        gemm_regs<8, 8>(wp + fwd_pack_off(4) / 4 + 32 * 8 * 64, lane, enc, acc8);
-        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(5) * a.Mpad : nullptr, a.Mpad, voff);
+        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(4) + h * 16, nxt, row(save_h(5)), a.Mpad, voff, 0.f};
+        stream_layer<32, 8, 8, 8>(wp + fwd_pack_off(4) / 4, lane, act, enc, ep);
+        advance();
     }
     // ---- layers 5, 6
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        load_bias<8>(a.packed + bias_pack_off(5) + (l - 5) * 256, h, acc8);
-        gemm_regs<32, 8>(wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, act, acc8);
-        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)save_h(l + 1) * a.Mpad : nullptr, a.Mpad, voff);
+        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(5) + (l - 5) * 256 + h * 16, nxt, row(save_h(l + 1)), a.Mpad, voff, 0.f};
+        stream_layer<32, 0, 8, 8>(wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, act, none, ep);
+        advance();
     }
-    // ---- layer 7: 256 -> 256 features (+ density row 256)
-    float sig_raw;
+    // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
-        load_bias<9>(a.packed + bias_pack_off(7), h, acc);
-        gemm_regs<32, 9>(wp + fwd_pack_off(7) / 4, lane, act, acc);
-        sig_raw = acc[8][0];                                   // kernel row 256: register 0 of half 0
+        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(7) + h * 16, nxt, row(kSaveFeat), a.Mpad, voff, 0.f};
+        stream_layer<32, 0, 9, 9>(wp + fwd_pack_off(7) / 4, lane, act, none, ep);
+        advance();
+        float sig_raw = ep.sig_raw;
         if (a.noise != nullptr) sig_raw += a.noise[mc];
-        f32x16(&acc8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        relu_store<8, SAVE>(acc8, act, SAVE ? a.save + (long long)kSaveFeat * a.Mpad : nullptr, a.Mpad, voff);
         if (h == 0) {
             if (SAVE) (a.save + (long long)kSaveSigma * a.Mpad)[voff] = sig_raw;
             if (valid) a.sigma[m] = density_act(sig_raw, a.act);
@@ -242,20 +238,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
     float hr[64];
     {
-        f32x16(&acc4)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
-        load_bias<4>(a.packed + bias_pack_off(8), h, acc4);
-        gemm_regs<32, 4>(wp + fwd_pack_off(8) / 4, lane, act, acc4);
-        gemm_regs<4, 4>(wp + fwd_pack_off(8) / 4 + 32 * 4 * 64, lane, venc, acc4);
-        relu_store<4, SAVE>(acc4, hr, SAVE ? a.save + (long long)kSaveHr * a.Mpad : nullptr, a.Mpad, voff);
+        FwdEpilogue<4, true, SAVE> ep{a.packed + bias_pack_off(8) + h * 16, hr, row(kSaveHr), a.Mpad, voff, 0.f};
+        stream_layer<32, 4, 4, 4>(wp + fwd_pack_off(8) / 4, lane, act, venc, ep);
     }
     // ---- colour layer 1: 128 -> 3, sigmoid
     {
-        f32x16(&acc1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
-        load_bias<1>(a.packed + bias_pack_off(9), h, acc1);
-        gemm_regs<16, 1>(wp + fwd_pack_off(9) / 4, lane, hr, acc1);
+        float o[16];
+        FwdEpilogue<1, false, false> ep{a.packed + bias_pack_off(9) + h * 16, o, nullptr, a.Mpad, voff, 0.f};
+        stream_layer<16, 0, 1, 1>(wp + fwd_pack_off(9) / 4, lane, hr, none, ep);
         if (h == 0 && valid) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-acc1[0][c]));
+            for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-o[c]));
         }
     }
 }
