@@ -77,10 +77,13 @@ def main():
     import torch.distributed as dist
     from neural_invertible_warp_amd import configs, engine, ops, parallel
 
-    rank, world, local = parallel.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # NIW_DIST_BACKEND=gloo + fewer GPUs than ranks is a logic test of the N>1 path on a 1-GPU box
+    backend = os.environ.get("NIW_DIST_BACKEND")
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    rank, world, _ = parallel.init_from_env(backend=backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = f"cuda:{local}"
 
     B, rays_per_gpu = 18, 4096

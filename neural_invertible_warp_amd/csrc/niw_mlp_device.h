@@ -2,6 +2,11 @@
 #pragma once
 #include "niw_common.h"
 
+// weight fragments kept in flight per wave (each covers 4 MFMAs = 256 cycles)
+#ifndef NIW_RING_DEPTH
+#define NIW_RING_DEPTH 8
+#endif
+
 namespace niw {
 
 // band frequency 2^k * fp32(pi)  (reference: 2**arange(L) * np.pi evaluated in fp32, nerf.py:478)
@@ -33,7 +38,7 @@ __device__ __forceinline__ float band_freq(int k) { return 3.14159274101257324f 
 template <int KB1, int KB2, int NB, int STRIDE, typename Policy>
 __device__ __forceinline__ void stream_layer(const f32x4* __restrict__ wp, int lane, const float (&b1)[4 * KB1],
                                              const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol) {
-    constexpr int KB = KB1 + KB2, N = NB * KB, D = 8, GAPS = 4 * KB;
+    constexpr int KB = KB1 + KB2, N = NB * KB, D = NIW_RING_DEPTH, GAPS = 4 * KB;
     constexpr int G0 = GAPS >= 32 ? 8 : 0;                 // first gap used by the epilogue
     constexpr int GS = (GAPS - G0) / 16 > 0 ? (GAPS - G0) / 16 : 1;
     f32x4 ring[D];

@@ -58,20 +58,41 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
 // ---------------------------------------------------------------------------------------
 // band frequency 2^k * fp32(pi)  (reference: 2**arange(L) * np.pi evaluated in fp32)
 
-// One sincos pair (compile-time pair index per lane half, selected by h).
+// sin / cos of the band argument fl32(x * 2^k * pi32).
+// The reference evaluates sin(fl32(x * f_k)) with f_k = 2^k * fl32(pi) (nerf.py:478-480).  Scaling by a
+// power of two commutes with rounding, so fl32(x * f_k) == 2^k * fl32(x * pi32) EXACTLY: one range
+// reduction per coordinate serves all bands.  t = arg0 / (2 pi) is formed in fp64 (arguments reach
+// 1e8 with inverse-depth sampling; fp64 keeps the reduced angle good to < 1e-6 even there), the
+// band's revolution fraction is frac(2^k t), and sin / cos come from the Cephes minimax polynomials
+// on [-pi/4, pi/4] (~1 ulp) with quadrant rotation.  ~35 instructions instead of the ~500 of a
+// full-range sincosf, which was 8 % of the forward kernel as an un-overlappable prologue.
+__device__ __forceinline__ void sincos_band(double t, int k, float& s, float& c) {
+    const double tk = t * (double)(1 << k);
+    const double fr = tk - rint(tk);                       // revolutions in [-0.5, 0.5]
+    const double q = rint(fr * 4.0);                       // quadrant -2..2
+    const float th = (float)((fr - q * 0.25) * 6.283185307179586476925);   // [-pi/4, pi/4]
+    const float z = th * th;
+    const float ps = th + th * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float pc = 1.f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const int qi = (int)q & 3;                             // rotate by q * 90 degrees
+    const float ss = (qi & 1) ? pc : ps, cc = (qi & 1) ? ps : pc;
+    s = (qi == 2 || qi == 3) ? -ss : ss;
+    c = (qi == 1 || qi == 2) ? -cc : cc;
+}
+
+// One sincos pair (compile-time pair index per lane half, selected by h).  rev[c] = fl32(p_c*pi32)/(2 pi).
 template <int L>
-__device__ __forceinline__ void enc_pair(const float (&p)[3], const float* __restrict__ w, int h, int pair0, int pair1,
+__device__ __forceinline__ void enc_pair(const double (&rev)[3], const float* __restrict__ w, int h, int pair0, int pair1,
                                          float& s_out, float& c_out) {
     // pair index -> (coordinate, band); pairs >= 3L are zero padding
     const bool valid0 = pair0 < 3 * L, valid1 = pair1 < 3 * L;
     const int c0 = valid0 ? pair0 / L : 0, k0 = valid0 ? pair0 % L : 0;
     const int c1 = valid1 ? pair1 / L : 0, k1 = valid1 ? pair1 % L : 0;
-    const float x = h ? p[c1] : p[c0];
-    const float f = h ? band_freq(k1) : band_freq(k0);
+    const double t = h ? rev[c1] : rev[c0];
+    const int k = h ? k1 : k0;
     const float wk = h ? w[k1] : w[k0];
-    const float arg = __fmul_rn(x, f);          // separate fp32 rounding of x*freq, as the reference
     float s, c;
-    sincosf(arg, &s, &c);
+    sincos_band(t, k, s, c);
     const bool valid = h ? valid1 : valid0;
     s_out = valid ? s * wk : 0.f;
     c_out = valid ? c * wk : 0.f;
@@ -80,21 +101,24 @@ __device__ __forceinline__ void enc_pair(const float (&p)[3], const float* __res
 // enc[4q+t] = feature of slot 8q+4h+t for this lane's half h
 template <int L, int NQ>
 __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* __restrict__ w, int h, float (&enc)[4 * NQ]) {
+    double rev[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rev[c] = (double)__fmul_rn(p[c], 3.14159274101257324f) * 0.15915494309189533577;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         // combo g = 2q + h; g == 0: raw coordinates; else pairs 2(g-1), 2(g-1)+1
         const int pa0 = 2 * (2 * q - 1), pa1 = 2 * (2 * q);      // first pair for h = 0 / h = 1
         float s0, c0, s1, c1;
         if (q == 0) {
-            enc_pair<L>(p, w, 1, 0, 0, s0, c0);                   // only h = 1 lanes use these
-            enc_pair<L>(p, w, 1, 1, 1, s1, c1);
+            enc_pair<L>(rev, w, 1, 0, 0, s0, c0);                   // only h = 1 lanes use these
+            enc_pair<L>(rev, w, 1, 1, 1, s1, c1);
             enc[0] = h ? s0 : p[0];
             enc[1] = h ? c0 : p[1];
             enc[2] = h ? s1 : p[2];
             enc[3] = h ? c1 : 0.f;
         } else {
-            enc_pair<L>(p, w, h, pa0, pa1, s0, c0);
-            enc_pair<L>(p, w, h, pa0 + 1, pa1 + 1, s1, c1);
+            enc_pair<L>(rev, w, h, pa0, pa1, s0, c0);
+            enc_pair<L>(rev, w, h, pa0 + 1, pa1 + 1, s1, c1);
             enc[4 * q + 0] = s0;
             enc[4 * q + 1] = c0;
             enc[4 * q + 2] = s1;

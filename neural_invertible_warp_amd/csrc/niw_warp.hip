@@ -9,7 +9,8 @@
 // `view_b` (computed by the host mirror together with weight-norm), so a point costs
 // 3 * 128 * (26 + 13) MACs instead of 3 * 128 * (154 + 141).
 //
-// Forward / inverse: one thread per point, one view per blockIdx.y, first-layer weights of all
+// Forward / inverse: one QUAD of lanes per point (each lane a quarter of the 128 hidden units, quad
+// sums by DPP shuffle), one view per blockIdx.y, first-layer weights of all
 // blocks staged once in LDS (69 KB) and read as broadcasts.
 // Backward: the same thread-per-point kernel walks the blocks in reverse for d(points) and
 // writes, feature-major, the per-point factors of every parameter gradient (pre-activation
@@ -107,25 +108,36 @@ __device__ __forceinline__ void stage_weights(const WarpArgs& a, float* lw, floa
     __syncthreads();
 }
 
+// A point is served by a QUAD of adjacent lanes; lane `sub` (0..3) owns hidden units sub, sub+4, ...
+// and the quad combines its partial head sums with two DPP shuffles.
+constexpr int kQuad = 4;
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
 // part a: delta = head_a(softplus(W_a e + v_a))
-__device__ __forceinline__ float part_a(const float* lw, const float* lh, const float* lv, int b, const float (&ea)[kEa]) {
+__device__ __forceinline__ float part_a(const float* lw, const float* lh, const float* lv, int b, int sub, const float (&ea)[kEa]) {
     const float* W = lw + b * kWembBlock;
     const float* hd = lh + b * kHeadBlock;
     const float* vb = lv + (b * 2 + 0) * kHid;
-    float delta = hd[kHid];
-    for (int u = 0; u < kHid; ++u) delta += hd[u] * softplus100(vb[u] + dot_row<kEa>(W + u * kEa, ea));
-    return delta;
+    float delta = 0.f;
+    for (int u = sub; u < kHid; u += kQuad) delta += hd[u] * softplus100(vb[u] + dot_row<kEa>(W + u * kEa, ea));
+    return quad_sum(delta) + hd[kHid];
 }
 // part b: (theta, t0, t1) = head_b(softplus(W_b e + v_b))
-__device__ __forceinline__ void part_b(const float* lw, const float* lh, const float* lv, int b, const float (&eb)[kEb], float (&o)[3]) {
+__device__ __forceinline__ void part_b(const float* lw, const float* lh, const float* lv, int b, int sub, const float (&eb)[kEb], float (&o)[3]) {
     const float* W = lw + b * kWembBlock + kHid * kEa;
     const float* hd = lh + b * kHeadBlock + kHid + 1;
     const float* vb = lv + (b * 2 + 1) * kHid;
-    o[0] = hd[3 * kHid]; o[1] = hd[3 * kHid + 1]; o[2] = hd[3 * kHid + 2];
-    for (int u = 0; u < kHid; ++u) {
+    o[0] = o[1] = o[2] = 0.f;
+    for (int u = sub; u < kHid; u += kQuad) {
         const float hh = softplus100(vb[u] + dot_row<kEb>(W + u * kEb, eb));
         o[0] += hd[u] * hh; o[1] += hd[kHid + u] * hh; o[2] += hd[2 * kHid + u] * hh;
     }
+    o[0] = quad_sum(o[0]) + hd[3 * kHid];
+    o[1] = quad_sum(o[1]) + hd[3 * kHid + 1];
+    o[2] = quad_sum(o[2]) + hd[3 * kHid + 2];
 }
 
 __device__ __forceinline__ void axes(int b, int& f, int& o0, int& o1) {
@@ -135,16 +147,16 @@ __device__ __forceinline__ void axes(int b, int& f, int& o0, int& o1) {
 }
 
 __device__ __forceinline__ void block_fwd(const float* lw, const float* lh, const float* lv, const float* cw, float psa, float psb,
-                                          int b, float (&x)[3]) {
+                                          int b, int sub, float (&x)[3]) {
     int f, o0, o1;
     axes(b, f, o0, o1);
     const float oth[2] = {x[o0], x[o1]};
     float ea[kEa];
     embed<2>(oth, cw, psa, ea);
-    const float foc[1] = {x[f] - part_a(lw, lh, lv, b, ea)};
+    const float foc[1] = {x[f] - part_a(lw, lh, lv, b, sub, ea)};
     float eb[kEb], o[3];
     embed<1>(foc, cw, psb, eb);
-    part_b(lw, lh, lv, b, eb, o);
+    part_b(lw, lh, lv, b, sub, eb, o);
     float s, c;
     sincosf(o[0], &s, &c);
     const float d0 = oth[0] - o[1], d1 = oth[1] - o[2];
@@ -154,19 +166,19 @@ __device__ __forceinline__ void block_fwd(const float* lw, const float* lh, cons
 }
 
 __device__ __forceinline__ void block_inv(const float* lw, const float* lh, const float* lv, const float* cw, float psa, float psb,
-                                          int b, float (&x)[3]) {
+                                          int b, int sub, float (&x)[3]) {
     int f, o0, o1;
     axes(b, f, o0, o1);
     const float single[1] = {x[f]};
     float eb[kEb], o[3];
     embed<1>(single, cw, psb, eb);
-    part_b(lw, lh, lv, b, eb, o);
+    part_b(lw, lh, lv, b, sub, eb, o);
     float s, c;
     sincosf(o[0], &s, &c);                            // euler2rot_2d: [[cos, -sin], [sin, cos]]
     const float pr[2] = {c * x[o0] - s * x[o1] + o[1], s * x[o0] + c * x[o1] + o[2]};
     float ea[kEa];
     embed<2>(pr, cw, psa, ea);
-    x[f] = single[0] + part_a(lw, lh, lv, b, ea);
+    x[f] = single[0] + part_a(lw, lh, lv, b, sub, ea);
     x[o0] = pr[0];
     x[o1] = pr[1];
 }
@@ -178,17 +190,18 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
     float* lv = lh + 3 * kHeadBlock;
     const int view = blockIdx.y;
     stage_weights(a, lw, lh, lv, view);
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_pts) return;
+    const int sub = threadIdx.x & (kQuad - 1);
+    const long long p = (long long)blockIdx.x * (blockDim.x / kQuad) + (threadIdx.x >> 2);
+    if (p >= a.n_pts) return;                     // whole quads leave together
     const long long gi = (long long)view * a.n_pts + p;
     float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
     const float psa = a.ps_a ? a.ps_a[p] : 1.f, psb = a.ps_b ? a.ps_b[p] : 1.f;
     if (!a.inverse) {
-        for (int b = 0; b < 3; ++b) block_fwd(lw, lh, lv, a.cw, psa, psb, b, x);
+        for (int b = 0; b < 3; ++b) block_fwd(lw, lh, lv, a.cw, psa, psb, b, sub, x);
     } else {
-        for (int b = 2; b >= 0; --b) block_inv(lw, lh, lv, a.cw, psa, psb, b, x);
+        for (int b = 2; b >= 0; --b) block_inv(lw, lh, lv, a.cw, psa, psb, b, sub, x);
     }
-    a.out[gi * 3] = x[0]; a.out[gi * 3 + 1] = x[1]; a.out[gi * 3 + 2] = x[2];
+    if (sub == 0) { a.out[gi * 3] = x[0]; a.out[gi * 3 + 1] = x[1]; a.out[gi * 3 + 2] = x[2]; }
 }
 
 __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
@@ -198,8 +211,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     float* lv = lh + 3 * kHeadBlock;
     const int view = blockIdx.y;
     stage_weights(a, lw, lh, lv, view);
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_pts) return;
+    const int sub = threadIdx.x & (kQuad - 1);
+    const long long p = (long long)blockIdx.x * (blockDim.x / kQuad) + (threadIdx.x >> 2);
+    if (p >= a.n_pts) return;                     // whole quads leave together
     const long long gi = (long long)view * a.n_pts + p;
     const float psa = a.ps_a ? a.ps_a[p] : 1.f, psb = a.ps_b ? a.ps_b[p] : 1.f;
     float xin[3][3];
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
         for (int b = 0; b < 3; ++b) {
             xin[b][0] = x[0]; xin[b][1] = x[1]; xin[b][2] = x[2];
-            block_fwd(lw, lh, lv, a.cw, psa, psb, b, x);
+            block_fwd(lw, lh, lv, a.cw, psa, psb, b, sub, x);
         }
     }
     float gx[3] = {a.d_out[gi * 3], a.d_out[gi * 3 + 1], a.d_out[gi * 3 + 2]};
@@ -226,9 +240,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         const float oth[2] = {xin[b][o0], xin[b][o1]};
         float ea[kEa], eb[kEb], o[3];
         embed<2>(oth, a.cw, psa, ea);
-        const float foc[1] = {xin[b][f] - part_a(lw, lh, lv, b, ea)};
+        const float foc[1] = {xin[b][f] - part_a(lw, lh, lv, b, sub, ea)};
         embed<1>(foc, a.cw, psb, eb);
-        part_b(lw, lh, lv, b, eb, o);
+        part_b(lw, lh, lv, b, sub, eb, o);
         float s, c;
         sincosf(o[0], &s, &c);
         const float d0 = oth[0] - o[1], d1 = oth[1] - o[2];
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         float geb[kEb];
 #pragma unroll
         for (int k = 0; k < kEb; ++k) geb[k] = 0.f;
-        for (int u = 0; u < kHid; ++u) {
+        for (int u = sub; u < kHid; u += kQuad) {
             const float pre = vb[u] + dot_row<kEb>(Wb + u * kEb, eb);
             const float gh = hdb[u] * go[0] + hdb[kHid + u] * go[1] + hdb[2 * kHid + u] * go[2];
             const float gp = gh * dsoftplus100(pre);
@@ -250,6 +264,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
 #pragma unroll
             for (int k = 0; k < kEb; ++k) geb[k] += Wb[u * kEb + k] * gp;
         }
+#pragma unroll
+        for (int k = 0; k < kEb; ++k) geb[k] = quad_sum(geb[k]);
         float gfoc[1];
         embed_bwd<1>(eb, geb, psb, gfoc);
         const float g_foc = gx[f] + gfoc[0];          // d focus'
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         float gea[kEa];
 #pragma unroll
         for (int k = 0; k < kEa; ++k) gea[k] = 0.f;
-        for (int u = 0; u < kHid; ++u) {
+        for (int u = sub; u < kHid; u += kQuad) {
             const float pre = va[u] + dot_row<kEa>(Wa + u * kEa, ea);
             const float gp = g_delta * hda[u] * dsoftplus100(pre);
             ws[(long long)(kRowGa + u) * P] = gp;
@@ -266,23 +282,30 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
 #pragma unroll
             for (int k = 0; k < kEa; ++k) gea[k] += Wa[u * kEa + k] * gp;
         }
+#pragma unroll
+        for (int k = 0; k < kEa; ++k) gea[k] = quad_sum(gea[k]);
         float goth[2];
         embed_bwd<2>(ea, gea, psa, goth);
         // ---- per-point factors of the parameter gradients
+        // (the factor rows that do not depend on the hidden unit are split over the quad)
 #pragma unroll
-        for (int k = 0; k < 32; ++k) ws[(long long)(kRowEa + k) * P] = k < kEa ? ea[k] : 0.f;
+        for (int k = 0; k < 32; ++k)
+            if ((k & 3) == sub) ws[(long long)(kRowEa + k) * P] = k < kEa ? ea[k] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) ws[(long long)(kRowEb + k) * P] = k < kEb ? eb[k] : 0.f;
-        for (int v = 0; v < 64; ++v) ws[(long long)(kRowInd + v) * P] = v == view ? 1.f : 0.f;
-        ws[(long long)(kRowGo + 0) * P] = g_delta;
-        ws[(long long)(kRowGo + 1) * P] = go[0];
-        ws[(long long)(kRowGo + 2) * P] = go[1];
-        ws[(long long)(kRowGo + 3) * P] = go[2];
+        for (int k = 0; k < 32; ++k)
+            if ((k & 3) == sub) ws[(long long)(kRowEb + k) * P] = k < kEb ? eb[k] : 0.f;
+        for (int v = sub; v < 64; v += kQuad) ws[(long long)(kRowInd + v) * P] = v == view ? 1.f : 0.f;
+        if (sub == 0) {
+            ws[(long long)(kRowGo + 0) * P] = g_delta;
+            ws[(long long)(kRowGo + 1) * P] = go[0];
+            ws[(long long)(kRowGo + 2) * P] = go[1];
+            ws[(long long)(kRowGo + 3) * P] = go[2];
+        }
         gx[f] = g_foc;
         gx[o0] = g_d0 + goth[0];
         gx[o1] = g_d1 + goth[1];
     }
-    if (a.d_pts) { a.d_pts[gi * 3] = gx[0]; a.d_pts[gi * 3 + 1] = gx[1]; a.d_pts[gi * 3 + 2] = gx[2]; }
+    if (a.d_pts && sub == 0) { a.d_pts[gi * 3] = gx[0]; a.d_pts[gi * 3 + 1] = gx[1]; a.d_pts[gi * 3 + 2] = gx[2]; }
 }
 
 // reduce the partial tiles of the two GEMM families and scatter into d_w_emb / d_view_b / d_w_head
@@ -351,7 +374,7 @@ extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float
     a.out = out; a.inverse = inverse;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
-    warp_fwd_kernel<<<dim3((unsigned)((n_pts + 255) / 256), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
+    warp_fwd_kernel<<<dim3((unsigned)((n_pts + 63) / 64), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_fwd");
     return NIW_OK;
 }
@@ -378,7 +401,7 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
         (void)hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
-    warp_bwd_kernel<<<dim3((unsigned)((n_pts + 255) / 256), n_views), 256, kWarpLds, st>>>(a);
+    warp_bwd_kernel<<<dim3((unsigned)((n_pts + 63) / 64), n_views), 256, kWarpLds, st>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_bwd");
     float* p1 = workspace + 3ll * kRowsPerBlock * ppad;
     float* p2 = p1 + 3ll * 256 * (256 * 256 + 256);
