@@ -18,7 +18,7 @@ _BASE = dict(
     camera=dict(model="perspective", ndc=False),
     loss_weight=dict(render=0, render_fine=None, global_alignment=None),
     optim=dict(lr=1e-3, lr_end=1e-4, lr_pose=5e-4, lr_pose_end=1e-8, test_photo=True, test_iter=100),
-    inn=dict(real_nvp=dict(c2f=True, max_pe_iter=100000, d_hidden=128, multires=6), actfn="softplus"),
+    inn=dict(real_nvp=dict(c2f=True, max_pe_iter=100000, d_hidden=128, multires=6, latent_dim=128), actfn="softplus"),
     warp_latent=dict(enc_type="l2fbarf", embed_dim=128),
 )
 

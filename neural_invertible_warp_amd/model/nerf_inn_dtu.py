@@ -1,0 +1,73 @@
+"""Mirror of the reference's model/nerf_inn_dtu.py `Graph` (363-567) and `NeRF` (569-680): the DTU
+copy of the INN graph.  Differences from the LLFF copy: the depth range of metric sampling comes
+from the data (`var.depth_range[0]`, :373-376) and is threaded through render / render_local /
+sample_depth; the alignment loss uses the detached Kabsch pose kept by the pose network
+(:410-414); the inverse-CDF bins still use the yaml range (:549), as in the reference."""
+import torch
+
+from .. import camera, ops
+from ..util import edict
+from . import nerf, nerf_inn_llff
+
+
+class NeRF(nerf.NeRF):
+    """reference nerf_inn_dtu.py:569-680 (duplicate of model/nerf.py's NeRF)"""
+
+
+class Graph(nerf_inn_llff.Graph):
+
+    def __init__(self, opt):
+        torch.nn.Module.__init__(self)
+        self.nerf = NeRF(opt)
+        if opt.nerf.fine_sampling:
+            self.nerf_fine = NeRF(opt)
+
+    def forward(self, opt, var, mode=None, iter=None):
+        """reference nerf_inn_dtu.py:371-396"""
+        batch_size = len(var.idx)
+        depth_range = opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else [float(x) for x in var.depth_range[0]]
+        if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
+            var.ray_idx = self.draw_ray_idx(opt, batch_size)
+            ray, center, grid_3d = self.get_pose(opt, var, mode=mode, iter=iter)
+            ret = self.render_local(opt, ray, center, intr=var.intr, mode=mode, depth_range=depth_range)
+            ret.update(grid_local=grid_3d, center_local=center, grid_init=self.pose_net.grid_init, center_init=self.pose_net.center_init)
+        else:
+            pose_w2c = self.get_pose(opt, var, mode=mode)
+            ret = self.render_by_slices(opt, pose_w2c, intr=var.intr, mode=mode, depth_range=depth_range) if opt.nerf.rand_rays else \
+                self.render(opt, pose_w2c, intr=var.intr, mode=mode, depth_range=depth_range)
+        var.update(ret)
+        return var
+
+    def compute_loss(self, opt, var, mode=None):
+        """reference nerf_inn_dtu.py:398-415"""
+        loss = nerf.Graph.compute_loss(self, opt, var, mode=mode)
+        if mode == "train" and opt.loss_weight.global_alignment is not None:
+            target = torch.cat([var.grid_local, var.center_local], dim=1)
+            source = torch.cat([var.grid_init, var.center_init], dim=1)
+            pose_global_w2c = self.pose_net.get_w2c_poses()
+            loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, pose_global_w2c))
+        return loss
+
+    def render(self, opt, pose, intr=None, ray_idx=None, mode=None, depth_range=None):
+        """reference nerf_inn_dtu.py:472-509"""
+        center, ray = camera.get_center_and_ray(opt, pose, intr=intr, ray_idx=ray_idx)
+        if opt.camera.ndc:
+            center, ray = camera.convert_NDC(opt, center, ray, intr=intr)
+        return self._render_rays(opt, center, ray, mode=mode, depth_range=depth_range)
+
+    def render_by_slices(self, opt, pose, intr=None, mode=None, depth_range=None):
+        """reference nerf_inn_dtu.py:511-522"""
+        ret_all = edict(rgb=[], depth=[], opacity=[])
+        if opt.nerf.fine_sampling:
+            ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
+        for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
+            ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
+            ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode, depth_range=depth_range)
+            for k in ret: ret_all[k].append(ret[k])
+        for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)
+        return ret_all
+
+    def sample_depth(self, opt, batch_size, num_rays=None, depth_range=None):
+        """reference nerf_inn_dtu.py:524-546 (explicit depth_range)"""
+        return nerf.Graph.sample_depth(self, opt, batch_size, num_rays=num_rays,
+                                       depth_range=opt.nerf.depth.range if depth_range is None else depth_range)

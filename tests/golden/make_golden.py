@@ -396,6 +396,58 @@ def main():
                 out[f"grad.{k}"] = gsum(prm.grad)
         save(f"inn_step_{tag}", **out)
 
+    # ---------------------------------------------------------------- G0 DTU INN step (cfg-5 like): noisy initial poses,
+    # data depth range, warp through INNPoseParams.  The reference's model/barf_inn_dtu.py module pulls the COLMAP /
+    # PDC-Net tool chain in at import time, so its 3-line Graph.get_pose dispatch (barf_inn_dtu.py:535-545) is restated
+    # on top of the reference's own nerf_inn_dtu.Graph; every number below is produced by reference functions
+    # (INNPoseParams.get_warped_rays_in_world, nerf_inn_dtu.Graph.forward / render_local / compute_loss).
+    import roma
+    from oracle import niw_oracle as _O
+    roma.rigid_points_registration = lambda x, y, *a, **k: _O.rigid_registration(x, y)   # only feeds the detached pose_global
+    import model.nerf_inn_dtu as ref_dtu
+    from model.pose_models.inn import INNPoseParams
+
+    class _DtuGraph(ref_dtu.Graph):
+        def __init__(self, opt, pose_net):
+            super().__init__(opt)
+            self.pose_net = pose_net
+
+        def get_pose(self, opt, var, mode=None, iter=None):
+            return self.pose_net.get_warped_rays_in_world(var, mode, iter)
+
+    o5 = load_opt("barf_inn_dtu", "barf_inn_dtu", **{"data.image_size": [H, W]})
+    o5.nerf.sample_intvs, o5.nerf.rand_rays = S, Rr * B
+    o5.loss_weight.global_alignment = None
+    pose_init = rand_pose(rng, B, rot=0.15, trans=0.15)
+    pn = INNPoseParams(o5, num_poses=B, initial_poses_w2c=pose_init, device="cpu")
+    set_params(pn.pose_embedding, O.make_warp_params(seed=64, perturb=0.02))
+    with torch.no_grad():
+        pn.pose_latent.weight.copy_(O.make_latent(63, B))
+    g = _DtuGraph(o5, pn)
+    set_params(g.nerf, O.make_nerf_params(seed=61))
+    u = torch.from_numpy(rng.uniform(0, 1, (B, Rr, S, 1)).astype(np.float32))
+    ray_idx = torch.from_numpy(rng.permutation(H * W)[:Rr].astype(np.int64))
+    image = torch.from_numpy(rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32))
+    depth_range = torch.tensor([[1.2, 5.2]] * B)
+    var = edict(idx=torch.arange(B), image=image, intr=intr, pose=pose_init, depth_range=depth_range)
+    _perm = torch.randperm
+    torch.rand = lambda *a, **k: u.clone()
+    torch.randperm = lambda *a, **k: ray_idx.clone()
+    it = 45000
+    var = g.forward(o5, var, mode="train", iter=it)
+    torch.rand, torch.randperm = _rand, _perm
+    loss = g.compute_loss(o5, var, mode="train")
+    loss.render.backward()
+    out = dict(H=H, W=W, S=S, R=Rr, it=it, max_pe_iter=o5.inn.real_nvp.max_pe_iter, intr=intr, pose_init=pose_init, ray_idx=ray_idx, u=u,
+               image=image, depth_range=depth_range, seed_coarse=61, seed_latent=63, seed_warp=64, warp_perturb=0.02,
+               center=var.center_local, grid_3D=var.grid_local, grid_init=var.grid_init, center_init=var.center_init,
+               rgb=var.rgb, depth=var.depth, opacity=var.opacity, loss_render=loss.render)
+    for k, prm in list(g.nerf.named_parameters()) + [("pose_embedding." + n, p) for n, p in pn.pose_embedding.named_parameters()] + \
+            [("pose_latent.weight", pn.pose_latent.weight)]:
+        if prm.grad is not None:
+            out[f"grad.{k}"] = gsum(prm.grad)
+    save("inn_step_cfg5", **out)
+
 
 if __name__ == "__main__":
     main()
