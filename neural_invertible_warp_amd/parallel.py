@@ -60,14 +60,19 @@ class GradBucket:
         self.flat = torch.zeros(self.offsets[-1], device=device, dtype=torch.float32)
 
     def gather(self):
-        off = 0
-        for g in self.groups:
+        """One concatenation kernel per group (not one copy per parameter: a step is ~100 tensors)."""
+        for i, g in enumerate(self.groups):
+            seg = self.segment(i)
+            if all(p.grad is not None for p in g):
+                torch.cat([p.grad.reshape(-1) for p in g], out=seg)
+                continue
+            off = 0
             for p in g:
                 n = p.numel()
                 if p.grad is None:
-                    self.flat[off:off + n].zero_()
+                    seg[off:off + n].zero_()
                 else:
-                    self.flat[off:off + n].copy_(p.grad.reshape(-1))
+                    seg[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
         return self.flat
 
