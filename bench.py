@@ -151,7 +151,18 @@ def main():
     roofline = None
     if dom:
         a = kernels[dom]["tflops"]
-        roofline = dict(bound="mfma", kernel=dom, achieved=a, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=round(a / PEAK_FP32_MFMA, 4), traffic=None)
+        # HBM bytes per launch of that kernel: rocprofv3 PMC passes recorded in profiles/r1_traffic.json
+        # (FETCH_SIZE x2 + WRITE_SIZE, bytes per sample) times the samples one launch processes
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+                t = json.load(f)["bytes_per_sample"].get(dom)
+            if t:
+                traffic = dict(value=round((t["fetch_corrected"] + t["write"]) * kernels[dom]["samples_per_launch"] / 1e9, 3), unit="GB",
+                               source="profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
+        except (OSError, KeyError, ValueError):
+            pass
+        roofline = dict(bound="mfma", kernel=dom, achieved=a, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=round(a / PEAK_FP32_MFMA, 4), traffic=traffic)
 
     out = dict(metric="ray-samples/sec (warp+MLP+composite) on LLFF-fern, 1/2/4/8 GPUs + PSNR parity",
                value=evals_total * args.steps / dt, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
