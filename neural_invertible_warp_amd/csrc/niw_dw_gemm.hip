@@ -242,7 +242,7 @@ extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const fl
     NIW_REQUIRE((d_center == nullptr) == (d_ray == nullptr), "niw_mlp_bwd_dx: d_center and d_ray must both be given or both be NULL");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd_dx: empty input");
     NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_bwd_dx: unknown density activation %d", density_activ);
-    NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 27), "niw_mlp_bwd_dx: too many samples per call");
+    NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 24), "niw_mlp_bwd_dx: too many samples per call");
     return niw_launch_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
                                  d_center, d_ray, (hipStream_t)stream);
 }

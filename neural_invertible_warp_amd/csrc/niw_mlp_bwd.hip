@@ -27,47 +27,43 @@ struct MlpBwdArgs {
     int S, act, ray_grad;
 };
 
-// Epilogue policies for stream_layer() (niw_mlp_device.h).
+// Epilogue policies for stream_layer() (niw_mlp_device.h); all workspace traffic uses buffer addressing.
 // ReLU mask + hand-over + store: the mask source (the activation the forward saved for this layer's
 // input) is fetched one row block ahead; dY is stored feature-major for the dW pass.
 template <int NBOUT>
 struct MaskEpilogue {
-    const float* __restrict__ act_row0;
+    RowWindow act;                       // saved activations of the layer input (mask source)
     float (&out)[16 * NBOUT];
-    float* __restrict__ grad_row0;
-    long long mpad;
-    unsigned voff;
+    RowWindow grad;                      // where dY of the producing layer is stored
     bool valid;
     __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
+        const rsrc_t r0 = act.rsrc(nb * 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[r] = (act_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff];
+        for (int r = 0; r < 16; ++r) buf[r] = buf_load1(r0, act.voff4, reg_row(r) * act.pitch4);
     }
     __device__ __forceinline__ void epi(int nb, int r, float a, float p) {
         const float g = (valid && p > 0.f) ? a : 0.f;
         out[nb * 16 + r] = g;
-        (grad_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff] = g;
+        buf_store1(g, grad.rsrc(nb * 32), grad.voff4, reg_row(r) * grad.pitch4);
     }
 };
 // park a result in the workspace (d encoding slots of the skip connection, d view-encoding slots)
 struct StashEpilogue {
-    float* __restrict__ row0;
-    long long mpad;
-    unsigned voff;
+    RowWindow win;
     __device__ __forceinline__ void pre(int, float (&)[16]) const {}
     __device__ __forceinline__ void epi(int nb, int r, float a, float) {
-        (row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff] = a;
+        buf_store1(a, win.rsrc(nb * 32), win.voff4, reg_row(r) * win.pitch4);
     }
 };
 // add a parked result and keep the sum in registers
 template <int NBOUT>
 struct AddStashEpilogue {
-    const float* __restrict__ row0;
+    RowWindow win;
     float (&out)[16 * NBOUT];
-    long long mpad;
-    unsigned voff;
     __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
+        const rsrc_t r0 = win.rsrc(nb * 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[r] = (row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff];
+        for (int r = 0; r < 16; ++r) buf[r] = buf_load1(r0, win.voff4, reg_row(r) * win.pitch4);
     }
     __device__ __forceinline__ void epi(int nb, int r, float a, float p) { out[nb * 16 + r] = a + p; }
 };
@@ -118,6 +114,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);     // plain feature-major [row][Mpad] (see niw_mlp_fwd.hip)
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
     const long long P = a.Mpad;
+    const PackedWeights pw = packed_weights(a.packed, lane);
+    const int pitch4 = (int)(P * 4), voff4 = (int)((4ll * h * P + m) * 4);
+    auto swin = [&](int r) { return RowWindow{a.save + (long long)r * P, pitch4, voff4}; };     // activation rows
+    auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };     // gradient rows
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
 
     float dy[128], nxt[128];
@@ -140,17 +140,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     float dyr[64];
     {
-        MaskEpilogue<4> ep{a.save + (long long)kSaveHr * P, dyr, a.grad + (long long)kGradRgb0 * P, P, voff, valid};
-        stream_layer<1, 0, 4, 4>(wp + bwd_pack_off(9) / 4, lane, dy9, none, ep);
+        MaskEpilogue<4> ep{swin(kSaveHr), dyr, gwin(kGradRgb0), valid};
+        stream_layer<1, 0, 4, 4>(pw, wp + bwd_pack_off(9) / 4, dy9, none, ep);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = row block 8 of 9)
     if (a.ray_grad) {
-        StashEpilogue ep{a.grad + (long long)kGradStashVenc * P, P, voff};
-        stream_layer<16, 0, 1, 9>(wp + bwd_pack_off(8) / 4 + 8 * 64, lane, dyr, none, ep);
+        StashEpilogue ep{gwin(kGradStashVenc)};
+        stream_layer<16, 0, 1, 9>(pw, wp + bwd_pack_off(8) / 4 + 8 * 64, dyr, none, ep);
     }
     {
-        MaskEpilogue<8> ep{a.save + (long long)kSaveFeat * P, dy, a.grad + (long long)kGradY7 * P, P, voff, valid};
-        stream_layer<16, 0, 8, 9>(wp + bwd_pack_off(8) / 4, lane, dyr, none, ep);
+        MaskEpilogue<8> ep{swin(kSaveFeat), dy, gwin(kGradY7), valid};
+        stream_layer<16, 0, 8, 9>(pw, wp + bwd_pack_off(8) / 4, dyr, none, ep);
     }
     // ---- density head: d sigma_raw (kernel row 256 of layer 7)
     float dsig[4] = {0.f, 0.f, 0.f, 0.f};
@@ -167,40 +167,40 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
-        MaskEpilogue<8> ep{a.save + (long long)save_h(7) * P, nxt, a.grad + 6ll * 256 * P, P, voff, valid};
-        stream_layer<32, 1, 8, 8>(wp + bwd_pack_off(7) / 4, lane, dy, dsig, ep);
+        MaskEpilogue<8> ep{swin(save_h(7)), nxt, gwin(6 * 256), valid};
+        stream_layer<32, 1, 8, 8>(pw, wp + bwd_pack_off(7) / 4, dy, dsig, ep);
         advance();
     }
     // ---- layers 6, 5 transposed: produce dY5, dY4
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
-        MaskEpilogue<8> ep{a.save + (long long)save_h(l) * P, nxt, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid};
-        stream_layer<32, 0, 8, 8>(wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, dy, none, ep);
+        MaskEpilogue<8> ep{swin(save_h(l)), nxt, gwin((l - 1) * 256), valid};
+        stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), dy, none, ep);
         advance();
     }
     // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots = row blocks 8, 9 of 10)
     if (a.ray_grad) {
-        StashEpilogue ep{a.grad + (long long)kGradStashEnc * P, P, voff};
-        stream_layer<32, 0, 2, 10>(wp + bwd_pack_off(4) / 4 + 8 * 64, lane, dy, none, ep);
+        StashEpilogue ep{gwin(kGradStashEnc)};
+        stream_layer<32, 0, 2, 10>(pw, wp + bwd_pack_off(4) / 4 + 8 * 64, dy, none, ep);
     }
     {
-        MaskEpilogue<8> ep{a.save + (long long)save_h(4) * P, nxt, a.grad + 3ll * 256 * P, P, voff, valid};
-        stream_layer<32, 0, 8, 10>(wp + bwd_pack_off(4) / 4, lane, dy, none, ep);
+        MaskEpilogue<8> ep{swin(save_h(4)), nxt, gwin(3 * 256), valid};
+        stream_layer<32, 0, 8, 10>(pw, wp + bwd_pack_off(4) / 4, dy, none, ep);
         advance();
     }
     // ---- layers 3, 2, 1 transposed: produce dY2, dY1, dY0
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
-        MaskEpilogue<8> ep{a.save + (long long)save_h(l) * P, nxt, a.grad + (long long)(l - 1) * 256 * P, P, voff, valid};
-        stream_layer<32, 0, 8, 8>(wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, dy, none, ep);
+        MaskEpilogue<8> ep{swin(save_h(l)), nxt, gwin((l - 1) * 256), valid};
+        stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), dy, none, ep);
         advance();
     }
     if (!a.ray_grad) return;
     // ---- layer 0 transposed: 256 -> 64 encoding slots (+ the parked skip-connection part)
     float denc[32], dvenc[16];
     {
-        AddStashEpilogue<2> ep{a.grad + (long long)kGradStashEnc * P, denc, P, voff};
-        stream_layer<32, 0, 2, 2>(wp + bwd_pack_off(0) / 4, lane, dy, none, ep);
+        AddStashEpilogue<2> ep{gwin(kGradStashEnc), denc};
+        stream_layer<32, 0, 2, 2>(pw, wp + bwd_pack_off(0) / 4, dy, none, ep);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dvenc[r] = (a.grad + (long long)(kGradStashVenc + 8 * (r >> 2) + (r & 3)) * P)[voff];
     }

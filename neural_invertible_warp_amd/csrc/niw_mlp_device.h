@@ -13,6 +13,49 @@ namespace niw {
 __device__ __forceinline__ float band_freq(int k) { return 3.14159274101257324f * (float)(1 << k); }
 
 // ---------------------------------------------------------------------------------------------
+// Buffer addressing.  Measured on MI355X (scratch/mfma_ceiling.hip): a global_load/store whose 64
+// lanes each carry a 64-bit address costs the issuing wave ~17 (load) / ~24 (store) cycles that a
+// dependent MFMA chain cannot hide -- 6.5 % + 4.7 % of this kernel shape.  The same access through
+// a buffer instruction (SGPR descriptor + SGPR byte offset + ONE 32-bit lane offset shared by all
+// accesses) is free: 154 TFLOP/s (98 %) versus 136.  Every hot-loop access therefore goes through
+// raw_buffer_load/store; byte offsets must stay below 2^31 (the host caps Mpad accordingly).
+// ---------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// The packed-weight image of one network (niw_mlp_pack_weights) as seen by a wave.
+struct PackedWeights {
+    rsrc_t rsrc;
+    const float* base;
+    int lane16;          // this lane's byte offset inside a 1 KiB fragment
+};
+__device__ __forceinline__ PackedWeights packed_weights(const float* packed, int lane) {
+    return PackedWeights{make_rsrc(packed), packed, lane * 16};
+}
+
+// A feature-major workspace [rows][Mpad] (saved activations / gradients) as seen by a lane:
+// element (row0 + rr, this lane's row-of-half and sample) = descriptor(row0) + rr*pitch4 + voff4.
+struct RowWindow {
+    const float* base;   // first row of the window
+    int pitch4;          // Mpad * 4 bytes
+    int voff4;           // (4*h*Mpad + m) * 4 bytes
+    __device__ __forceinline__ rsrc_t rsrc(int row) const { return make_rsrc(base + (long long)row * (pitch4 >> 2)); }
+};
+// row offset inside a 32-row block of accumulator register r (the lane half's +4 rows live in voff4)
+__device__ __forceinline__ constexpr int reg_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// ---------------------------------------------------------------------------------------------
 // Streaming register-chained layer.
 //
 //   out[n][m] = sum_k A[n][k] * B[k][m]      A = packed weight fragments (global, L2 resident)
@@ -22,29 +65,31 @@ __device__ __forceinline__ float band_freq(int k) { return 3.14159274101257324f 
 // accumulator (16 registers) is being produced at a time.  While block nb accumulates, the
 // epilogue of block nb-1 (accumulator -> activation/mask -> next-layer operand + store) is
 // spread over the MFMA gaps of block nb: the wave is in-order and a dependent
-// v_mfma_f32_32x32x2_f32 cannot issue for 64 cycles, so VALU/VMEM work placed between two MFMAs
-// of one chain is free.  Only the last block's epilogue is exposed.
+// v_mfma_f32_32x32x2_f32 cannot issue for 64 cycles, so work placed between two MFMAs of one
+// chain is free.  Only the last block's epilogue is exposed.
 //
-//   * weight fragments: one coalesced 16 B/lane load per (row block, k-block), an 8-deep ring
-//     keeps 8 loads (>= 2048 MFMA cycles) in flight; the ring index is compile-time;
+//   * weight fragments: one coalesced 16 B/lane buffer load per (row block, k-block), a ring keeps
+//     NIW_RING_DEPTH loads (>= 2048 MFMA cycles) in flight; the ring index is compile-time;
 //   * per-block epilogue inputs (bias / saved activation for the ReLU mask) are fetched by
 //     `pol.pre(nb, buf)` at the START of block nb and consumed during block nb+1;
 //   * `pol.epi(nb, r, acc_r, pre_r)` handles accumulator register r of block nb.
 //
-// STRIDE = row blocks per k-block in the packed image ([k-block][row block][lane][4]).
+// `wp` points at the first fragment of the (sub-range of the) layer inside the packed image;
+// STRIDE = row blocks per k-block there ([k-block][row block][lane][4]).
 // sched_barrier(0) after every k-block pins this order (hipcc otherwise sinks the loads next to
 // their uses and gathers the epilogue at the end).
 // ---------------------------------------------------------------------------------------------
 template <int KB1, int KB2, int NB, int STRIDE, typename Policy>
-__device__ __forceinline__ void stream_layer(const f32x4* __restrict__ wp, int lane, const float (&b1)[4 * KB1],
+__device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x4* __restrict__ wp, const float (&b1)[4 * KB1],
                                              const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol) {
     constexpr int KB = KB1 + KB2, N = NB * KB, D = NIW_RING_DEPTH, GAPS = 4 * KB;
     constexpr int G0 = GAPS >= 32 ? 8 : 0;                 // first gap used by the epilogue
     constexpr int GS = (GAPS - G0) / 16 > 0 ? (GAPS - G0) / 16 : 1;
+    const int base = (int)(reinterpret_cast<const char*>(wp) - reinterpret_cast<const char*>(pw.base));   // wave-uniform
     f32x4 ring[D];
 #pragma unroll
     for (int i = 0; i < D; ++i)
-        if (i < N) ring[i] = wp[((i % KB) * STRIDE + i / KB) * 64 + lane];
+        if (i < N) ring[i] = buf_load4(pw.rsrc, pw.lane16, base + ((i % KB) * STRIDE + i / KB) * 1024);
     f32x16 acc[2];
     float pre[2][16];
 #pragma unroll
@@ -57,7 +102,7 @@ __device__ __forceinline__ void stream_layer(const f32x4* __restrict__ wp, int l
         for (int q = 0; q < KB; ++q) {
             const int i = nb * KB + q;
             const f32x4 a = ring[i % D];
-            if (i + D < N) ring[i % D] = wp[(((i + D) % KB) * STRIDE + (i + D) / KB) * 64 + lane];
+            if (i + D < N) ring[i % D] = buf_load4(pw.rsrc, pw.lane16, base + (((i + D) % KB) * STRIDE + (i + D) / KB) * 1024);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float bv = q < KB1 ? b1[4 * (q < KB1 ? q : 0) + t] : b2[4 * (q >= KB1 ? q - KB1 : 0) + t];

@@ -133,18 +133,17 @@ __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* _
 // element offset `voff`, so every store is scalar-base + vector-offset.
 template <int NBOUT, bool RELU, bool SAVE>
 struct FwdEpilogue {
-    const float* __restrict__ bias;      // packed bias of the layer, already offset by h*16
+    const PackedWeights& pw;
+    int bias_bytes;                      // byte offset of the layer's packed bias ([row block][half][16])
+    int hoff;                            // this lane half's offset inside it: h * 64
     float (&out)[16 * NBOUT];
-    float* __restrict__ save_row0;
-    long long mpad;
-    unsigned voff;
+    RowWindow win;                       // where the layer's output rows live in the activation workspace
     float sig_raw;                       // kernel row 256 of layer 7 (row block NBOUT, register 0, half 0)
 
     __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
-        const f32x4* src = reinterpret_cast<const f32x4*>(bias + nb * 32);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 v = src[g];
+            const f32x4 v = buf_load4(pw.rsrc, hoff, bias_bytes + nb * 128 + g * 16);
             buf[4 * g] = v[0]; buf[4 * g + 1] = v[1]; buf[4 * g + 2] = v[2]; buf[4 * g + 3] = v[3];
         }
     }
@@ -152,12 +151,25 @@ struct FwdEpilogue {
         if (nb < NBOUT) {
             const float v = RELU ? fmaxf(a + p, 0.f) : a + p;
             out[nb * 16 + r] = v;
-            if (SAVE) (save_row0 + (long long)(nb * 32 + (r & 3) + 8 * (r >> 2)) * mpad)[voff] = v;
+            if (SAVE) buf_store1(v, win.rsrc(nb * 32), win.voff4, reg_row(r) * win.pitch4);
         } else if (r == 0) {
             sig_raw = a + p;
         }
     }
 };
+
+// Diagnostic build only (-DNIW_STAMPS): per-layer s_memtime stamps of every wave, read back with
+// niw_debug_read_stamps().  Never compiled into the product library.
+#ifdef NIW_STAMPS
+__device__ unsigned long long niw_stamps[8192 * 16];
+#define NIW_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        const int w_ = blockIdx.x * 4 + wave;                                                                \
+        if (lane == 0 && w_ < 8192) niw_stamps[w_ * 16 + (i)] = __builtin_readcyclecounter();                \
+    } while (0)
+#else
+#define NIW_STAMP(i) do {} while (0)
+#endif
 
 struct MlpFwdArgs {
     const float* packed;
@@ -187,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const bool valid = m < a.M;
     const long long mc = valid ? m : a.M - 1;
     const long long ri = mc / a.S;
+    NIW_STAMP(11);
 
     // ---- sample point and unit view direction (camera.py:517-521, nerf.py:452)
     float p[3], u[3];
@@ -204,72 +217,83 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     encode_slots<NIW_LVIEW, 4>(u, a.wview, h, venc);
     // Workspace layout: plain feature-major [row][Mpad].  (A blocked [128-sample block][row][128]
     // image was measured 10-14 % slower for this kernel and the dX chain on MI355X.)
-    const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);     // host guarantees 5*Mpad < 2^30
+    // All hot-loop memory traffic uses buffer addressing (see niw_mlp_device.h): host guarantees 128*Mpad < 2^31.
+    const PackedWeights pw = packed_weights(a.packed, lane);
+    const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)((4ll * h * a.Mpad + m) * 4), hoff = h * 64;
+    auto window = [&](int r) { return RowWindow{SAVE ? a.save + (long long)r * a.Mpad : nullptr, pitch4, voff4}; };
     if (SAVE) {
+        const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) (a.save + (long long)(kSaveEnc + 8 * (i >> 2) + (i & 3)) * a.Mpad)[voff] = enc[i];
+        for (int i = 0; i < 32; ++i) buf_store1(enc[i], we.rsrc(0), voff4, (8 * (i >> 2) + (i & 3)) * pitch4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) (a.save + (long long)(kSaveVenc + 8 * (i >> 2) + (i & 3)) * a.Mpad)[voff] = venc[i];
+        for (int i = 0; i < 16; ++i) buf_store1(venc[i], wv.rsrc(0), voff4, (8 * (i >> 2) + (i & 3)) * pitch4);
     }
 
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
     float act[128], nxt[128];
-    auto row = [&](int r) { return SAVE ? a.save + (long long)r * a.Mpad : nullptr; };
     auto advance = [&]() {
 #pragma unroll
         for (int i = 0; i < 128; ++i) act[i] = nxt[i];
     };
 
+    NIW_STAMP(0);
     // ---- layer 0: 63 -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(0) + h * 16, nxt, row(save_h(1)), a.Mpad, voff, 0.f};
-        stream_layer<8, 0, 8, 8>(wp + fwd_pack_off(0) / 4, lane, enc, none, ep);
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, window(save_h(1)), 0.f};
+        stream_layer<8, 0, 8, 8>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep);
         advance();
+        NIW_STAMP(1);
     }
     // ---- layers 1..3
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(1) + (l - 1) * 256 + h * 16, nxt, row(save_h(l + 1)), a.Mpad, voff, 0.f};
-        stream_layer<32, 0, 8, 8>(wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), lane, act, none, ep);
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, window(save_h(l + 1)), 0.f};
+        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep);
         advance();
+        NIW_STAMP(1 + l);
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(4) + h * 16, nxt, row(save_h(5)), a.Mpad, voff, 0.f};
-        stream_layer<32, 8, 8, 8>(wp + fwd_pack_off(4) / 4, lane, act, enc, ep);
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, window(save_h(5)), 0.f};
+        stream_layer<32, 8, 8, 8>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep);
         advance();
+        NIW_STAMP(5);
     }
     // ---- layers 5, 6
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(5) + (l - 5) * 256 + h * 16, nxt, row(save_h(l + 1)), a.Mpad, voff, 0.f};
-        stream_layer<32, 0, 8, 8>(wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), lane, act, none, ep);
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, window(save_h(l + 1)), 0.f};
+        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep);
         advance();
+        NIW_STAMP(1 + l);
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
-        FwdEpilogue<8, true, SAVE> ep{a.packed + bias_pack_off(7) + h * 16, nxt, row(kSaveFeat), a.Mpad, voff, 0.f};
-        stream_layer<32, 0, 9, 9>(wp + fwd_pack_off(7) / 4, lane, act, none, ep);
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(7), hoff, nxt, window(kSaveFeat), 0.f};
+        stream_layer<32, 0, 9, 9>(pw, wp + fwd_pack_off(7) / 4, act, none, ep);
         advance();
+        NIW_STAMP(8);
         float sig_raw = ep.sig_raw;
         if (a.noise != nullptr) sig_raw += a.noise[mc];
         if (h == 0) {
-            if (SAVE) (a.save + (long long)kSaveSigma * a.Mpad)[voff] = sig_raw;
+            if (SAVE) (a.save + (long long)kSaveSigma * a.Mpad)[m] = sig_raw;
             if (valid) a.sigma[m] = density_act(sig_raw, a.act);
         }
     }
     // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
     float hr[64];
     {
-        FwdEpilogue<4, true, SAVE> ep{a.packed + bias_pack_off(8) + h * 16, hr, row(kSaveHr), a.Mpad, voff, 0.f};
-        stream_layer<32, 4, 4, 4>(wp + fwd_pack_off(8) / 4, lane, act, venc, ep);
+        FwdEpilogue<4, true, SAVE> ep{pw, 4 * bias_pack_off(8), hoff, hr, window(kSaveHr), 0.f};
+        stream_layer<32, 4, 4, 4>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep);
+        NIW_STAMP(9);
     }
     // ---- colour layer 1: 128 -> 3, sigmoid
     {
         float o[16];
-        FwdEpilogue<1, false, false> ep{a.packed + bias_pack_off(9) + h * 16, o, nullptr, a.Mpad, voff, 0.f};
-        stream_layer<16, 0, 1, 1>(wp + fwd_pack_off(9) / 4, lane, hr, none, ep);
+        FwdEpilogue<1, false, false> ep{pw, 4 * bias_pack_off(9), hoff, o, window(0), 0.f};
+        stream_layer<16, 0, 1, 1>(pw, wp + fwd_pack_off(9) / 4, hr, none, ep);
+        NIW_STAMP(10);
         if (h == 0 && valid) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-o[c]));
@@ -280,6 +304,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
+#ifdef NIW_STAMPS
+extern "C" int niw_debug_read_stamps(unsigned long long* dst, int count) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(niw_stamps), sizeof(unsigned long long) * count);
+}
+#endif
+
 extern "C" int64_t niw_mlp_padded_rows(int64_t n_rays, int n_samples) {
     int64_t m = n_rays * (int64_t)n_samples;
     return (m + 127) / 128 * 128;
@@ -302,7 +332,7 @@ extern "C" int niw_mlp_fwd(const float* packed, const float* params, const float
     (void)params;
     NIW_REQUIRE(packed && center && ray && depth && rgb && sigma, "niw_mlp_fwd: null pointer");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_fwd: n_rays=%lld n_samples=%d must be positive", (long long)n_rays, n_samples);
-    NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 27), "niw_mlp_fwd: too many samples per call (%lld)", (long long)(n_rays * n_samples));
+    NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 24), "niw_mlp_fwd: too many samples per call (%lld)", (long long)(n_rays * n_samples));
     NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_fwd: unknown density activation %d", density_activ);
     MlpFwdArgs a;
     a.packed = packed; a.center = center; a.ray = ray; a.depth = depth; a.noise = noise;
