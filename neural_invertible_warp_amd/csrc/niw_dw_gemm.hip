@@ -214,7 +214,9 @@ int launch_piece(const Piece& p, NiwGemmOperand A, NiwGemmOperand B, long long m
     int rc = niw_launch_nt_gemm(p.wide, A, B, (int)(mpad / 32), mpad, 1, partial, bias_side, &nsplit, st);
     if (rc != NIW_OK) return rc;
     ReduceArgs r;
-    r.partial = partial; r.d_params = d_params; r.nsplit = nsplit; r.TN = 256; r.TK = p.wide ? 256 : 64; r.layer = p.layer;
+    r.partial = partial; r.d_params = d_params; r.nsplit = nsplit; r.layer = p.layer;
+    r.TN = p.wide == 2 ? 128 : 256;
+    r.TK = p.wide == 2 ? 288 : (p.wide == 1 ? 256 : 64);
     r.n_off = p.n_off; r.k_off = p.k_off; r.transposed = p.transposed; r.bias = p.bias;
     dw_reduce_kernel<<<(r.TN * r.TK + 256 + 255) / 256, 256, 0, st>>>(r);
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dW reduce)");
@@ -225,6 +227,8 @@ int launch_piece(const Piece& p, NiwGemmOperand A, NiwGemmOperand B, long long m
 
 int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
                        int bias_side, int* nsplit_out, hipStream_t st) {
+    // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
+    if (wide == 2) return launch_gemm<4, 1, 1, 9>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st);
     return wide ? launch_gemm<4, 2, 2, 4>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st)
                 : launch_gemm<8, 1, 1, 2>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st);
 }
@@ -267,8 +271,7 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         {6, 6 * 256, 256, save_h(6), 256, 0, 0, 0, 1, 1},
         {7, kGradY7, 256, save_h(7), 256, 0, 0, 0, 1, 1},
         {7, save_h(7), 256, kGradY7 + 256, 1, 256, 0, 1, 1, 0},          // density row (transposed)
-        {8, kGradRgb0, 128, kSaveFeat, 256, 0, 0, 0, 1, 1},
-        {8, kGradRgb0, 128, kSaveVenc, 32, 0, 256, 0, 0, 0},
+        {8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2},              // feat rows and the 32 view-slot rows are contiguous
         {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0},                  // colour rows (transposed)
     };
     for (const Piece& p : pieces) {

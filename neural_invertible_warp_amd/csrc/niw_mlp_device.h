@@ -95,8 +95,6 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         f32x16& cur = acc[nb & 1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cur[r] = 0.f;
         pol.pre(nb, pre[nb & 1]);
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
@@ -106,7 +104,8 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float bv = q < KB1 ? b1[4 * (q < KB1 ? q : 0) + t] : b2[4 * (q >= KB1 ? q - KB1 : 0) + t];
-                cur = mfma32(a[t], bv, cur);
+                // the block's first MFMA takes a literal zero accumulator (no 16-register clear, no VALU->MFMA hazard)
+                cur = mfma32(a[t], bv, (q == 0 && t == 0) ? f32x16{0.f} : cur);
                 const int gap = 4 * q + t;
                 if (nb > 0 && gap >= G0 && (gap - G0) % GS == 0 && (gap - G0) / GS < 16) {
                     const int r = (gap - G0) / GS;
