@@ -7,6 +7,10 @@
 #define NIW_RING_DEPTH 8
 #endif
 
+#ifdef NIW_STAMPS
+extern __device__ unsigned long long niw_stamps[8192 * 16];
+#endif
+
 namespace niw {
 
 // band frequency 2^k * fp32(pi)  (reference: 2**arange(L) * np.pi evaluated in fp32, nerf.py:478)
@@ -81,7 +85,17 @@ __device__ __forceinline__ constexpr int reg_row(int r) { return (r & 3) + 8 * (
 // ---------------------------------------------------------------------------------------------
 template <int KB1, int KB2, int NB, int STRIDE, typename Policy>
 __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x4* __restrict__ wp, const float (&b1)[4 * KB1],
-                                             const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol) {
+                                             const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol, int stamp_base = -1) {
+#ifdef NIW_STAMPS
+#define NIW_STAMP_L(k)                                                                                                     \
+    do {                                                                                                                   \
+        const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                                                \
+        if (stamp_base >= 0 && (threadIdx.x & 63) == 0 && w_ < 8192) niw_stamps[w_ * 16 + stamp_base + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define NIW_STAMP_L(k) do {} while (0)
+#endif
+    NIW_STAMP_L(0);
     constexpr int KB = KB1 + KB2, N = NB * KB, D = NIW_RING_DEPTH, GAPS = 4 * KB;
     constexpr int G0 = GAPS >= 32 ? 8 : 0;                 // first gap used by the epilogue
     constexpr int GS = (GAPS - G0) / 16 > 0 ? (GAPS - G0) / 16 : 1;
@@ -120,8 +134,10 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
                 if (G0 + r * GS >= GAPS) pol.epi(nb - 1, r, acc[(nb - 1) & 1][r], pre[(nb - 1) & 1][r]);
         }
     }
+    NIW_STAMP_L(1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) pol.epi(NB - 1, r, acc[(NB - 1) & 1][r], pre[(NB - 1) & 1][r]);
+    NIW_STAMP_L(2);
 }
 
 }  // namespace niw

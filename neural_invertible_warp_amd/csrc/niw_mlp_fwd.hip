@@ -161,7 +161,7 @@ struct FwdEpilogue {
 // Diagnostic build only (-DNIW_STAMPS): per-layer s_memtime stamps of every wave, read back with
 // niw_debug_read_stamps().  Never compiled into the product library.
 #ifdef NIW_STAMPS
-__device__ unsigned long long niw_stamps[8192 * 16];
+__device__ unsigned long long niw_stamps[8192 * 16];   // (declared extern in niw_mlp_device.h)
 #define NIW_STAMP(i)                                                                                         \
     do {                                                                                                     \
         const int w_ = blockIdx.x * 4 + wave;                                                                \
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, window(save_h(l + 1)), 0.f};
-        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep);
+        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, l == 2 ? 12 : -1);
         advance();
         NIW_STAMP(1 + l);
     }
