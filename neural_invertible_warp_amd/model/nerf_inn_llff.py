@@ -9,15 +9,35 @@ from ..util import edict
 from . import nerf
 
 
-def rigid_points_registration(x, y):
+def _all_reduce_sum(t):
+    """Differentiable SUM over ranks (identity without a process group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch.distributed.nn.functional as dist_fn
+        return dist_fn.all_reduce(t.contiguous(), op=dist.ReduceOp.SUM)
+    return t
+
+
+def rigid_points_registration(x, y, sharded=False):
     """R, t minimising sum ||R x + t - y||^2 over points [B,N,3] (Kabsch with reflection fix).
     Stands in for roma.rigid_points_registration (roma==1.4.1, reference requirements.txt:1, call
     site model/nerf_inn_llff.py:569); that package is not vendored in the reference, so this
     restates the published algorithm -- parity unpinned.  Differentiable: the
     reference does not detach the result (nerf_inn_llff.py:569-572).  Per-view 3x3 SVD on [B,3,3]
-    moments: host-side glue, not part of the per-sample path."""
-    xm, ym = x.mean(dim=1, keepdim=True), y.mean(dim=1, keepdim=True)
-    M = (y - ym).transpose(1, 2) @ (x - xm)
+    moments: host-side glue, not part of the per-sample path.
+    sharded=True (ray-shard data parallelism): every rank holds a slice of the points; the per-view
+    moments n, sum x, sum y, sum y x^T (16 floats per view) are summed over ranks before the SVD, so
+    all ranks obtain the registration of the GLOBAL point set."""
+    if sharded:
+        n = torch.full((x.shape[0], 1), float(x.shape[1]), device=x.device, dtype=x.dtype)
+        mom = torch.cat([n, x.sum(dim=1), y.sum(dim=1), (y.transpose(1, 2) @ x).reshape(x.shape[0], 9)], dim=1)
+        mom = _all_reduce_sum(mom)
+        n, sx, sy, syx = mom[:, :1], mom[:, 1:4], mom[:, 4:7], mom[:, 7:].reshape(-1, 3, 3)
+        xm, ym = (sx / n)[:, None], (sy / n)[:, None]
+        M = syx - n[:, :, None] * ym.transpose(1, 2) @ xm
+    else:
+        xm, ym = x.mean(dim=1, keepdim=True), y.mean(dim=1, keepdim=True)
+        M = (y - ym).transpose(1, 2) @ (x - xm)
     U, _, Vt = torch.linalg.svd(M)
     det = torch.det(U @ Vt)
     D = torch.diag_embed(torch.stack([torch.ones_like(det), torch.ones_like(det), det], dim=-1))
@@ -83,11 +103,17 @@ class Graph(nerf.Graph):
         if opt.loss_weight.global_alignment is not None and mode == "train":
             source = torch.cat([var.grid_cam, var.center_cam], dim=1)
             target = torch.cat([var.grid_3D, var.center], dim=1)
-            R_global, t_global = rigid_points_registration(target, source)
+            shard = getattr(opt, "ray_shard", None)
+            R_global, t_global = rigid_points_registration(target, source, sharded=shard is not None)
             svd_poses = torch.cat((R_global, t_global[..., None]), -1)
             if hasattr(self, "global_rigid"):
                 self.global_rigid.weight.data = svd_poses.detach().clone().view(-1, 12)
-            loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, svd_poses))
+            if shard is None:
+                loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, svd_poses))
+            else:
+                # this rank's share of the global mean (the gradient all-reduce sums the shares)
+                n_global = 3 * target.shape[0] * 2 * (opt.nerf.rand_rays // target.shape[0])   # grid + centre points of the global draw
+                loss.global_alignment = ((target - camera.cam2world(source, svd_poses)) ** 2).sum() / n_global
         return loss
 
     def get_pose(self, opt, var, mode=None):

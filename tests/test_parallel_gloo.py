@@ -58,7 +58,7 @@ def _worker(rank, world, port, q):
     bucket.gather()
     bucket.all_reduce()
     if rank == 0:
-        q.put(bucket.flat.clone())
+        q.put(bucket.flat.numpy().copy())          # by value: the worker exits right after
     dist.destroy_process_group()
 
 
@@ -69,7 +69,7 @@ def test_two_rank_gradients_equal_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    flat2 = q.get(timeout=300)
+    flat2 = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -100,3 +100,61 @@ def test_bucket_roundtrip_single_process():
     bk.flat.mul_(2)
     bk.scatter()
     assert torch.equal(a.grad, torch.full((3, 4), 4.0))
+
+
+# ---------------------------------------------------------------------------------------------
+# global-alignment (Kabsch) loss under ray sharding: per-view moments are all-reduced before the SVD
+# ---------------------------------------------------------------------------------------------
+def _ga_points(seed=3):
+    gen = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, 2 * R, 3, generator=gen)
+    tgt = (src @ torch.linalg.qr(torch.randn(3, 3, generator=gen))[0] + 0.1 * torch.randn(B, 2 * R, 3, generator=gen)).requires_grad_(True)
+    return src, tgt
+
+
+def _ga_worker(rank, world, port, q):
+    from neural_invertible_warp_amd import parallel
+    from neural_invertible_warp_amd.model import nerf_inn_llff
+    from neural_invertible_warp_amd.util import edict
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_from_env(backend="gloo")
+    src, tgt = _ga_points()
+    sel = torch.arange(2 * R)[rank::world]
+    g = nerf_inn_llff.Graph.__new__(nerf_inn_llff.Graph)
+    torch.nn.Module.__init__(g)
+    opt = edict(loss_weight=edict(render=None, render_fine=None, global_alignment=2), nerf=edict(rand_rays=R * B, fine_sampling=False),
+                ray_shard=(rank, world))
+    n = len(sel) // 2
+    var = edict(grid_cam=src[:, sel[:n]], center_cam=src[:, sel[n:]], grid_3D=tgt[:, sel[:n]], center=tgt[:, sel[n:]], idx=torch.arange(B),
+                ray_idx=torch.arange(n))
+    loss = g.compute_loss(opt, var, mode="train").global_alignment
+    loss.backward()
+    grad = tgt.grad.clone()
+    dist.all_reduce(grad)
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    if rank == 0:
+        q.put((float(lsum), grad.numpy()))        # by value: the worker exits right after
+    dist.destroy_process_group()
+
+
+def test_sharded_kabsch_alignment_loss_matches_single_process():
+    from neural_invertible_warp_amd import camera
+    from neural_invertible_warp_amd.model.nerf_inn_llff import rigid_points_registration
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ga_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    lsum, grad2 = q.get(timeout=90)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    src, tgt = _ga_points()
+    Rg, tg = rigid_points_registration(tgt, src)
+    loss = ((tgt - camera.cam2world(src, torch.cat([Rg, tg[..., None]], -1))) ** 2).mean()
+    loss.backward()
+    assert abs(float(lsum) - float(loss)) < 1e-6 * max(1.0, float(loss))
+    assert (tgt.grad - torch.from_numpy(grad2)).abs().max() <= 1e-4 * tgt.grad.abs().max()
