@@ -92,21 +92,29 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(NiwGemmOperand op
         if (s + 1 < nsteps) gload(step0 + s + 1);
         const float* As = lds + buf * ROWS * kLdsStride;
         const float* Bs = As + TN * kLdsStride;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f32x4 af[NBW], bf[KBW];
+        // fragment reads of k-block kb+1 are issued before the MFMAs of k-block kb (the two waves of a SIMD are
+        // barrier-synchronised, so without this both sit in the LDS latency at the same time)
+        f32x4 af[2][NBW], bf[2][KBW];
+        auto lread = [&](int kb, int slot) {
 #pragma unroll
             for (int x = 0; x < NBW; ++x)
-                af[x] = *reinterpret_cast<const f32x4*>(As + ((wn * NBW + x) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+                af[slot][x] = *reinterpret_cast<const f32x4*>(As + ((wn * NBW + x) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
 #pragma unroll
             for (int y = 0; y < KBW; ++y)
-                bf[y] = *reinterpret_cast<const f32x4*>(Bs + ((wk * KBW + y) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+                bf[slot][y] = *reinterpret_cast<const f32x4*>(Bs + ((wk * KBW + y) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+        };
+        lread(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb + 1 < 4) lread(kb + 1, (kb + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int x = 0; x < NBW; ++x)
 #pragma unroll
                 for (int y = 0; y < KBW; ++y)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[x][y] = mfma32(af[x][t], bf[y][t], acc[x][y]);
+                    for (int t = 0; t < 4; ++t) acc[x][y] = mfma32(af[kb & 1][x][t], bf[kb & 1][y][t], acc[x][y]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (bias_side) {
             // row sums of the dY operand: thread t < rows sums its row of the staged slice
