@@ -17,7 +17,7 @@ namespace niw {
 __device__ __forceinline__ float band_freq(int k) { return 3.14159274101257324f * (float)(1 << k); }
 
 // ---------------------------------------------------------------------------------------------
-// Buffer addressing.  Measured on MI355X (scratch/mfma_ceiling.hip): a global_load/store whose 64
+// Buffer addressing.  Measured on MI355X (tools/mfma_ceiling.hip): a global_load/store whose 64
 // lanes each carry a 64-bit address costs the issuing wave ~17 (load) / ~24 (store) cycles that a
 // dependent MFMA chain cannot hide -- 6.5 % + 4.7 % of this kernel shape.  The same access through
 // a buffer instruction (SGPR descriptor + SGPR byte offset + ONE 32-bit lane offset shared by all
