@@ -36,15 +36,16 @@ class INNTrainer:
                     if "_1." in name or "_c." in name:
                         p.normal_(0.0, warp_perturb)
         self.nets = [self.graph.nerf] + ([self.graph.nerf_fine] if opt.nerf.fine_sampling else [])
-        self.warp_params = list(self.graph.warp_mlp.parameters()) + [self.graph.warp_latent.weight]
-        self.warp_flat = _flatten_params(self.warp_params)
-        dev = self.warp_flat.device
-        self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets] + [self.warp_params], dev)
-        self.flats = [n.flat_params for n in self.nets] + [self.warp_flat]
+        # optimizer groups = the flat buffers the kernels read (NeRF nets, warp network) + the latent table
+        latent = self.graph.warp_latent.weight
+        dev = latent.device
+        self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets] +
+                                          [list(self.graph.warp_mlp.parameters()), [latent]], dev)
+        self.flats = [n.flat_params for n in self.nets] + [self.graph.warp_mlp.flat_params, latent.data.view(-1)]
         self.m = [torch.zeros_like(f) for f in self.flats]
         self.v = [torch.zeros_like(f) for f in self.flats]
         o = opt.optim
-        self.lrs = [(o.lr, o.lr_end)] * len(self.nets) + [(o.lr_pose, o.lr_pose_end)]
+        self.lrs = [(o.lr, o.lr_end)] * len(self.nets) + [(o.lr_pose, o.lr_pose_end)] * 2
         self.it = 0
         if world > 1:
             opt.ray_shard = (rank, world)

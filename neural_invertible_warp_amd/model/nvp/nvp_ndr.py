@@ -4,9 +4,9 @@ constructor arguments, parameter names (lin{b}_a_0.weight_g/.weight_v/.bias, lin
 lin{b}_b_0.*, lin{b}_b_1.*, lin{b}_c.*), initialisation and forward / inverse signatures.
 
 Split of the work: the per-parameter / per-view preprocessing (weight norm, code projection,
-latent half of the first layers: O(parameters), [B,128]-sized tensors) is expressed with torch
-ops so autograd delivers d weight_g / d weight_v / d lin_c / d latent; everything per point
-(embedding, coupling blocks, rotations; forward, inverse and backward) runs in niw_warp_*.
+latent half of the first layers: O(parameters), [B,128]-sized tensors) is one fused launch
+(niw_warp_prep_fwd, backward niw_warp_prep_bwd) over the flat parameter buffer; everything per
+point (embedding, coupling blocks, rotations; forward, inverse and backward) runs in niw_warp_*.
 """
 import math
 
@@ -72,22 +72,40 @@ class DeformNetwork(torch.nn.Module):
         self._ea, self._eb = ea, eb
 
     # ------------------------------------------------------------------ operand preparation
+    def _ensure_flat(self):
+        """The kernels read the parameters from ONE flat buffer in parameters() order (layout documented in
+        csrc/niw_warp_prep.hip); the Parameters are views of it.  (Re-)flatten after construction, .to() /
+        .cuda() or any external re-assignment of parameter storage."""
+        ps = list(self.parameters())
+        flat = getattr(self, "_flat", None)
+        if flat is not None:
+            off, ok = 0, True
+            for p in ps:
+                if p.data_ptr() != flat.data_ptr() + 4 * off or p.device != flat.device:
+                    ok = False
+                    break
+                off += p.numel()
+            if ok:
+                return flat
+        flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+        assert flat.numel() == ops.WARP_PARAM_FLOATS
+        off = 0
+        for p in ps:
+            p.data = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self._flat = flat
+        return flat
+
+    @property
+    def flat_params(self):
+        return self._ensure_flat()
+
     def _operands(self, code):
-        """-> w_emb [3*(128*26+128*13)], view_b [B,3,2,128], w_head [3*516] (layout of include/niw.h)."""
-        w_emb, view_b, w_head = [], [], []
-        for b in range(self.n_blocks):
-            lin_c = getattr(self, f"lin{b}_c")
-            code_b = F.linear(code, lin_c.weight, lin_c.bias) + code            # nvp_ndr.py:381
-            vb = []
-            for part, e in (("a", self._ea), ("b", self._eb)):
-                l0 = getattr(self, f"lin{b}_{part}_0")
-                w = l0.weight()
-                w_emb.append(w[:, :e].reshape(-1))
-                vb.append(F.linear(code_b, w[:, e:], l0.bias))                 # latent columns folded per view
-            view_b.append(torch.stack(vb, dim=1))
-            a1, b1 = getattr(self, f"lin{b}_a_1"), getattr(self, f"lin{b}_b_1")
-            w_head += [a1.weight.reshape(-1), a1.bias, b1.weight.reshape(-1), b1.bias]
-        return torch.cat(w_emb), torch.stack(view_b, dim=1).contiguous(), torch.cat(w_head)
+        """-> w_emb [3*(128*26+128*13)], view_b [B,3,2,128], w_head [3*516] (layout of include/niw.h):
+        weight norm (nvp_ndr.py:291-292), code projection (:381) and the latent half of the first layers,
+        fused in niw_warp_prep_fwd / _bwd."""
+        flat = self._ensure_flat()
+        return ops.warp_prepare(flat, list(self.parameters()), code)
 
     def _anneal(self, n_pts, alpha_ratio, device):
         """-> (chan_w[6], pt_scale_a [P] | None, pt_scale_b [P] | None).  reference_exact: the

@@ -339,6 +339,55 @@ class _Warp(torch.autograd.Function):
         return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None
 
 
+WARP_PARAM_FLOATS = 165900
+WARP_WEMB_FLOATS = 3 * (128 * 26 + 128 * 13)
+WARP_WHEAD_FLOATS = 3 * (128 + 1 + 3 * 128 + 3)
+
+
+class _WarpPrep(torch.autograd.Function):
+    """Weight norm + code projection + latent folding of DeformNetwork in one launch (and one for the
+    backward).  `flat` is the parameter storage the module's Parameters are views of; the Parameters
+    themselves are passed so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, flat, code, *params):
+        code = _f32(code, "deformation_code")
+        B = code.shape[0]
+        dev = code.device
+        w_emb = torch.empty(WARP_WEMB_FLOATS, device=dev)
+        view_b = torch.empty(B, 3, 2, 128, device=dev)
+        w_head = torch.empty(WARP_WHEAD_FLOATS, device=dev)
+        _lib.call("niw_warp_prep_fwd", _p(flat), _p(code), B, _p(w_emb), _p(view_b), _p(w_head), _stream())
+        ctx.flat = flat
+        ctx.param_shapes = [p.shape for p in params]
+        ctx.save_for_backward(code)
+        return w_emb, view_b, w_head
+
+    @staticmethod
+    def backward(ctx, d_w_emb, d_view_b, d_w_head):
+        (code,) = ctx.saved_tensors
+        B = code.shape[0]
+        dev = code.device
+        z = lambda g, n: torch.zeros(n, device=dev) if g is None else _f32(g, "grad")
+        d_w_emb, d_view_b, d_w_head = z(d_w_emb, WARP_WEMB_FLOATS), z(d_view_b, B * 3 * 2 * 128), z(d_w_head, WARP_WHEAD_FLOATS)
+        scratch = torch.empty(3 * B * 128, device=dev)
+        d_params = torch.empty(WARP_PARAM_FLOATS, device=dev)
+        d_code = torch.empty(B, 128, device=dev)
+        _lib.call("niw_warp_prep_bwd", _p(ctx.flat), _p(code), B, _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(scratch),
+                  _p(d_params), _p(d_code), _stream())
+        grads, off = [], 0
+        for shp in ctx.param_shapes:
+            n = math.prod(shp)
+            grads.append(d_params[off:off + n].view(shp))
+            off += n
+        return (None, d_code, *grads)
+
+
+def warp_prepare(flat, params, code):
+    """-> (w_emb, view_b, w_head) in the operand layout of niw_warp_fwd."""
+    return _WarpPrep.apply(flat, code, *params)
+
+
 def warp_points(w_emb, view_b, w_head, pts, chan_w, ps_a=None, ps_b=None, inverse=False):
     """pts [B,P,3] -> warped [B,P,3]; see include/niw.h niw_warp_fwd for the operand layout."""
     return _Warp.apply(w_emb, view_b, w_head, pts, chan_w, ps_a, ps_b, inverse)

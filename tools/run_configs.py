@@ -1,0 +1,63 @@
+"""Functional run of every BASELINE config shape on one GPU (a few steps each): losses finite and decreasing,
+ray-samples/s printed.  Not the headline benchmark (bench.py is)."""
+import sys, time
+sys.path.insert(0, '.')
+import torch
+from neural_invertible_warp_amd import configs, engine, ops
+from neural_invertible_warp_amd.model import nerf, barf_inn_dtu
+from neural_invertible_warp_amd.model.pose_models.inn import INNPoseParams
+from neural_invertible_warp_amd.util import edict
+dev = 'cuda:0'
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize(); t = time.perf_counter()
+    out = [fn() for _ in range(n)]
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n, out
+
+# cfg1: vanilla NeRF, GT poses, relu density + noise, 64 + 128 hierarchical, Adam via torch
+opt = configs.cfg1_nerf_llff_repr(device=dev)
+g = nerf.Graph(opt)
+optim = torch.optim.Adam(g.parameters(), lr=opt.optim.lr)
+var0 = engine.synthetic_scene(opt, 18)
+def step1():
+    optim.zero_grad(set_to_none=True)
+    var = g.forward(opt, edict(var0), mode="train")
+    loss = g.compute_loss(opt, var, mode="train")
+    (loss.render + loss.render_fine).backward(); optim.step()
+    return float(loss.render.detach())
+dt, ls = timeit(step1)
+print(f"cfg1 {18*56*(64+192)/dt/1e6:.2f} M ray-samples/s  {dt*1e3:.2f} ms/step  losses {ls[0]:.4f} -> {ls[-1]:.4f}")
+
+# cfg3: barf_inn_llff, 2048 rays x 128, Kabsch alignment loss 10^4
+opt = configs.cfg3_barf_inn_llff(device=dev)
+tr = engine.INNTrainer(opt, 18, warp_perturb=0.02)
+var0 = engine.synthetic_scene(opt, 18)
+dt, ls = timeit(lambda: {k: float(v.detach()) for k, v in tr.train_iteration(edict(var0)).items()})
+print(f"cfg3 {18*113*128/dt/1e6:.2f} M ray-samples/s  {dt*1e3:.2f} ms/step  render {ls[0]['render']:.4f} -> {ls[-1]['render']:.4f}  ga {ls[0]['global_alignment']:.3e} -> {ls[-1]['global_alignment']:.3e}")
+
+# cfg5: barf_inn_dtu, 3 views x 682 rays x 128, metric depth from the data, noisy initial poses
+opt = configs.cfg5_barf_inn_dtu(device=dev)
+B = 3
+pose0 = torch.eye(3, 4, device=dev).repeat(B, 1, 1); pose0[:, :, 3] = torch.tensor([0., 0., 3.], device=dev) + 0.1 * torch.randn(B, 3, device=dev)
+pn = INNPoseParams(opt, num_poses=B, initial_poses_w2c=pose0, device=dev)
+g5 = barf_inn_dtu.Graph(opt, pn)
+optim5 = torch.optim.Adam(list(g5.nerf.parameters()) + list(pn.parameters()), lr=1e-3)
+var0 = engine.synthetic_scene(opt, B); var0.depth_range = torch.tensor([[1.2, 5.2]] * B, device=dev)
+it = [0]
+def step5():
+    it[0] += 1
+    optim5.zero_grad(set_to_none=True)
+    var = g5.forward(opt, edict(var0), mode="train", iter=it[0])
+    loss = g5.compute_loss(opt, var, mode="train")
+    (loss.render + 1e3 * loss.global_alignment).backward(); optim5.step()
+    return float(loss.render.detach()), float(loss.global_alignment.detach())
+dt, ls = timeit(step5)
+print(f"cfg5 {B*682*128/dt/1e6:.2f} M ray-samples/s  {dt*1e3:.2f} ms/step  render {ls[0][0]:.4f} -> {ls[-1][0]:.4f}  ga {ls[0][1]:.3e}")
+
+# eval path: full 300x400 image of one view through render_by_slices (no grad)
+opt = configs.cfg3_barf_inn_llff(device=dev)
+gr = nerf.Graph(opt)
+with torch.no_grad():
+    dt, _ = timeit(lambda: gr.render_by_slices(opt, var0.pose[:1], intr=var0.intr[:1], mode="eval"), n=2)
+print(f"eval: 300x400 image, 128 samples/ray in {dt*1e3:.1f} ms ({120000*128/dt/1e6:.1f} M ray-samples/s forward only, {-(-120000//opt.nerf.rand_rays)} slices)")
