@@ -4,9 +4,12 @@ Ray generation runs in libniw_hip.so (niw_raygen / niw_convert_ndc).  The pose a
 here (Pose, cam2world on [B,N,3] point sets) is host glue on [B,3,4] matrices used by the
 alignment loss and evaluation poses, not part of the per-sample path.
 """
+import math
+
 import torch
 
 from . import ops
+from .util import edict
 
 
 def to_hom(X):
@@ -46,7 +49,110 @@ class Pose:
         return out
 
 
+class Lie:
+    """so(3) / se(3) exponential and logarithm with the closed-form coefficients evaluated as truncated
+    power series in theta^2 (terms up to theta^20), reference camera.py:193-274.  Host-side [.,6]-sized
+    algebra (test-time pose refinement, noisy initial poses); not on the per-sample path."""
+    _TERMS = 11
+
+    @staticmethod
+    def _series(theta, first_factorial):
+        # sum_i (-1)^i theta^(2i) / (2i + first_factorial)!   evaluated by Horner in theta^2
+        x2 = theta * theta
+        coef = [(-1.0) ** i / math.factorial(2 * i + first_factorial) for i in range(Lie._TERMS)]
+        acc = torch.full_like(theta, coef[-1])
+        for c in reversed(coef[:-1]):
+            acc = acc * x2 + c
+        return acc
+
+    def taylor_A(self, x):   # sin(x)/x
+        return self._series(x, 1)
+
+    def taylor_B(self, x):   # (1-cos(x))/x^2
+        return self._series(x, 2)
+
+    def taylor_C(self, x):   # (x-sin(x))/x^3
+        return self._series(x, 3)
+
+    def skew_symmetric(self, w):
+        w0, w1, w2 = w.unbind(dim=-1)
+        z = torch.zeros_like(w0)
+        return torch.stack([torch.stack([z, -w2, w1], -1), torch.stack([w2, z, -w0], -1), torch.stack([-w1, w0, z], -1)], -2)
+
+    def so3_to_SO3(self, w):
+        wx = self.skew_symmetric(w)
+        theta = w.norm(dim=-1)[..., None, None]
+        eye = torch.eye(3, device=w.device, dtype=torch.float32)
+        return eye + self.taylor_A(theta) * wx + self.taylor_B(theta) * wx @ wx
+
+    def SO3_to_so3(self, R, eps=1e-7):
+        trace = R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2]
+        theta = ((trace - 1) / 2).clamp(-1 + eps, 1 - eps).acos()[..., None, None] % math.pi
+        lnR = 1 / (2 * self.taylor_A(theta) + 1e-8) * (R - R.transpose(-2, -1))
+        return torch.stack([lnR[..., 2, 1], lnR[..., 0, 2], lnR[..., 1, 0]], dim=-1)
+
+    def se3_to_SE3(self, wu):
+        w, u = wu.split([3, 3], dim=-1)
+        wx = self.skew_symmetric(w)
+        theta = w.norm(dim=-1)[..., None, None]
+        eye = torch.eye(3, device=w.device, dtype=torch.float32)
+        A, B, C = self.taylor_A(theta), self.taylor_B(theta), self.taylor_C(theta)
+        wx2 = wx @ wx
+        R = eye + A * wx + B * wx2
+        V = eye + B * wx + C * wx2
+        return torch.cat([R, V @ u[..., None]], dim=-1)
+
+    def SE3_to_se3(self, Rt, eps=1e-8):
+        R, t = Rt.split([3, 1], dim=-1)
+        w = self.SO3_to_so3(R)
+        wx = self.skew_symmetric(w)
+        theta = w.norm(dim=-1)[..., None, None]
+        eye = torch.eye(3, device=w.device, dtype=torch.float32)
+        A, B = self.taylor_A(theta), self.taylor_B(theta)
+        invV = eye - 0.5 * wx + (1 - A / (2 * B)) / (theta ** 2 + eps) * wx @ wx
+        return torch.cat([w, (invV @ t)[..., 0]], dim=-1)
+
+
 pose = Pose()
+lie = Lie()
+
+
+def pad_poses(p):
+    """[...,3,4] -> [...,4,4] with the homogeneous row (reference utils/camera.py:24-29)"""
+    bottom = torch.tensor([0, 0, 0, 1.0], device=p.device, dtype=p.dtype).expand(p[..., :1, :4].shape)
+    return torch.cat((p[..., :3, :4], bottom), dim=-2)
+
+
+def pose_inverse_4x4(mat, use_inverse=False):
+    """Rigid inverse of [B,4,4] / [4,4] matrices (reference camera.py:34-61)"""
+    R, t = mat[..., :3, :3], mat[..., :3, 3:]
+    R_inv = R.inverse() if use_inverse else R.transpose(-1, -2)
+    out = torch.zeros_like(mat)
+    out[..., :3, :3] = R_inv
+    out[..., :3, 3:] = -R_inv @ t
+    out[..., 3, 3] = 1
+    return out
+
+
+def rotation_distance(R1, R2, eps=1e-7):
+    """Geodesic angle between rotations (reference camera.py:542-547)"""
+    R_diff = R1 @ R2.transpose(-2, -1)
+    trace = R_diff[..., 0, 0] + R_diff[..., 1, 1] + R_diff[..., 2, 2]
+    return ((trace - 1) / 2).clamp(-1 + eps, 1 - eps).acos()
+
+
+def procrustes_analysis(X0, X1):
+    """Similarity transform between two [N,3] point sets, X1to0 = (X1-t1)/s1 @ R.t() * s0 + t0
+    (reference camera.py:549-566; rotation from a double-precision SVD)."""
+    t0, t1 = X0.mean(dim=0, keepdim=True), X1.mean(dim=0, keepdim=True)
+    X0c, X1c = X0 - t0, X1 - t1
+    s0 = (X0c ** 2).sum(dim=-1).mean().sqrt()
+    s1 = (X1c ** 2).sum(dim=-1).mean().sqrt()
+    U, _, Vh = torch.linalg.svd(((X0c / s0).t() @ (X1c / s1)).double(), full_matrices=False)
+    R = (U @ Vh).float()
+    if R.det() < 0:
+        R[2] *= -1
+    return edict(t0=t0[0], t1=t1[0], s0=s0, s1=s1, R=R)
 
 
 def cam2world(X, pose_w2c):
@@ -70,6 +176,12 @@ def get_center_and_ray(opt, pose, intr=None, ray_idx=None):
     """reference camera.py:419-443 -> (center_3D, ray), each [B,R,3].  `ray_idx` (an extension
     of the reference signature) restricts generation to the pixels the caller would index."""
     assert opt.camera.model == "perspective"
+    if torch.is_grad_enabled() and pose.requires_grad:
+        # pose optimisation (test-time photometric refinement, barf_inn_llff.py:218-234): camera-frame grid
+        # from the kernel, then the reference's cam2world algebra so that autograd reaches the pose
+        center_cam, grid_cam = ops.raygen(intr, None, ray_idx, opt.H, opt.W, 0)
+        center, grid = cam2world(center_cam, pose), cam2world(grid_cam, pose)
+        return center, grid - center
     return ops.raygen(intr, pose, ray_idx, opt.H, opt.W, 1)
 
 

@@ -1,0 +1,139 @@
+"""Checkpoint wire format of the reference (util.py:124-163): one torch.save'd dict
+
+    {epoch, iter, graph: graph.state_dict(), optim, optim_pose, sched, sched_pose}
+
+with the reference's state-dict keys (nerf.mlp_feat.N.weight ..., nerf.progress, [nerf_fine.*],
+warp_mlp.lin{b}_{a,b}_0.{weight_g,weight_v,bias}, warp_mlp.lin{b}_{a,b}_1.*, warp_mlp.lin{b}_c.*,
+warp_latent.weight, global_rigid.weight) and optimizer / scheduler states in torch.optim's own format, laid
+out as the reference's setup_optimizer builds them (nerf_inn_llff.py:34-47: `optim` = Adam, group 0 nerf,
+group 1 nerf_fine; barf_inn_llff.py:84-104: `optim_pose` = Adam, group 0 warp_mlp, group 1 warp_latent; both
+under ExponentialLR).  A reference-trained model.ckpt therefore restores into the INNTrainer (weights, Adam
+moments, step, learning-rate schedule) and vice versa.
+
+The engine keeps Adam moments as flat buffers (one fused niw_adam_step per group); here they are scattered
+to / gathered from per-parameter `exp_avg` / `exp_avg_sq` entries through real torch.optim objects that are
+used only as (de)serialisers -- they never step.
+"""
+import os
+import shutil
+
+import torch
+
+
+def get_child_state_dict(state_dict, key):
+    return {".".join(k.split(".")[1:]): v for k, v in state_dict.items() if k.startswith("{}.".format(key))}
+
+
+def _gamma(lr0, lr_end, max_iter):
+    return (lr_end / lr0) ** (1.0 / max_iter) if lr_end else 1.0
+
+
+def _optimizers(trainer):
+    """torch.optim.Adam / ExponentialLR shells with the reference's group layout -> dict(optim, optim_pose,
+    sched, sched_pose) plus, per optimizer, the trainer group index behind each param group."""
+    opt, g = trainer.opt, trainer.graph
+    n_nets = len(trainer.nets)
+    o = opt.optim
+    optim = torch.optim.Adam([dict(params=list(net.parameters()), lr=o.lr) for net in trainer.nets])
+    optim_pose = torch.optim.Adam([dict(params=list(g.warp_mlp.parameters()), lr=o.lr_pose),
+                                   dict(params=list(g.warp_latent.parameters()), lr=o.lr_pose)])
+    sched = torch.optim.lr_scheduler.ExponentialLR(optim, gamma=_gamma(o.lr, o.lr_end, opt.max_iter))
+    sched_pose = torch.optim.lr_scheduler.ExponentialLR(optim_pose, gamma=_gamma(o.lr_pose, o.lr_pose_end, opt.max_iter))
+    return dict(optim=optim, optim_pose=optim_pose, sched=sched, sched_pose=sched_pose), \
+        dict(optim=list(range(n_nets)), optim_pose=[n_nets, n_nets + 1])
+
+
+def _param_slices(trainer, gi):
+    """{id(param): (offset, numel)} of trainer group gi inside its flat buffers"""
+    out, off = {}, 0
+    for p in trainer.bucket.groups[gi]:
+        out[id(p)] = (off, p.numel())
+        off += p.numel()
+    return out
+
+
+def optimizer_state_dicts(trainer):
+    """-> {optim, optim_pose, sched, sched_pose} state dicts in torch format for the trainer's current step"""
+    objs, groups = _optimizers(trainer)
+    it = trainer.it
+    for name in ("optim", "optim_pose"):
+        optim = objs[name]
+        for pg, gi in zip(optim.param_groups, groups[name]):
+            where = _param_slices(trainer, gi)
+            lr0, lr_end = trainer.lrs[gi]
+            pg["lr"] = lr0 * _gamma(lr0, lr_end, trainer.opt.max_iter) ** it
+            pg["initial_lr"] = lr0
+            if it == 0:
+                continue
+            for p in pg["params"]:
+                if id(p) not in where:                       # e.g. nerf.progress: never receives a gradient
+                    continue
+                off, n = where[id(p)]
+                optim.state[p] = dict(step=torch.tensor(float(it)),
+                                      exp_avg=trainer.m[gi][off:off + n].view(p.shape).clone(),
+                                      exp_avg_sq=trainer.v[gi][off:off + n].view(p.shape).clone())
+    out = {k: objs[k].state_dict() for k in ("optim", "optim_pose")}
+    for name in ("sched", "sched_pose"):
+        s = objs[name]
+        s.last_epoch, s._step_count = it, it + 1
+        s._last_lr = [pg["lr"] for pg in s.optimizer.param_groups]
+        out[name] = s.state_dict()
+    return out
+
+
+def load_optimizer_state_dicts(trainer, checkpoint):
+    """Scatter `optim` / `optim_pose` Adam moments of a reference-format checkpoint into the trainer's flat
+    buffers (parameters without state keep zero moments)."""
+    objs, groups = _optimizers(trainer)
+    for name in ("optim", "optim_pose"):
+        if name not in checkpoint:
+            continue
+        optim = objs[name]
+        optim.load_state_dict(checkpoint[name])
+        for pg, gi in zip(optim.param_groups, groups[name]):
+            where = _param_slices(trainer, gi)
+            trainer.m[gi].zero_()
+            trainer.v[gi].zero_()
+            for p in pg["params"]:
+                st = optim.state.get(p)
+                if not st or id(p) not in where:
+                    continue
+                off, n = where[id(p)]
+                trainer.m[gi][off:off + n].copy_(st["exp_avg"].reshape(-1))
+                trainer.v[gi][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+
+
+def save_checkpoint(opt, trainer, ep, it, latest=False, children=None):
+    """reference util.py:147-163; `trainer` plays the reference's `model` (has .graph and optimizer state)"""
+    os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
+    sd = trainer.graph.state_dict()
+    if children is not None:
+        sd = {k: v for k, v in sd.items() if k.startswith(children)}
+    checkpoint = dict(epoch=ep, iter=it, graph=sd)
+    checkpoint.update(optimizer_state_dicts(trainer))
+    torch.save(checkpoint, "{0}/model.ckpt".format(opt.output_path))
+    if not latest:
+        shutil.copy("{0}/model.ckpt".format(opt.output_path), "{0}/model/{1}.ckpt".format(opt.output_path, ep or it))
+
+
+def restore_checkpoint(opt, trainer, load_name=None, resume=False):
+    """reference util.py:124-145 -> (epoch, iter) when resuming, (None, None) when only loading weights"""
+    assert (load_name is None) == (resume is not False)
+    if resume:
+        load_name = "{0}/model.ckpt".format(opt.output_path) if resume is True else "{0}/model/{1}.ckpt".format(opt.output_path, resume)
+    checkpoint = torch.load(load_name, map_location=opt.device, weights_only=False)
+    for name, child in trainer.graph.named_children():
+        child_sd = get_child_state_dict(checkpoint["graph"], name)
+        if child_sd:
+            child.load_state_dict(child_sd)
+    for net in trainer.nets:                                   # host copy of the c2f progress the kernels use
+        if hasattr(net, "progress"):
+            net.set_progress(float(net.progress.data))
+    if not resume:
+        return None, None
+    load_optimizer_state_dicts(trainer, checkpoint)
+    ep, it = checkpoint["epoch"], checkpoint["iter"]
+    if resume is not True:
+        assert resume == (ep or it)
+    trainer.it = it or 0
+    return ep, it

@@ -17,7 +17,7 @@ _BASE = dict(
     data=dict(dataset="llff", scene="fern", image_size=[300, 400], bgcolor=None),
     camera=dict(model="perspective", ndc=False),
     loss_weight=dict(render=0, render_fine=None, global_alignment=None),
-    optim=dict(lr=1e-3, lr_end=1e-4, lr_pose=5e-4, lr_pose_end=1e-8, test_photo=True, test_iter=100),
+    optim=dict(algo="Adam", lr=1e-3, lr_end=1e-4, lr_pose=5e-4, lr_pose_end=1e-8, test_photo=True, test_iter=100),
     inn=dict(real_nvp=dict(c2f=True, max_pe_iter=100000, d_hidden=128, multires=6, latent_dim=128), actfn="softplus"),
     warp_latent=dict(enc_type="l2fbarf", embed_dim=128),
 )
@@ -68,4 +68,5 @@ def cfg5_barf_inn_dtu(device="cuda:0"):
     return _mk(model="barf_inn_dtu", device=device, barf_c2f=[0.1, 0.5],
                nerf=dict(depth=dict(param="metric", range=[1.2, 5.2])),
                data=dict(dataset="dtu", scene="scan65"),
+               pose=dict(parameterization="inn", init="noisy_gt", noise=0.15, n_first_fixed_poses=0),
                loss_weight=dict(render=0, global_alignment=3))

@@ -10,9 +10,10 @@
 // These are O(parameters) = 166k MACs x views, i.e. launch-latency sized; as ~150 separate torch
 // kernels (forward + autograd) they made small configurations host-dispatch bound.
 //
-// Flat parameter layout (= DeformNetwork.parameters() order of the host mirror, 165,900 floats):
-//   for b in 0..2: lin{b}_a_0.weight_g[128] .weight_v[128x154] .bias[128]  lin{b}_a_1.weight[128] .bias[1]
-//   for b in 0..2: lin{b}_b_0.weight_g[128] .weight_v[128x141] .bias[128]  lin{b}_b_1.weight[3x128] .bias[3]
+// Flat parameter layout (= DeformNetwork.parameters() order, reference and host mirror alike: old-style
+// weight_norm leaves `bias` registered before `weight_g` / `weight_v`; 165,900 floats):
+//   for b in 0..2: lin{b}_a_0.bias[128] .weight_g[128] .weight_v[128x154]  lin{b}_a_1.weight[128] .bias[1]
+//   for b in 0..2: lin{b}_b_0.bias[128] .weight_g[128] .weight_v[128x141]  lin{b}_b_1.weight[3x128] .bias[3]
 //   for b in 0..2: lin{b}_c.weight[128x128] .bias[128]
 #include "niw_common.h"
 
@@ -33,11 +34,11 @@ struct Layer {                 // first layer of part a / b of block b inside th
 };
 __device__ __forceinline__ Layer layer_of(int b, int part) {
     Layer l;
-    if (part == 0) { l.g = b * kBlkA; l.E = kEa; l.K = kKa; l.nhead = kHid + 1; }
-    else           { l.g = kOffB + b * kBlkB; l.E = kEb; l.K = kKb; l.nhead = 3 * kHid + 3; }
+    if (part == 0) { l.bias = b * kBlkA; l.E = kEa; l.K = kKa; l.nhead = kHid + 1; }
+    else           { l.bias = kOffB + b * kBlkB; l.E = kEb; l.K = kKb; l.nhead = 3 * kHid + 3; }
+    l.g = l.bias + kHid;
     l.v = l.g + kHid;
-    l.bias = l.v + kHid * l.K;
-    l.head = l.bias + kHid;
+    l.head = l.v + kHid * l.K;
     return l;
 }
 

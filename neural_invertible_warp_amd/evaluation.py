@@ -1,0 +1,192 @@
+"""Val / eval tooling around the Graph: pose evaluation up to a similarity transform,
+the test-pose alignment the val / eval branch of `Graph.get_pose` consumes, full-image rendering through
+`render_by_slices` and the image / depth metrics.  Mirrors the evaluation methods of the reference's
+`Model` classes, taking the graph and the ground-truth poses explicitly instead of a dataset object:
+
+  LLFF (model/barf_inn_llff.py):  get_all_training_poses :156-169, prealign_cameras :171-187,
+        evaluate_camera_alignment :189-197, evaluate_full :199-216 (+ nerf_inn_llff.py:193-228),
+        evaluate_test_time_photometric_optim :218-234
+  DTU  (model/barf_inn_dtu.py):   evaluate_any_poses :116-137, evaluate_camera_alignment :139-170,
+        prealign_w2c_large_camera_systems :173-201, prealign_w2c_small_camera_systems :203-299,
+        validate :370-382, evaluate_full :437-465 (+ nerf_inn_dtu.py:205-262)
+
+The renders run on the HIP path (graph.forward(mode="eval")); the pose algebra is [N,3,4]-sized host work.
+"""
+import numpy as np
+import torch
+
+from . import camera, metrics
+from .align_trajectories import align_ate_c2b_use_a2b
+from .util import edict
+
+
+# ------------------------------------------------------------------------------------------ LLFF
+class LLFFEvaluator:
+    def __init__(self, opt, graph, pose_GT):
+        """pose_GT: ground-truth w2c poses of the training views [N,3,4] (train_data.get_all_camera_poses)"""
+        self.opt, self.graph, self.pose_GT = opt, graph, pose_GT.to(opt.device)
+
+    @torch.no_grad()
+    def get_all_training_poses(self, opt):
+        pose = self.graph.pose_eye
+        pose_refine = self.graph.global_rigid.weight.data.detach().clone().view(-1, 3, 4)
+        return camera.pose.compose([pose_refine, pose]), self.pose_GT
+
+    @torch.no_grad()
+    def prealign_cameras(self, opt, pose, pose_GT):
+        """Procrustes alignment of the predicted camera centres onto the ground truth -> (pose_aligned, sim3)"""
+        center = torch.zeros(1, 1, 3, device=opt.device)
+        center_pred = camera.cam2world(center, pose)[:, 0]
+        center_GT = camera.cam2world(center, pose_GT)[:, 0]
+        try:
+            sim3 = camera.procrustes_analysis(center_GT, center_pred)
+        except Exception:  # SVD did not converge
+            sim3 = edict(t0=0, t1=0, s0=1, s1=1, R=torch.eye(3, device=opt.device))
+        center_aligned = (center_pred - sim3.t1) / sim3.s1 @ sim3.R.t() * sim3.s0 + sim3.t0
+        R_aligned = pose[..., :3] @ sim3.R.t()
+        t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
+        return camera.pose(R=R_aligned, t=t_aligned), sim3
+
+    @torch.no_grad()
+    def evaluate_camera_alignment(self, opt, pose_aligned, pose_GT):
+        R_aligned, t_aligned = pose_aligned.split([3, 1], dim=-1)
+        R_GT, t_GT = pose_GT.split([3, 1], dim=-1)
+        return edict(R=camera.rotation_distance(R_aligned, R_GT), t=(t_aligned - t_GT)[..., 0].norm(dim=-1))
+
+    def evaluate_test_time_photometric_optim(self, opt, var):
+        """Absorb the remaining pose error of a test view in an se(3) correction optimised photometrically"""
+        var.se3_refine_test = torch.nn.Parameter(torch.zeros(1, 6, device=opt.device))
+        optim_pose = getattr(torch.optim, opt.optim.algo)([dict(params=[var.se3_refine_test], lr=opt.optim.lr_pose)])
+        with torch.enable_grad():
+            for _ in range(opt.optim.test_iter):
+                optim_pose.zero_grad()
+                var.pose_refine_test = camera.lie.se3_to_SE3(var.se3_refine_test)
+                var = self.graph.forward(opt, var, mode="test-optim")
+                loss = self.graph.compute_loss(opt, var, mode="test-optim")
+                loss.render.backward()
+                optim_pose.step()
+        return var
+
+    def evaluate_full(self, opt, test_views, eps=1e-10):
+        """test_views: iterable of var dicts (idx, image [1,3,H,W], intr, pose) -> edict(error=pose errors,
+        res=[edict(psnr, ssim)], rgb / invdepth maps of the last view)"""
+        self.graph.eval()
+        pose, pose_GT = self.get_all_training_poses(opt)
+        pose_aligned, self.graph.sim3 = self.prealign_cameras(opt, pose, pose_GT)
+        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
+        res, maps = [], None
+        for var in test_views:
+            var = edict(var)
+            if opt.optim.test_photo:
+                var = self.evaluate_test_time_photometric_optim(opt, var)
+            with torch.no_grad():
+                var = self.graph.forward(opt, var, mode="eval")
+                invdepth = (1 - var.depth) / var.opacity if opt.camera.ndc else 1 / (var.depth / var.opacity + eps)
+                rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+                invdepth_map = invdepth.view(-1, opt.H, opt.W, 1).permute(0, 3, 1, 2)
+                res.append(edict(psnr=metrics.psnr(rgb_map, var.image).item(), ssim=metrics.ssim(rgb_map.contiguous(), var.image).item()))
+                maps = edict(rgb=rgb_map, invdepth=invdepth_map)
+        return edict(error=error, res=res, maps=maps)
+
+
+# ------------------------------------------------------------------------------------------ DTU
+class DTUEvaluator:
+    def __init__(self, opt, graph, pose_GT):
+        """graph: barf_inn_dtu.Graph (poses live on graph.pose_net); pose_GT: training w2c poses [N,3,4]"""
+        self.opt, self.graph, self.pose_GT = opt, graph, pose_GT.to(opt.device)
+
+    @torch.no_grad()
+    def get_all_training_poses(self, opt):
+        net = self.graph.pose_net
+        return camera.pose.compose([net.get_w2c_poses(), net.initial_poses_w2c]), self.pose_GT
+
+    @torch.no_grad()
+    def evaluate_camera_alignment(self, opt, pose_aligned_w2c, pose_GT_w2c):
+        """Rotation (rad) and camera-centre (world frame) errors, not averaged"""
+        a, g = camera.pose.invert(pose_aligned_w2c), camera.pose.invert(pose_GT_w2c)
+        return edict(R=camera.rotation_distance(a[..., :3], g[..., :3]), t=(a[..., 3] - g[..., 3]).norm(dim=-1))
+
+    @torch.no_grad()
+    def prealign_w2c_large_camera_systems(self, opt, pose_w2c, pose_GT_w2c):
+        """sim3 trajectory alignment (Umeyama on the camera centres) -> (aligned w2c poses, est->gt similarity)"""
+        identity = edict(R=torch.eye(3, device=opt.device).unsqueeze(0), t=torch.zeros(1, 3, 1, device=opt.device), s=1., type="traj_align")
+        if opt.pose.n_first_fixed_poses > 1:
+            return pose_w2c, identity
+        try:
+            aligned_c2w, sim = align_ate_c2b_use_a2b(camera.pose.invert(pose_w2c), camera.pose.invert(pose_GT_w2c), method="sim3")
+            sim.type = "traj_align"
+            return camera.pose.invert(aligned_c2w[:, :3]), sim
+        except np.linalg.LinAlgError:
+            return pose_w2c, identity
+
+    @torch.no_grad()
+    def prealign_w2c_small_camera_systems(self, opt, pose_w2c, pose_GT_w2c):
+        """For < 10 views: try every ordered pair (a, b) - scale from the a-b baseline, rigid transform from
+        view a - and keep the candidate with the smallest (mean rot deg x mean trans) error."""
+        if opt.pose.n_first_fixed_poses > 1:
+            return pose_w2c, edict(R=torch.eye(3, device=opt.device).unsqueeze(0), t=torch.zeros(1, 3, 1, device=opt.device), s=1.)
+        src = camera.pad_poses(camera.pose.invert(pose_w2c))
+        dst = camera.pad_poses(camera.pose.invert(pose_GT_w2c))
+        n = min(src.shape[0], 10)
+        best = None
+        for a in range(n):
+            for b in range(n):
+                if a == b:
+                    continue
+                scale = torch.norm(dst[a, :3, 3] - dst[b, :3, 3]) / torch.norm(src[a, :3, 3] - src[b, :3, 3])
+                scaled = src.clone()
+                scaled[:, :3, 3] = scaled[:, :3, 3] * scale
+                T = dst[a] @ camera.pose_inverse_4x4(scaled[a])
+                aligned_w2c = camera.pose_inverse_4x4(T[None] @ scaled)[:, :3]
+                err = self.evaluate_camera_alignment(opt, aligned_w2c, pose_GT_w2c)
+                score = err.t.mean().item() * (err.R.mean().item() * 180. / np.pi)
+                if best is None or score < best[0]:
+                    best = (score, aligned_w2c, edict(R=T[:3, :3].unsqueeze(0), type="traj_align", t=T[:3, 3].reshape(1, 3, 1), s=scale))
+        return best[1], best[2]
+
+    def _prealign(self, opt, pose, pose_GT, large_above):
+        fn = self.prealign_w2c_large_camera_systems if pose.shape[0] > large_above else self.prealign_w2c_small_camera_systems
+        return fn(opt, pose, pose_GT)
+
+    @torch.no_grad()
+    def evaluate_any_poses(self, opt, pose_w2c, pose_GT_w2c):
+        stats = {}
+        error = self.evaluate_camera_alignment(opt, pose_w2c.detach(), pose_GT_w2c)
+        stats["error_R_before_align"] = error.R.mean() * 180. / np.pi
+        stats["error_t_before_align"] = error.t.mean()
+        pose_aligned, _ = self._prealign(opt, pose_w2c.detach(), pose_GT_w2c, large_above=10)
+        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT_w2c)
+        stats["error_R"] = error.R.mean() * 180. / np.pi
+        stats["error_t"] = error.t.mean()
+        return stats
+
+    def evaluate_poses(self, opt):
+        return self.evaluate_any_poses(opt, *self.get_all_training_poses(opt))
+
+    @torch.no_grad()
+    def validate(self, opt):
+        """Install the est->gt similarity the val / eval branch of Graph.get_pose needs (barf_inn_dtu.py:370-382)"""
+        pose, pose_GT = self.get_all_training_poses(opt)
+        pose_aligned, self.graph.pose_net.sim3_est_to_gt_c2w = self._prealign(opt, pose, pose_GT, large_above=9)
+        return pose_aligned
+
+    def evaluate_full(self, opt, test_views):
+        """-> edict(error, res=[edict(psnr, ssim, abs_err, rms_err)]); test views carry depth_gt /
+        valid_depth_gt / depth_range when the dataset has them (nerf_inn_dtu.py:205-262)"""
+        self.graph.eval()
+        pose, pose_GT = self.get_all_training_poses(opt)
+        pose_aligned = self.validate(opt)
+        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
+        scale = self.graph.pose_net.sim3_est_to_gt_c2w.s
+        res = []
+        for var in test_views:
+            var = edict(var)
+            with torch.no_grad():
+                var = self.graph.forward(opt, var, mode="eval")
+                rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2).contiguous()
+                r = edict(psnr=metrics.psnr(rgb_map, var.image).item(), ssim=metrics.ssim(rgb_map, var.image).item(),
+                          abs_err=float("nan"), rms_err=float("nan"))
+                if "depth_gt" in var and float(scale) != 1.:
+                    r.abs_err, r.rms_err = metrics.compute_depth_metrics(var, float(scale))
+                res.append(r)
+        return edict(error=error, res=res)

@@ -4,6 +4,7 @@ passes into the graph, barf_inn_dtu.py:325-336) + BARF coarse-to-fine encoding."
 import torch
 
 from .. import camera
+from ..align_trajectories import backtrack_from_aligning_the_trajectory
 from . import barf_inn_llff, nerf_inn_dtu
 
 
@@ -25,17 +26,18 @@ class Graph(nerf_inn_dtu.Graph):
         return self.get_w2c_pose(opt, var, mode, iter)
 
     def get_w2c_pose(self, opt, var, mode=None, iter=None):
-        """reference barf_inn_dtu.py:538-567.  The val / eval branch needs the sim3 trajectory
-        alignment of the pose-evaluation mixin (barf_inn_dtu.py:173-299), which is outside the render
-        path; an already aligned pose can be supplied as var.pose_aligned."""
+        """reference barf_inn_dtu.py:538-567.  val / eval: the ground-truth test pose is brought into the
+        frame of the optimised poses with the est->gt similarity stored on the pose network by the
+        evaluator (evaluation.DTUEvaluator.validate, reference :370-382)."""
         if mode == "train":
             assert iter is not None, "ERROR: Iteration is needed for the c2f embedding in INN"
             return self.pose_net.get_warped_rays_in_world(var, mode, iter)
         if mode in ["val", "eval", "test-optim", "test"]:
-            if "pose_aligned" not in var:
-                raise NotImplementedError("sim3 test-pose alignment is evaluation tooling outside the render path; "
-                                          "pass var.pose_aligned (w2c poses in the optimised frame)")
-            pose = var.pose_aligned
+            assert hasattr(self.pose_net, "sim3_est_to_gt_c2w")
+            sim = self.pose_net.sim3_est_to_gt_c2w
+            if sim.type != "traj_align":
+                raise ValueError(sim.type)
+            pose = backtrack_from_aligning_the_trajectory(var.pose, sim)
             if opt.optim.test_photo and mode != "val":
                 pose = camera.pose.compose([var.pose_refine_test, pose])
             return pose

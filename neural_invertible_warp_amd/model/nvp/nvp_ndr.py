@@ -28,9 +28,10 @@ class _WNLinear(torch.nn.Module):
         super().__init__()
         v = torch.zeros(k_out, k_in)
         torch.nn.init.normal_(v[:, :ori_in], 0.0, np.sqrt(2) / np.sqrt(k_out))      # nvp_ndr.py:278-282
+        # registration order of the reference: nn.Linear's bias first, then what weight_norm adds
+        self.bias = torch.nn.Parameter(torch.zeros(k_out))
         self.weight_g = torch.nn.Parameter(v.norm(dim=1, keepdim=True))
         self.weight_v = torch.nn.Parameter(v)
-        self.bias = torch.nn.Parameter(torch.zeros(k_out))
 
     def weight(self):
         return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))

@@ -1,0 +1,177 @@
+"""Val / eval path on the GPU: similarity alignment of the optimised poses, test-pose
+back-alignment, full-image rendering through render_by_slices on the HIP path, PSNR / SSIM / depth
+metrics -- checked end to end against the CPU oracle rendering the same view from the same aligned pose.
+Tolerances: image 1e-4 (same amplification as test_render_cfg1_golden), PSNR 0.01 dB, SSIM 1e-4."""
+import pytest
+import torch
+
+from oracle import niw_oracle as O
+from tests.test_gpu_parity import DEV, close, g, load_nerf, mk_opt
+
+pytestmark = pytest.mark.gpu
+
+
+def _poses(n, gen, scale=0.3):
+    from neural_invertible_warp_amd import camera
+    return camera.lie.se3_to_SE3(torch.randn(n, 6, generator=gen) * scale)
+
+
+def _intr(H, W):
+    return torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32)[None]
+
+
+def test_llff_evaluate_full_matches_oracle_render():
+    from neural_invertible_warp_amd import camera, evaluation, metrics
+    from neural_invertible_warp_amd.model import barf_inn_llff
+    from neural_invertible_warp_amd.util import edict
+    H, W, S, n = 20, 24, 32, 6
+    opt = mk_opt("cfg3_barf_inn_llff", H=H, W=W, **{"nerf.sample_intvs": S, "nerf.rand_rays": 128, "nerf.sample_stratified": False})
+    opt.optim.test_photo = False
+    gen = torch.Generator().manual_seed(5)
+    graph = barf_inn_llff.Graph(opt).attach_warp(opt, n)
+    p = O.make_nerf_params(21)
+    load_nerf(graph.nerf, p)
+    graph.nerf.set_progress(1.0)                                     # all encoding bands on
+    # optimised poses = a similarity transform of the ground truth (+ small noise), as after training
+    pose_GT = _poses(n, gen)
+    sim_R = camera.lie.so3_to_SO3(torch.tensor([0.2, 0.1, -0.4]))
+    c_pred = (camera.cam2world(torch.zeros(1, 1, 3), pose_GT)[:, 0] * 0.7) @ sim_R.t() + torch.tensor([0.3, 0.2, -0.1])
+    R_pred = camera.lie.so3_to_SO3(torch.randn(n, 3, generator=gen) * 0.01) @ pose_GT[..., :3] @ sim_R.t()
+    pose_pred = camera.pose(R=R_pred, t=(-R_pred @ c_pred[..., None])[..., 0])
+    with torch.no_grad():
+        graph.global_rigid.weight.copy_(pose_pred.reshape(n, 12))
+    test_pose, image = _poses(1, gen), torch.rand(1, 3, H, W, generator=gen)
+    ev = evaluation.LLFFEvaluator(opt, graph, g(pose_GT))
+    out = ev.evaluate_full(opt, [edict(idx=torch.arange(1), image=g(image), intr=g(_intr(H, W)), pose=g(test_pose))])
+    assert out.error.R.mean() < 0.03 and out.error.t.mean() < 0.03
+    # oracle: same aligned test pose (host algebra, float32 on both sides), rendered on the CPU
+    sim3 = graph.sim3
+    pose_al = barf_inn_llff.Graph.get_pose(graph, opt, edict(pose=g(test_pose)), mode="eval").cpu()
+    center, ray = O.center_and_ray(H, W, pose_al, _intr(H, W))
+    with torch.no_grad():
+        ref = O.render_rays(p, center, ray, 0.5, S, opt.nerf.depth.range, opt.nerf.depth.param, density_activ="softplus")
+    rgb_ref = ref["rgb"].view(1, H, W, 3).permute(0, 3, 1, 2)
+    close(out.maps.rgb, rgb_ref, atol=1e-4, rtol=1e-3)
+    assert abs(out.res[0].psnr - metrics.psnr(rgb_ref, image).item()) < 0.01
+    assert abs(out.res[0].ssim - metrics.ssim(rgb_ref.contiguous(), image).item()) < 1e-4
+    assert sim3.R.shape == (3, 3)
+
+
+def test_dtu_evaluate_full_matches_oracle_render():
+    from neural_invertible_warp_amd import camera, evaluation, metrics
+    from neural_invertible_warp_amd.align_trajectories import backtrack_from_aligning_the_trajectory
+    from neural_invertible_warp_amd.model import barf_inn_dtu
+    from neural_invertible_warp_amd.model.pose_models.inn import INNPoseParams
+    from neural_invertible_warp_amd.util import edict
+    H, W, S, n = 20, 24, 32, 3
+    opt = mk_opt("cfg5_barf_inn_dtu", H=H, W=W, **{"nerf.sample_intvs": S, "nerf.rand_rays": 128, "nerf.sample_stratified": False})
+    opt.optim.test_photo = False
+    gen = torch.Generator().manual_seed(9)
+    pose_GT = _poses(n, gen, 0.4)
+    init = camera.pose.compose([_poses(n, gen, 0.05), pose_GT])                       # noisy initial poses
+    pose_net = INNPoseParams(opt, num_poses=n, initial_poses_w2c=g(init), device=DEV)
+    with torch.no_grad():                                                             # a learnt global correction
+        pose_net.pose_global.weight.copy_(g(_poses(n, gen, 0.03).reshape(n, 12)))
+    graph = barf_inn_dtu.Graph(opt, pose_net)
+    p = O.make_nerf_params(33)
+    load_nerf(graph.nerf, p)
+    graph.nerf.set_progress(1.0)
+    test_pose, image = _poses(1, gen, 0.4), torch.rand(1, 3, H, W, generator=gen)
+    depth_gt, valid = torch.rand(1, H, W, generator=gen) * 4 + 1.2, torch.rand(1, H, W, generator=gen) > 0.2
+    rng = torch.tensor([[1.2, 5.2]])
+    ev = evaluation.DTUEvaluator(opt, graph, g(pose_GT))
+    stats = ev.evaluate_poses(opt)
+    assert float(stats["error_t"]) <= float(stats["error_t_before_align"]) + 1e-6
+    var = edict(idx=torch.arange(1), image=g(image), intr=g(_intr(H, W)), pose=g(test_pose), depth_range=g(rng),
+                depth_gt=g(depth_gt), valid_depth_gt=g(valid))
+    out = ev.evaluate_full(opt, [var])
+    sim = pose_net.sim3_est_to_gt_c2w
+    pose_al = backtrack_from_aligning_the_trajectory(g(test_pose), sim).cpu()
+    center, ray = O.center_and_ray(H, W, pose_al, _intr(H, W))
+    with torch.no_grad():
+        ref = O.render_rays(p, center, ray, 0.5, S, [1.2, 5.2], "metric", density_activ="softplus")
+    rgb_ref = ref["rgb"].view(1, H, W, 3).permute(0, 3, 1, 2)
+    assert abs(out.res[0].psnr - metrics.psnr(rgb_ref, image).item()) < 0.01
+    assert abs(out.res[0].ssim - metrics.ssim(rgb_ref.contiguous(), image).item()) < 1e-4
+    want = metrics.compute_depth_metrics(edict(depth=ref["depth"], depth_gt=depth_gt, valid_depth_gt=valid), float(sim.s))
+    assert abs(out.res[0].abs_err - want[0]) < 1e-3 and abs(out.res[0].rms_err - want[1]) < 1e-3
+
+
+def test_llff_test_time_pose_refinement_gradient_matches_oracle():
+    """First iteration of evaluate_test_time_photometric_optim (barf_inn_llff.py:218-234): d loss / d se3 of the
+    test-pose correction through lie.se3_to_SE3 -> pose composition -> rays -> HIP render, vs oracle autograd.
+    Tolerance 2e-2 of the gradient's max (positions pass through the 2^9*pi encoding band)."""
+    import types
+    from neural_invertible_warp_amd import camera, evaluation
+    from neural_invertible_warp_amd.model import barf_inn_llff
+    from neural_invertible_warp_amd.util import edict
+    from tests.test_gpu_parity import _capture_rng
+    H, W, S, n, R = 20, 24, 32, 6, 96
+    opt = mk_opt("cfg3_barf_inn_llff", H=H, W=W, **{"nerf.sample_intvs": S, "nerf.rand_rays": R, "nerf.sample_stratified": False})
+    opt.optim.test_iter = 3
+    gen = torch.Generator().manual_seed(11)
+    graph = barf_inn_llff.Graph(opt).attach_warp(opt, n)
+    p = O.make_nerf_params(4)
+    load_nerf(graph.nerf, p)
+    graph.nerf.set_progress(1.0)
+    pose_GT = _poses(n, gen)
+    with torch.no_grad():
+        graph.global_rigid.weight.copy_(camera.pose.compose([_poses(n, gen, 0.02), pose_GT]).reshape(n, 12))
+    ev = evaluation.LLFFEvaluator(opt, graph, g(pose_GT))
+    _, graph.sim3 = ev.prealign_cameras(opt, *ev.get_all_training_poses(opt))
+    test_pose, image, intr = _poses(1, gen), torch.rand(1, 3, H, W, generator=gen), _intr(H, W)
+    idx = torch.randperm(H * W, generator=gen)[:R]
+    w = torch.nn.Parameter(torch.zeros(1, 6, device=DEV))
+    var = edict(idx=torch.arange(1), image=g(image), intr=g(intr), pose=g(test_pose), pose_refine_test=camera.lie.se3_to_SE3(w))
+    with _capture_rng(None, g(idx)):
+        var = graph.forward(opt, var, mode="test-optim")
+    loss = graph.compute_loss(opt, var, mode="test-optim")
+    loss.render.backward()
+    # oracle: identical algebra on the CPU
+    copt = edict(device="cpu", optim=edict(test_photo=True))
+    sim3 = edict({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in graph.sim3.items()})
+    wc = torch.zeros(1, 6, requires_grad=True)
+    pose_c = barf_inn_llff.Graph.get_pose(types.SimpleNamespace(sim3=sim3), copt,
+                                          edict(pose=test_pose, pose_refine_test=camera.lie.se3_to_SE3(wc)), mode="test-optim")
+    center, ray = O.center_and_ray(H, W, pose_c, intr)
+    ref = O.render_rays(p, center[:, idx], ray[:, idx], 0.5, S, opt.nerf.depth.range, opt.nerf.depth.param, density_activ="softplus")
+    loss_c = O.mse_loss(ref["rgb"], O.gather_pixels(image, idx))
+    loss_c.backward()
+    close(loss.render, loss_c, atol=1e-6)
+    assert (w.grad.cpu() - wc.grad).abs().max() <= 2e-2 * wc.grad.abs().max(), (w.grad, wc.grad)
+    # and the optimisation loop itself runs and moves the correction
+    out = ev.evaluate_test_time_photometric_optim(opt, edict(idx=torch.arange(1), image=g(image), intr=g(intr), pose=g(test_pose)))
+    assert torch.isfinite(out.se3_refine_test).all() and out.se3_refine_test.abs().max() > 0
+
+
+def test_checkpoint_resume_continues_bit_exactly(tmp_path):
+    """train 2 steps, save in the reference's wire format, restore into a fresh trainer: the third
+    step (same RNG state) gives bit-identical losses and weights as continuing without the round trip."""
+    from neural_invertible_warp_amd import checkpoint, configs, engine
+    from neural_invertible_warp_amd.util import edict
+    n = 4
+
+    def fresh():
+        opt = configs.cfg3_barf_inn_llff(device=DEV)
+        opt.H, opt.W, opt.nerf.sample_intvs, opt.nerf.rand_rays = 24, 32, 32, 64 * n
+        opt.loss_weight.global_alignment = 2
+        opt.output_path = str(tmp_path)
+        tr = engine.INNTrainer(opt, n, warp_perturb=0.02, seed=3)
+        return opt, tr, engine.synthetic_scene(opt, n, seed=1)
+
+    opt, tr, var0 = fresh()
+    for _ in range(2):
+        tr.train_iteration(edict(var0))
+    checkpoint.save_checkpoint(opt, tr, ep=None, it=tr.it)
+    torch.manual_seed(77)
+    loss_a = tr.train_iteration(edict(var0))
+    opt2, tr2, _ = fresh()
+    assert checkpoint.restore_checkpoint(opt2, tr2, resume=True) == (None, 2)
+    torch.manual_seed(77)
+    loss_b = tr2.train_iteration(edict(var0))
+    for k in loss_a:
+        assert torch.equal(torch.as_tensor(loss_a[k]).detach().cpu(), torch.as_tensor(loss_b[k]).detach().cpu()), k
+    for (k, a), (_, b) in zip(tr.graph.state_dict().items(), tr2.graph.state_dict().items()):
+        assert torch.equal(a, b), k
+    for i in range(len(tr.m)):
+        assert torch.equal(tr.m[i], tr2.m[i]) and torch.equal(tr.v[i], tr2.v[i])
