@@ -165,16 +165,19 @@ int niw_convert_ndc(const float* center, const float* ray, const float* intr, in
 #define NIW_WARP_WHEAD_FLOATS (3 * (128 + 1 + 3 * 128 + 3))
 #define NIW_WARP_PARAM_FLOATS 165900    /* DeformNetwork parameters, flat in parameters() order (see niw_warp_prep.hip) */
 
-/* Operand preparation of the warp and its backward, one launch each (reference nvp_ndr.py:291-292 weight
- * norm, :381 code projection, :416-420 / :433-437 latent half of the first layers).
+/* Operand preparation of the warp and its backward (reference nvp_ndr.py:291-292 weight norm, :381 code
+ * projection, :416-420 / :433-437 latent half of the first layers).
  *   params [NIW_WARP_PARAM_FLOATS] flat parameters; code [n_views,128] (warp_latent.weight)
  *   -> w_emb [NIW_WARP_WEMB_FLOATS], view_b [n_views,3,2,128], w_head [NIW_WARP_WHEAD_FLOATS]
- * backward: d_w_emb, d_view_b, d_w_head -> d_params [NIW_WARP_PARAM_FLOATS] (overwritten), d_code [n_views,128];
- *   scratch: 3 * n_views * 128 floats.  n_views <= 64. */
-int niw_warp_prep_fwd(const float* params, const float* code, int n_views, float* w_emb, float* view_b, float* w_head,
-                      niw_stream_t stream);
+ * backward: d_w_emb, d_view_b, d_w_head -> d_params [NIW_WARP_PARAM_FLOATS] (overwritten), d_code [n_views,128].
+ * workspace: caller-allocated scratch of niw_warp_prep_{fwd,bwd}_workspace_floats(n_views) floats (contents need not
+ * survive between the two calls).  n_views <= 64. */
+int64_t niw_warp_prep_fwd_workspace_floats(int n_views);
+int64_t niw_warp_prep_bwd_workspace_floats(int n_views);
+int niw_warp_prep_fwd(const float* params, const float* code, int n_views, float* workspace, float* w_emb, float* view_b,
+                      float* w_head, niw_stream_t stream);
 int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
-                      const float* d_w_head, float* scratch, float* d_params, float* d_code, niw_stream_t stream);
+                      const float* d_w_head, float* workspace, float* d_params, float* d_code, niw_stream_t stream);
 int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
                  int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
                  int inverse, float* out, niw_stream_t stream);

@@ -9,8 +9,8 @@
 // `view_b` (computed by the host mirror together with weight-norm), so a point costs
 // 3 * 128 * (26 + 13) MACs instead of 3 * 128 * (154 + 141).
 //
-// Forward / inverse: one QUAD of lanes per point (each lane a quarter of the 128 hidden units, quad
-// sums by DPP shuffle), one view per blockIdx.y, first-layer weights of all
+// Forward / inverse: a group of 16 lanes per point (each lane 8 of the 128 hidden units, group
+// sums by xor shuffles), one view per blockIdx.y, first-layer weights of all
 // blocks staged once in LDS (69 KB) and read as broadcasts.
 // Backward: the same thread-per-point kernel walks the blocks in reverse for d(points) and
 // writes, feature-major, the per-point factors of every parameter gradient (pre-activation
@@ -36,6 +36,7 @@ constexpr int kRowHa = 384, kRowHb = 512;                // A2: hidden activatio
 constexpr int kRowGo = 640;                              // B2: head gradients (d delta, d theta, d t0, d t1)
 constexpr int kRowsPerBlock = 644;
 
+
 __device__ __forceinline__ float softplus100(float x) {
     const float z = 100.f * x;
     return z > 20.f ? x : log1pf(expf(z)) / 100.f;
@@ -45,20 +46,46 @@ __device__ __forceinline__ float dsoftplus100(float x) {
     return z > 20.f ? 1.f : 1.f / (1.f + expf(-z));
 }
 
-// embedding of D inputs: [x (D), then per band sin(D), cos(D)], times ps * cw[band]
+// A point is served by a GROUP of kGroup adjacent lanes; lane `sub` owns hidden units sub, sub+kGroup, ...
+// and the group combines partial sums with xor shuffles.  (4 lanes per point left half of the SIMDs idle at
+// the 8k points of a training step and made every lane evaluate all 18 sincos of a block's embeddings.)
+#ifndef NIW_WARP_GROUP
+#define NIW_WARP_GROUP 16
+#endif
+constexpr int kGroup = NIW_WARP_GROUP, kPtsPerWg = 256 / kGroup;
+static_assert(kGroup == 4 || kGroup == 8 || kGroup == 16, "lanes per point");
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < kGroup; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// embedding of D inputs: [x (D), then per band sin(D), cos(D)], times ps * cw[band].  The 6*D sincos
+// evaluations are spread over the group's lanes and exchanged by shuffles.
 template <int D>
-__device__ __forceinline__ void embed(const float (&x)[D], const float* __restrict__ cw, float ps, float (&e)[D * (1 + 2 * kNF)]) {
+__device__ __forceinline__ void embed(const float (&x)[D], const float* __restrict__ cw, float ps, int sub, float (&e)[D * (1 + 2 * kNF)]) {
+    constexpr int N = kNF * D, T = (N + kGroup - 1) / kGroup;
+    float sl[T], cl[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int n = t * kGroup + sub;
+        const int i = n / D, d = n % D;
+        float xv = x[0];
+#pragma unroll
+        for (int dd = 1; dd < D; ++dd) xv = d == dd ? x[dd] : xv;
+        sl[t] = cl[t] = 0.f;
+        if (n < N) sincosf(__fmul_rn(xv, kPi32 * (float)(1 << i)), &sl[t], &cl[t]);
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) e[d] = ps * x[d];
 #pragma unroll
     for (int i = 0; i < kNF; ++i) {
-        const float f = kPi32 * (float)(1 << i), w = ps * cw[i];
+        const float w = ps * cw[i];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            float s, c;
-            sincosf(__fmul_rn(x[d], f), &s, &c);
-            e[D * (1 + 2 * i) + d] = w * s;
-            e[D * (2 + 2 * i) + d] = w * c;
+            const int n = i * D + d;
+            e[D * (1 + 2 * i) + d] = w * __shfl(sl[n / kGroup], n % kGroup, kGroup);
+            e[D * (2 + 2 * i) + d] = w * __shfl(cl[n / kGroup], n % kGroup, kGroup);
         }
     }
 }
@@ -108,22 +135,14 @@ __device__ __forceinline__ void stage_weights(const WarpArgs& a, float* lw, floa
     __syncthreads();
 }
 
-// A point is served by a QUAD of adjacent lanes; lane `sub` (0..3) owns hidden units sub, sub+4, ...
-// and the quad combines its partial head sums with two DPP shuffles.
-constexpr int kQuad = 4;
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    return v;
-}
 // part a: delta = head_a(softplus(W_a e + v_a))
 __device__ __forceinline__ float part_a(const float* lw, const float* lh, const float* lv, int b, int sub, const float (&ea)[kEa]) {
     const float* W = lw + b * kWembBlock;
     const float* hd = lh + b * kHeadBlock;
     const float* vb = lv + (b * 2 + 0) * kHid;
     float delta = 0.f;
-    for (int u = sub; u < kHid; u += kQuad) delta += hd[u] * softplus100(vb[u] + dot_row<kEa>(W + u * kEa, ea));
-    return quad_sum(delta) + hd[kHid];
+    for (int u = sub; u < kHid; u += kGroup) delta += hd[u] * softplus100(vb[u] + dot_row<kEa>(W + u * kEa, ea));
+    return group_sum(delta) + hd[kHid];
 }
 // part b: (theta, t0, t1) = head_b(softplus(W_b e + v_b))
 __device__ __forceinline__ void part_b(const float* lw, const float* lh, const float* lv, int b, int sub, const float (&eb)[kEb], float (&o)[3]) {
@@ -131,13 +150,13 @@ __device__ __forceinline__ void part_b(const float* lw, const float* lh, const f
     const float* hd = lh + b * kHeadBlock + kHid + 1;
     const float* vb = lv + (b * 2 + 1) * kHid;
     o[0] = o[1] = o[2] = 0.f;
-    for (int u = sub; u < kHid; u += kQuad) {
+    for (int u = sub; u < kHid; u += kGroup) {
         const float hh = softplus100(vb[u] + dot_row<kEb>(W + u * kEb, eb));
         o[0] += hd[u] * hh; o[1] += hd[kHid + u] * hh; o[2] += hd[2 * kHid + u] * hh;
     }
-    o[0] = quad_sum(o[0]) + hd[3 * kHid];
-    o[1] = quad_sum(o[1]) + hd[3 * kHid + 1];
-    o[2] = quad_sum(o[2]) + hd[3 * kHid + 2];
+    o[0] = group_sum(o[0]) + hd[3 * kHid];
+    o[1] = group_sum(o[1]) + hd[3 * kHid + 1];
+    o[2] = group_sum(o[2]) + hd[3 * kHid + 2];
 }
 
 __device__ __forceinline__ void axes(int b, int& f, int& o0, int& o1) {
@@ -152,10 +171,10 @@ __device__ __forceinline__ void block_fwd(const float* lw, const float* lh, cons
     axes(b, f, o0, o1);
     const float oth[2] = {x[o0], x[o1]};
     float ea[kEa];
-    embed<2>(oth, cw, psa, ea);
+    embed<2>(oth, cw, psa, sub, ea);
     const float foc[1] = {x[f] - part_a(lw, lh, lv, b, sub, ea)};
     float eb[kEb], o[3];
-    embed<1>(foc, cw, psb, eb);
+    embed<1>(foc, cw, psb, sub, eb);
     part_b(lw, lh, lv, b, sub, eb, o);
     float s, c;
     sincosf(o[0], &s, &c);
@@ -171,13 +190,13 @@ __device__ __forceinline__ void block_inv(const float* lw, const float* lh, cons
     axes(b, f, o0, o1);
     const float single[1] = {x[f]};
     float eb[kEb], o[3];
-    embed<1>(single, cw, psb, eb);
+    embed<1>(single, cw, psb, sub, eb);
     part_b(lw, lh, lv, b, sub, eb, o);
     float s, c;
     sincosf(o[0], &s, &c);                            // euler2rot_2d: [[cos, -sin], [sin, cos]]
     const float pr[2] = {c * x[o0] - s * x[o1] + o[1], s * x[o0] + c * x[o1] + o[2]};
     float ea[kEa];
-    embed<2>(pr, cw, psa, ea);
+    embed<2>(pr, cw, psa, sub, ea);
     x[f] = single[0] + part_a(lw, lh, lv, b, sub, ea);
     x[o0] = pr[0];
     x[o1] = pr[1];
@@ -190,9 +209,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
     float* lv = lh + 3 * kHeadBlock;
     const int view = blockIdx.y;
     stage_weights(a, lw, lh, lv, view);
-    const int sub = threadIdx.x & (kQuad - 1);
-    const long long p = (long long)blockIdx.x * (blockDim.x / kQuad) + (threadIdx.x >> 2);
-    if (p >= a.n_pts) return;                     // whole quads leave together
+    const int sub = threadIdx.x & (kGroup - 1);
+    const long long p = (long long)blockIdx.x * (blockDim.x / kGroup) + threadIdx.x / kGroup;
+    if (p >= a.n_pts) return;                     // whole groups leave together
     const long long gi = (long long)view * a.n_pts + p;
     float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
     const float psa = a.ps_a ? a.ps_a[p] : 1.f, psb = a.ps_b ? a.ps_b[p] : 1.f;
@@ -211,9 +230,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     float* lv = lh + 3 * kHeadBlock;
     const int view = blockIdx.y;
     stage_weights(a, lw, lh, lv, view);
-    const int sub = threadIdx.x & (kQuad - 1);
-    const long long p = (long long)blockIdx.x * (blockDim.x / kQuad) + (threadIdx.x >> 2);
-    if (p >= a.n_pts) return;                     // whole quads leave together
+    const int sub = threadIdx.x & (kGroup - 1);
+    const long long p = (long long)blockIdx.x * (blockDim.x / kGroup) + threadIdx.x / kGroup;
+    if (p >= a.n_pts) return;                     // whole groups leave together
     const long long gi = (long long)view * a.n_pts + p;
     const float psa = a.ps_a ? a.ps_a[p] : 1.f, psb = a.ps_b ? a.ps_b[p] : 1.f;
     float xin[3][3];
@@ -239,9 +258,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         // ---- recompute the block forward
         const float oth[2] = {xin[b][o0], xin[b][o1]};
         float ea[kEa], eb[kEb], o[3];
-        embed<2>(oth, a.cw, psa, ea);
+        embed<2>(oth, a.cw, psa, sub, ea);
         const float foc[1] = {xin[b][f] - part_a(lw, lh, lv, b, sub, ea)};
-        embed<1>(foc, a.cw, psb, eb);
+        embed<1>(foc, a.cw, psb, sub, eb);
         part_b(lw, lh, lv, b, sub, eb, o);
         float s, c;
         sincosf(o[0], &s, &c);
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         float geb[kEb];
 #pragma unroll
         for (int k = 0; k < kEb; ++k) geb[k] = 0.f;
-        for (int u = sub; u < kHid; u += kQuad) {
+        for (int u = sub; u < kHid; u += kGroup) {
             const float pre = vb[u] + dot_row<kEb>(Wb + u * kEb, eb);
             const float gh = hdb[u] * go[0] + hdb[kHid + u] * go[1] + hdb[2 * kHid + u] * go[2];
             const float gp = gh * dsoftplus100(pre);
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
             for (int k = 0; k < kEb; ++k) geb[k] += Wb[u * kEb + k] * gp;
         }
 #pragma unroll
-        for (int k = 0; k < kEb; ++k) geb[k] = quad_sum(geb[k]);
+        for (int k = 0; k < kEb; ++k) geb[k] = group_sum(geb[k]);
         float gfoc[1];
         embed_bwd<1>(eb, geb, psb, gfoc);
         const float g_foc = gx[f] + gfoc[0];          // d focus'
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         float gea[kEa];
 #pragma unroll
         for (int k = 0; k < kEa; ++k) gea[k] = 0.f;
-        for (int u = sub; u < kHid; u += kQuad) {
+        for (int u = sub; u < kHid; u += kGroup) {
             const float pre = va[u] + dot_row<kEa>(Wa + u * kEa, ea);
             const float gp = g_delta * hda[u] * dsoftplus100(pre);
             ws[(long long)(kRowGa + u) * P] = gp;
@@ -283,18 +302,18 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
             for (int k = 0; k < kEa; ++k) gea[k] += Wa[u * kEa + k] * gp;
         }
 #pragma unroll
-        for (int k = 0; k < kEa; ++k) gea[k] = quad_sum(gea[k]);
+        for (int k = 0; k < kEa; ++k) gea[k] = group_sum(gea[k]);
         float goth[2];
         embed_bwd<2>(ea, gea, psa, goth);
         // ---- per-point factors of the parameter gradients
-        // (the factor rows that do not depend on the hidden unit are split over the quad)
+        // (the factor rows that do not depend on the hidden unit are split over the group)
 #pragma unroll
         for (int k = 0; k < 32; ++k)
-            if ((k & 3) == sub) ws[(long long)(kRowEa + k) * P] = k < kEa ? ea[k] : 0.f;
+            if (k % kGroup == sub) ws[(long long)(kRowEa + k) * P] = k < kEa ? ea[k] : 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k)
-            if ((k & 3) == sub) ws[(long long)(kRowEb + k) * P] = k < kEb ? eb[k] : 0.f;
-        for (int v = sub; v < 64; v += kQuad) ws[(long long)(kRowInd + v) * P] = v == view ? 1.f : 0.f;
+            if (k % kGroup == sub) ws[(long long)(kRowEb + k) * P] = k < kEb ? eb[k] : 0.f;
+        for (int v = sub; v < 64; v += kGroup) ws[(long long)(kRowInd + v) * P] = v == view ? 1.f : 0.f;
         if (sub == 0) {
             ws[(long long)(kRowGo + 0) * P] = g_delta;
             ws[(long long)(kRowGo + 1) * P] = go[0];
@@ -374,7 +393,7 @@ extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float
     a.out = out; a.inverse = inverse;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
-    warp_fwd_kernel<<<dim3((unsigned)((n_pts + 63) / 64), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
+    warp_fwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_fwd");
     return NIW_OK;
 }
@@ -401,7 +420,7 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
         (void)hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
-    warp_bwd_kernel<<<dim3((unsigned)((n_pts + 63) / 64), n_views), 256, kWarpLds, st>>>(a);
+    warp_bwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, st>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_bwd");
     float* p1 = workspace + 3ll * kRowsPerBlock * ppad;
     float* p2 = p1 + 3ll * 256 * (256 * 256 + 256);

@@ -1,5 +1,5 @@
 // NVP warp: per-parameter / per-view operand preparation of DeformNetwork (reference
-// model/nvp/nvp_ndr.py) and its backward, fused into one launch each.
+// model/nvp/nvp_ndr.py) and its backward.
 //
 //   weight norm          w = g * v / ||v||_row                        (nvp_ndr.py:291-292, nn.utils.weight_norm)
 //   code projection      code_b = lin_c(code) + code                  (nvp_ndr.py:381)
@@ -7,8 +7,10 @@
 //                        (the latent half of lin{b}_{a,b}_0 applied to the per-view code, nvp_ndr.py:416-420, 433-437)
 //   w_emb = w[:, :E],  w_head = (lin{b}_a_1, lin{b}_b_1) verbatim
 //
-// These are O(parameters) = 166k MACs x views, i.e. launch-latency sized; as ~150 separate torch
-// kernels (forward + autograd) they made small configurations host-dispatch bound.
+// These are O(parameters) = 166k MACs x views, i.e. latency sized; as ~150 separate torch kernels (forward +
+// autograd) they made small configurations host-dispatch bound.  Here: two launches forward, three backward,
+// every reduction a wave-wide butterfly over a coalesced row (one wave per weight row), every cross-workgroup
+// sum a fixed-order pass over partials (deterministic, no float atomics).
 //
 // Flat parameter layout (= DeformNetwork.parameters() order, reference and host mirror alike: old-style
 // weight_norm leaves `bias` registered before `weight_g` / `weight_v`; 165,900 floats):
@@ -28,6 +30,9 @@ constexpr int kOffB = 3 * kBlkA, kOffC = kOffB + 3 * kBlkB;
 static_assert(kOffC + 3 * kBlkC == NIW_WARP_PARAM_FLOATS, "flat warp parameter count");
 constexpr int kWembBlock = kHid * (kEa + kEb), kHeadBlock = kHid + 1 + 3 * kHid + 3;
 constexpr int kMaxViews = 64;
+constexpr int kGroups = 8, kRowsPerWave = 4;            // a workgroup (4 waves) owns 16 of the 128 rows of one first layer
+constexpr int kParts = 2 * kGroups * 4;                 // d(code_b) partials per coupling block: (part, group, wave)
+static_assert(kGroups * 4 * kRowsPerWave == kHid, "row decomposition");
 
 struct Layer {                 // first layer of part a / b of block b inside the flat buffer
     int g, v, bias, head, E, K, nhead;
@@ -42,153 +47,208 @@ __device__ __forceinline__ Layer layer_of(int b, int part) {
     return l;
 }
 
-// code_b[v][j] = bc[j] + code[v][j] + sum_k Wc[j][k] code[v][k]  -> LDS
-__device__ __forceinline__ void project_code(const float* __restrict__ P, const float* __restrict__ code, int B, int b, float* codeb) {
+__device__ __forceinline__ float wave_sum(float x) {    // butterfly: every lane ends with the total, same order on every run
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+// code_b[b][v][j] = bc[j] + code[v][j] + sum_k Wc[j][k] code[v][k];  grid (3, B), one wave per 32 rows j
+__global__ __launch_bounds__(256) void warp_prep_code_kernel(const float* __restrict__ P, const float* __restrict__ code, int B,
+                                                             float* __restrict__ codeb) {
+    const int b = blockIdx.x, v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* Wc = P + kOffC + b * kBlkC;
     const float* bc = Wc + kLat * kLat;
-    for (int idx = threadIdx.x; idx < B * kLat; idx += blockDim.x) {
-        const int v = idx / kLat, j = idx % kLat;
-        float acc = 0.f;
-        for (int k = 0; k < kLat; ++k) acc += Wc[j * kLat + k] * code[v * kLat + k];
-        codeb[idx] = acc + bc[j] + code[v * kLat + j];
+    const float c0 = code[v * kLat + lane], c1 = code[v * kLat + 64 + lane];
+    for (int jj = 0; jj < 32; ++jj) {
+        const int j = wave * 32 + jj;
+        const float s = wave_sum(Wc[j * kLat + lane] * c0 + Wc[j * kLat + 64 + lane] * c1);
+        if (lane == 0) codeb[((long long)b * B + v) * kLat + j] = s + bc[j] + code[v * kLat + j];
     }
 }
 
-__global__ __launch_bounds__(256) void warp_prep_fwd_kernel(const float* __restrict__ P, const float* __restrict__ code, int B,
+struct RowCtx { int b, part, u0; Layer l; };
+__device__ __forceinline__ RowCtx row_ctx() {           // grid 3 * 2 * kGroups; wave w owns rows u0 .. u0+3
+    RowCtx c;
+    c.b = blockIdx.x / (2 * kGroups);
+    c.part = (blockIdx.x / kGroups) & 1;
+    c.u0 = (blockIdx.x % kGroups) * 16 + (threadIdx.x >> 6) * kRowsPerWave;
+    c.l = layer_of(c.b, c.part);
+    return c;
+}
+
+__global__ __launch_bounds__(256) void warp_prep_fwd_kernel(const float* __restrict__ P, const float* __restrict__ codeb, int B,
                                                             float* __restrict__ w_emb, float* __restrict__ view_b, float* __restrict__ w_head) {
-    __shared__ float codeb[kMaxViews * kLat];
-    __shared__ float scale[kHid];
-    const int b = blockIdx.x >> 1, part = blockIdx.x & 1, tid = threadIdx.x;
-    const Layer l = layer_of(b, part);
-    project_code(P, code, B, b, codeb);
-    if (tid < kHid) {
-        float n2 = 0.f;
-        for (int c = 0; c < l.K; ++c) { const float x = P[l.v + tid * l.K + c]; n2 += x * x; }
-        scale[tid] = P[l.g + tid] / sqrtf(n2);
-    }
+    __shared__ float cb[kMaxViews * kLat];
+    const RowCtx c = row_ctx();
+    const Layer l = c.l;
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < B * kLat; i += blockDim.x) cb[i] = codeb[(long long)c.b * B * kLat + i];
     __syncthreads();
-    float* we = w_emb + b * kWembBlock + (part ? kHid * kEa : 0);
-    for (int idx = tid; idx < kHid * l.E; idx += blockDim.x) {
-        const int u = idx / l.E, c = idx % l.E;
-        we[idx] = P[l.v + u * l.K + c] * scale[u];
+    float* we = w_emb + c.b * kWembBlock + (c.part ? kHid * kEa : 0);
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int u = c.u0 + r;
+        const float* vrow = P + l.v + u * l.K;
+        const float e = lane < l.E ? vrow[lane] : 0.f;                    // embedding columns
+        const float y0 = vrow[l.E + lane], y1 = vrow[l.E + 64 + lane];   // latent columns
+        const float s = P[l.g + u] / sqrtf(wave_sum(e * e + y0 * y0 + y1 * y1));
+        if (lane < l.E) we[u * l.E + lane] = e * s;
+        const float bias = P[l.bias + u];
+        for (int v = 0; v < B; ++v) {
+            const float d = wave_sum(y0 * cb[v * kLat + lane] + y1 * cb[v * kLat + 64 + lane]);
+            if (lane == 0) view_b[((v * 3 + c.b) * 2 + c.part) * kHid + u] = bias + s * d;
+        }
     }
-    for (int idx = tid; idx < B * kHid; idx += blockDim.x) {
-        const int v = idx / kHid, u = idx % kHid;
-        const float* row = P + l.v + u * l.K + l.E;
-        float acc = 0.f;
-        for (int k = 0; k < kLat; ++k) acc += row[k] * codeb[v * kLat + k];
-        view_b[((v * 3 + b) * 2 + part) * kHid + u] = P[l.bias + u] + scale[u] * acc;
+    if (blockIdx.x % kGroups == 0) {
+        float* wh = w_head + c.b * kHeadBlock + (c.part ? kHid + 1 : 0);
+        for (int i = threadIdx.x; i < l.nhead; i += blockDim.x) wh[i] = P[l.head + i];
     }
-    float* wh = w_head + b * kHeadBlock + (part ? kHid + 1 : 0);
-    for (int idx = tid; idx < l.nhead; idx += blockDim.x) wh[idx] = P[l.head + idx];
 }
 
-// One workgroup per coupling block: both first layers (weight-norm backward), the code projection and
-// this block's share of d(code) (summed over the blocks by warp_prep_sum_kernel, fixed order).
-__global__ __launch_bounds__(256) void warp_prep_bwd_kernel(const float* __restrict__ P, const float* __restrict__ code, int B,
+// Weight-norm backward of the first layers + this wave's share of d(code_b)  (partials [b][kParts][B][128]).
+__global__ __launch_bounds__(256) void warp_prep_bwd_kernel(const float* __restrict__ P, const float* __restrict__ codeb, int B,
                                                             const float* __restrict__ d_w_emb, const float* __restrict__ d_view_b,
                                                             const float* __restrict__ d_w_head, float* __restrict__ dP,
-                                                            float* __restrict__ d_code_blk) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* codeb = lds;                               // [B][128]
-    float* dcodeb = codeb + kMaxViews * kLat;         // [B][128]
-    float* dwl = dcodeb + kMaxViews * kLat;           // [128 u][128 k]  latent half of dW
-    float* scale = dwl + kHid * kLat;                 // [128]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    project_code(P, code, B, b, codeb);
-    for (int idx = tid; idx < B * kLat; idx += blockDim.x) dcodeb[idx] = 0.f;
+                                                            float* __restrict__ partial) {
+    __shared__ float cb[kMaxViews * kLat];
+    const RowCtx c = row_ctx();
+    const Layer l = c.l;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < B * kLat; i += blockDim.x) cb[i] = codeb[(long long)c.b * B * kLat + i];
     __syncthreads();
-    for (int part = 0; part < 2; ++part) {
-        const Layer l = layer_of(b, part);
-        // latent half of dW:  dwl[u][k] = sum_v d_view_b[v][u] * code_b[v][k]
-        for (int idx = tid; idx < kHid * kLat; idx += blockDim.x) {
-            const int u = idx / kLat, k = idx % kLat;
-            float acc = 0.f;
-            for (int v = 0; v < B; ++v) acc += d_view_b[((v * 3 + b) * 2 + part) * kHid + u] * codeb[v * kLat + k];
-            dwl[idx] = acc;
+    const float* dvb = d_view_b + (c.b * 2 + c.part) * kHid;             // + v * 3*2*128 + u
+    float sr[kRowsPerWave], y0r[kRowsPerWave], y1r[kRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int u = c.u0 + r;
+        // latent half of dW:  dwl[k] = sum_v d_view_b[v][u] * code_b[v][k]
+        float dwl0 = 0.f, dwl1 = 0.f, db = 0.f;
+        for (int v = 0; v < B; ++v) {
+            const float t = dvb[v * 6 * kHid + u];
+            dwl0 += t * cb[v * kLat + lane];
+            dwl1 += t * cb[v * kLat + 64 + lane];
+            db += t;
         }
-        __syncthreads();
-        if (tid < kHid) {
-            const int u = tid;
-            const float* vrow = P + l.v + u * l.K;
-            const float* dwe = d_w_emb + b * kWembBlock + (part ? kHid * kEa : 0) + u * l.E;
-            float n2 = 0.f, dot = 0.f;
-            for (int c = 0; c < l.K; ++c) {
-                const float x = vrow[c];
-                n2 += x * x;
-                dot += (c < l.E ? dwe[c] : dwl[u * kLat + c - l.E]) * x;
-            }
-            const float n = sqrtf(n2), g = P[l.g + u], s = g / n;
-            scale[u] = s;
-            dP[l.g + u] = dot / n;                                    // d weight_g
-            const float coef = g * dot / (n2 * n);
-            for (int c = 0; c < l.K; ++c)                             // d weight_v = s dW - (g/n^3)(dW.v) v
-                dP[l.v + u * l.K + c] = s * (c < l.E ? dwe[c] : dwl[u * kLat + c - l.E]) - coef * vrow[c];
-            float db = 0.f;
-            for (int v = 0; v < B; ++v) db += d_view_b[((v * 3 + b) * 2 + part) * kHid + u];
+        const float* vrow = P + l.v + u * l.K;
+        const float* dwe = d_w_emb + c.b * kWembBlock + (c.part ? kHid * kEa : 0) + u * l.E;
+        const float e = lane < l.E ? vrow[lane] : 0.f, de = lane < l.E ? dwe[lane] : 0.f;
+        const float y0 = vrow[l.E + lane], y1 = vrow[l.E + 64 + lane];
+        const float n2 = wave_sum(e * e + y0 * y0 + y1 * y1);
+        const float dot = wave_sum(de * e + dwl0 * y0 + dwl1 * y1);
+        const float n = sqrtf(n2), g = P[l.g + u], s = g / n, coef = g * dot / (n2 * n);
+        float* drow = dP + l.v + u * l.K;                                // d weight_v = s dW - (g/n^3)(dW.v) v
+        if (lane < l.E) drow[lane] = s * de - coef * e;
+        drow[l.E + lane] = s * dwl0 - coef * y0;
+        drow[l.E + 64 + lane] = s * dwl1 - coef * y1;
+        if (lane == 0) {
+            dP[l.g + u] = dot / n;                                       // d weight_g
             dP[l.bias + u] = db;
         }
-        __syncthreads();
-        // d code_b[v][k] += sum_u d_view_b[v][u] * s[u] * V[u][E+k]
-        for (int idx = tid; idx < B * kLat; idx += blockDim.x) {
-            const int v = idx / kLat, k = idx % kLat;
-            float acc = 0.f;
-            for (int u = 0; u < kHid; ++u) acc += d_view_b[((v * 3 + b) * 2 + part) * kHid + u] * scale[u] * P[l.v + u * l.K + l.E + k];
-            dcodeb[idx] += acc;
+        sr[r] = s; y0r[r] = y0; y1r[r] = y1;
+    }
+    // d code_b[v][k] (this wave's 4 rows) = sum_r d_view_b[v][u_r] * s_r * V[u_r][E+k]
+    float* out = partial + (((long long)c.b * kParts + (c.part * kGroups + blockIdx.x % kGroups) * 4 + wave) * B) * kLat;
+    for (int v = 0; v < B; ++v) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const float t = dvb[v * 6 * kHid + c.u0 + r] * sr[r];
+            a0 += t * y0r[r];
+            a1 += t * y1r[r];
         }
-        const float* dh = d_w_head + b * kHeadBlock + (part ? kHid + 1 : 0);
-        for (int idx = tid; idx < l.nhead; idx += blockDim.x) dP[l.head + idx] = dh[idx];
+        out[v * kLat + lane] = a0;
+        out[v * kLat + 64 + lane] = a1;
+    }
+    if (blockIdx.x % kGroups == 0) {
+        const float* dh = d_w_head + c.b * kHeadBlock + (c.part ? kHid + 1 : 0);
+        for (int i = threadIdx.x; i < l.nhead; i += blockDim.x) dP[l.head + i] = dh[i];
+    }
+}
+
+__device__ __forceinline__ float sum_parts(const float* __restrict__ p, long long stride) {   // fixed order over kParts partials
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < kParts; w += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += p[(w + k) * stride];
+    }
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// Code projection backward.  Workgroups 0..B-1: d code[v];  workgroups B..B+23: 16 rows of d lin{b}_c.
+__global__ __launch_bounds__(256) void warp_prep_bwd_code_kernel(const float* __restrict__ P, const float* __restrict__ code, int B,
+                                                                 const float* __restrict__ partial, float* __restrict__ dP,
+                                                                 float* __restrict__ d_code) {
+    __shared__ float sh[kMaxViews * 16 > 3 * kLat ? kMaxViews * 16 : 3 * kLat];
+    const int tid = threadIdx.x;
+    const long long pstride = (long long)B * kLat;
+    if ((int)blockIdx.x < B) {
+        const int v = blockIdx.x;
+        for (int i = tid; i < 3 * kLat; i += blockDim.x) {                // d code_b[b][v][j], all three blocks
+            const int b = i / kLat, j = i % kLat;
+            sh[i] = sum_parts(partial + (long long)b * kParts * pstride + v * kLat + j, pstride);
+        }
         __syncthreads();
+        if (tid < kLat) {
+            float acc = 0.f;
+            for (int b = 0; b < 3; ++b) {
+                const float* Wc = P + kOffC + b * kBlkC;
+                float a = sh[b * kLat + tid];                             // identity path of code_b = lin_c(code) + code
+                for (int j = 0; j < kLat; ++j) a += sh[b * kLat + j] * Wc[j * kLat + tid];
+                acc += a;
+            }
+            d_code[v * kLat + tid] = acc;
+        }
+        return;
     }
-    // code projection backward
+    const int idx = blockIdx.x - B, b = idx / 8, j0 = (idx % 8) * 16;
+    for (int i = tid; i < B * 16; i += blockDim.x) {                      // d code_b[b][v][j0 + jj]
+        const int v = i / 16, jj = i % 16;
+        sh[i] = sum_parts(partial + (long long)b * kParts * pstride + v * kLat + j0 + jj, pstride);
+    }
+    __syncthreads();
     const int oc = kOffC + b * kBlkC;
-    for (int idx = tid; idx < kLat * kLat; idx += blockDim.x) {
-        const int j = idx / kLat, k = idx % kLat;
+    for (int i = tid; i < 16 * kLat; i += blockDim.x) {                   // d Wc[j][k] = sum_v d code_b[v][j] code[v][k]
+        const int jj = i / kLat, k = i % kLat;
         float acc = 0.f;
-        for (int v = 0; v < B; ++v) acc += dcodeb[v * kLat + j] * code[v * kLat + k];
-        dP[oc + idx] = acc;
+        for (int v = 0; v < B; ++v) acc += sh[v * 16 + jj] * code[v * kLat + k];
+        dP[oc + (j0 + jj) * kLat + k] = acc;
     }
-    for (int j = tid; j < kLat; j += blockDim.x) {
+    if (tid < 16) {
         float acc = 0.f;
-        for (int v = 0; v < B; ++v) acc += dcodeb[v * kLat + j];
-        dP[oc + kLat * kLat + j] = acc;
-    }
-    for (int idx = tid; idx < B * kLat; idx += blockDim.x) {
-        const int v = idx / kLat, k = idx % kLat;
-        float acc = dcodeb[idx];
-        for (int j = 0; j < kLat; ++j) acc += dcodeb[v * kLat + j] * P[oc + j * kLat + k];
-        d_code_blk[(b * B + v) * kLat + k] = acc;
+        for (int v = 0; v < B; ++v) acc += sh[v * 16 + tid];
+        dP[oc + kLat * kLat + j0 + tid] = acc;
     }
 }
-
-__global__ void warp_prep_sum_kernel(const float* __restrict__ d_code_blk, int n, float* __restrict__ d_code) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d_code[i] = (d_code_blk[i] + d_code_blk[n + i]) + d_code_blk[2 * n + i];
-}
-
-constexpr size_t kBwdLds = (2 * kMaxViews * kLat + kHid * kLat + kHid) * sizeof(float);
 
 }  // namespace
 
-extern "C" int niw_warp_prep_fwd(const float* params, const float* code, int n_views, float* w_emb, float* view_b, float* w_head,
-                                 niw_stream_t stream) {
-    NIW_REQUIRE(params && code && w_emb && view_b && w_head, "niw_warp_prep_fwd: null pointer");
+extern "C" int64_t niw_warp_prep_fwd_workspace_floats(int n_views) { return 3ll * n_views * kLat; }
+extern "C" int64_t niw_warp_prep_bwd_workspace_floats(int n_views) { return (3ll + 3ll * kParts) * n_views * kLat; }
+
+extern "C" int niw_warp_prep_fwd(const float* params, const float* code, int n_views, float* workspace, float* w_emb, float* view_b,
+                                 float* w_head, niw_stream_t stream) {
+    NIW_REQUIRE(params && code && workspace && w_emb && view_b && w_head, "niw_warp_prep_fwd: null pointer");
     NIW_REQUIRE(n_views > 0 && n_views <= kMaxViews, "niw_warp_prep_fwd: 1..%d views per call (got %d)", kMaxViews, n_views);
-    warp_prep_fwd_kernel<<<6, 256, 0, (hipStream_t)stream>>>(params, code, n_views, w_emb, view_b, w_head);
+    hipStream_t st = (hipStream_t)stream;
+    warp_prep_code_kernel<<<dim3(3, n_views), 256, 0, st>>>(params, code, n_views, workspace);
+    NIW_LAUNCH_CHECK("niw_warp_prep_fwd (code projection)");
+    warp_prep_fwd_kernel<<<3 * 2 * kGroups, 256, 0, st>>>(params, workspace, n_views, w_emb, view_b, w_head);
     NIW_LAUNCH_CHECK("niw_warp_prep_fwd");
     return NIW_OK;
 }
 
 extern "C" int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
-                                 const float* d_w_head, float* scratch, float* d_params, float* d_code, niw_stream_t stream) {
-    NIW_REQUIRE(params && code && d_w_emb && d_view_b && d_w_head && scratch && d_params && d_code, "niw_warp_prep_bwd: null pointer");
+                                 const float* d_w_head, float* workspace, float* d_params, float* d_code, niw_stream_t stream) {
+    NIW_REQUIRE(params && code && d_w_emb && d_view_b && d_w_head && workspace && d_params && d_code, "niw_warp_prep_bwd: null pointer");
     NIW_REQUIRE(n_views > 0 && n_views <= kMaxViews, "niw_warp_prep_bwd: 1..%d views per call (got %d)", kMaxViews, n_views);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_prep_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds); attr = true; }
-    warp_prep_bwd_kernel<<<3, 256, kBwdLds, (hipStream_t)stream>>>(params, code, n_views, d_w_emb, d_view_b, d_w_head, d_params, scratch);
+    hipStream_t st = (hipStream_t)stream;
+    float* codeb = workspace;
+    float* partial = workspace + 3ll * n_views * kLat;
+    warp_prep_code_kernel<<<dim3(3, n_views), 256, 0, st>>>(params, code, n_views, codeb);
+    NIW_LAUNCH_CHECK("niw_warp_prep_bwd (code projection)");
+    warp_prep_bwd_kernel<<<3 * 2 * kGroups, 256, 0, st>>>(params, codeb, n_views, d_w_emb, d_view_b, d_w_head, d_params, partial);
     NIW_LAUNCH_CHECK("niw_warp_prep_bwd");
-    const int n = n_views * kLat;
-    warp_prep_sum_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(scratch, n, d_code);
-    NIW_LAUNCH_CHECK("niw_warp_prep_bwd (sum)");
+    warp_prep_bwd_code_kernel<<<n_views + 24, 256, 0, st>>>(params, code, n_views, partial, d_params, d_code);
+    NIW_LAUNCH_CHECK("niw_warp_prep_bwd (code projection backward)");
     return NIW_OK;
 }

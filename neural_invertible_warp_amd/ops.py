@@ -357,7 +357,8 @@ class _WarpPrep(torch.autograd.Function):
         w_emb = torch.empty(WARP_WEMB_FLOATS, device=dev)
         view_b = torch.empty(B, 3, 2, 128, device=dev)
         w_head = torch.empty(WARP_WHEAD_FLOATS, device=dev)
-        _lib.call("niw_warp_prep_fwd", _p(flat), _p(code), B, _p(w_emb), _p(view_b), _p(w_head), _stream())
+        ws = torch.empty(_lib.load().niw_warp_prep_fwd_workspace_floats(B), device=dev)
+        _lib.call("niw_warp_prep_fwd", _p(flat), _p(code), B, _p(ws), _p(w_emb), _p(view_b), _p(w_head), _stream())
         ctx.flat = flat
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(code)
@@ -370,7 +371,7 @@ class _WarpPrep(torch.autograd.Function):
         dev = code.device
         z = lambda g, n: torch.zeros(n, device=dev) if g is None else _f32(g, "grad")
         d_w_emb, d_view_b, d_w_head = z(d_w_emb, WARP_WEMB_FLOATS), z(d_view_b, B * 3 * 2 * 128), z(d_w_head, WARP_WHEAD_FLOATS)
-        scratch = torch.empty(3 * B * 128, device=dev)
+        scratch = torch.empty(_lib.load().niw_warp_prep_bwd_workspace_floats(B), device=dev)
         d_params = torch.empty(WARP_PARAM_FLOATS, device=dev)
         d_code = torch.empty(B, 128, device=dev)
         _lib.call("niw_warp_prep_bwd", _p(ctx.flat), _p(code), B, _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(scratch),
