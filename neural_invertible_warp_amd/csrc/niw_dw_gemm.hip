@@ -172,17 +172,19 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int tile = a.TN * a.TK;
     const int stride = tile + 256;
+    const int layer = a.layer + blockIdx.y;                  // batched launch: blockIdx.y-th of consecutive layers
+    const float* partial = a.partial + (long long)blockIdx.y * a.nsplit * stride;
     if (idx < tile) {
         const int tr = idx / a.TK, tc = idx % a.TK;
         const int n = a.n_off + (a.transposed ? tc : tr), s = a.k_off + (a.transposed ? tr : tc);
-        const int row = out_row(a.layer, n), col = fwd_slot_col(a.layer, s);
+        const int row = out_row(layer, n), col = fwd_slot_col(layer, s);
         if (row < 0 || col < 0) return;
-        a.d_params[weight_off(a.layer) + row * layer_k(a.layer) + col] = sum_partials(a.partial + idx, stride, a.nsplit);
+        a.d_params[weight_off(layer) + row * layer_k(layer) + col] = sum_partials(partial + idx, stride, a.nsplit);
     } else if (a.bias && idx < tile + 256) {
         const int b = idx - tile;
-        const int row = out_row(a.layer, a.n_off + b);
+        const int row = out_row(layer, a.n_off + b);
         if (row < 0 || b >= (a.transposed ? a.TK : a.TN)) return;
-        a.d_params[bias_off(a.layer) + row] = sum_partials(a.partial + idx, stride, a.nsplit);
+        a.d_params[bias_off(layer) + row] = sum_partials(partial + idx, stride, a.nsplit);
     }
 }
 
@@ -198,9 +200,11 @@ int launch_gemm(NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int
                 int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
-    // at least 8 slices per workgroup, at most one workgroup per CU
+    // at least 8 slices per workgroup; one workgroup per CU, or -- for a batch of equal pieces -- just under two
+    // full rounds of the 256 CUs in total (fewer, longer workgroups: less partial-tile traffic for the reducer)
+    const int cap = batches >= 4 ? (2 * 256 - 1) / batches : 256;
     int nsplit = (steps_total + 7) / 8;
-    nsplit = nsplit < 1 ? 1 : (nsplit > 256 ? 256 : nsplit);
+    nsplit = nsplit < 1 ? 1 : (nsplit > cap ? cap : nsplit);
     const int per = (steps_total + nsplit - 1) / nsplit;
     nsplit = (steps_total + per - 1) / per;
     const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
@@ -216,17 +220,18 @@ int launch_gemm(NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int
     return NIW_OK;
 }
 
-int launch_piece(const Piece& p, NiwGemmOperand A, NiwGemmOperand B, long long mpad, float* partial, float* d_params, hipStream_t st) {
+int launch_piece(const Piece& p, NiwGemmOperand A, NiwGemmOperand B, long long mpad, int batches, float* partial, float* d_params,
+                 hipStream_t st) {
     const int bias_side = p.bias ? (p.transposed ? 2 : 1) : 0;
     int nsplit = 0;
-    int rc = niw_launch_nt_gemm(p.wide, A, B, (int)(mpad / 32), mpad, 1, partial, bias_side, &nsplit, st);
+    int rc = niw_launch_nt_gemm(p.wide, A, B, (int)(mpad / 32), mpad, batches, partial, bias_side, &nsplit, st);
     if (rc != NIW_OK) return rc;
     ReduceArgs r;
     r.partial = partial; r.d_params = d_params; r.nsplit = nsplit; r.layer = p.layer;
     r.TN = p.wide == 2 ? 128 : 256;
     r.TK = p.wide == 2 ? 288 : (p.wide == 1 ? 256 : 64);
     r.n_off = p.n_off; r.k_off = p.k_off; r.transposed = p.transposed; r.bias = p.bias;
-    dw_reduce_kernel<<<(r.TN * r.TK + 256 + 255) / 256, 256, 0, st>>>(r);
+    dw_reduce_kernel<<<dim3((r.TN * r.TK + 256 + 255) / 256, batches), 256, 0, st>>>(r);
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dW reduce)");
     return NIW_OK;
 }
@@ -243,7 +248,7 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, lo
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
     (void)n_rays; (void)n_samples;
-    return 256ll * (256 * 256 + 256);
+    return 512ll * (256 * 256 + 256);          // up to 511 partial tiles (7 batched pieces x 73 splits)
 }
 
 extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
@@ -270,23 +275,22 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     const Piece pieces[] = {
         // layer, a_row, a_rows, b_row, b_rows, n_off, k_off, transposed, bias, wide
         {0, 0 * 256, 256, kSaveEnc, 64, 0, 0, 0, 1, 0},
+        // layers 1..7, 256 x 256 each: dY rows l*256 (kGradY7 = 7*256), X rows save_h(l) = 64 + (l-1)*256 -> ONE batched
+        // launch of 7 pieces (batch stride 256 rows on both sides)
         {1, 1 * 256, 256, save_h(1), 256, 0, 0, 0, 1, 1},
-        {2, 2 * 256, 256, save_h(2), 256, 0, 0, 0, 1, 1},
-        {3, 3 * 256, 256, save_h(3), 256, 0, 0, 0, 1, 1},
-        {4, 4 * 256, 256, save_h(4), 256, 0, 0, 0, 1, 1},
         {4, 4 * 256, 256, kSaveEnc, 64, 0, 256, 0, 0, 0},
-        {5, 5 * 256, 256, save_h(5), 256, 0, 0, 0, 1, 1},
-        {6, 6 * 256, 256, save_h(6), 256, 0, 0, 0, 1, 1},
-        {7, kGradY7, 256, save_h(7), 256, 0, 0, 0, 1, 1},
         {7, save_h(7), 256, kGradY7 + 256, 1, 256, 0, 1, 1, 0},          // density row (transposed)
         {8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2},              // feat rows and the 32 view-slot rows are contiguous
         {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0},                  // colour rows (transposed)
     };
+    static_assert(kGradY7 == 7 * 256, "the batched wide launch assumes uniformly strided dY blocks");
     for (const Piece& p : pieces) {
         // workspaces are plain feature-major [row][Mpad]: row pitch Mpad, a single sample block
-        const NiwGemmOperand A{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad, 0};
-        const NiwGemmOperand B{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad, 0};
-        int rc = launch_piece(p, A, B, mpad, partial, d_params, st);
+        const int batches = p.wide == 1 ? 7 : 1;
+        const long long bstride = batches > 1 ? 256 * mpad : 0;
+        const NiwGemmOperand A{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, bstride, mpad, 0};
+        const NiwGemmOperand B{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, bstride, mpad, 0};
+        int rc = launch_piece(p, A, B, mpad, batches, partial, d_params, st);
         if (rc != NIW_OK) return rc;
     }
     return NIW_OK;
