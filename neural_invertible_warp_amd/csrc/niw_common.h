@@ -121,7 +121,12 @@ __host__ __device__ constexpr int out_row(int l, int n) {
 // rows of the activation / gradient workspaces
 constexpr int kSaveEnc = 0, kSaveH1 = 64, kSaveFeat = 64 + 7 * 256, kSaveVenc = kSaveFeat + 256,
               kSaveHr = kSaveVenc + 32, kSaveSigma = kSaveHr + 128;
-static_assert(kSaveSigma + 2 == NIW_SAVE_ROWS, "save rows");
+// ReLU sign bits of every hidden activation, for the dX chain (which otherwise re-read all of h1..h7, feat, hr --
+// 8.7 KB per sample -- only to recover them): per wave (32 samples) 9 records (output of layers 0..6, feat, hr) of
+// 1 KiB = [lane 0..63][4 dwords]: dword nb/2, bit 31 - (16*(nb&1) + r) = (activation > 0) of accumulator register r of row block nb of that
+// lane.  72 float-rows' worth of space.
+constexpr int kSaveMask = kSaveSigma + 2, kMaskRecords = 9, kMaskRecBytes = 1024, kMaskRows = kMaskRecords * kMaskRecBytes / (4 * 32);
+static_assert(kSaveMask + kMaskRows == NIW_SAVE_ROWS, "save rows");
 __host__ __device__ constexpr int save_h(int l) { return kSaveH1 + (l - 1) * 256; }   // output of layer l-1, l = 1..7
 constexpr int kGradY7 = 7 * 256, kGradRgb0 = kGradY7 + 288, kGradRgb1 = kGradRgb0 + 128;
 // stash rows: d(encoding slots) from the layer-4 skip and d(view-encoding slots), parked in the

@@ -28,21 +28,22 @@ struct MlpBwdArgs {
 };
 
 // Epilogue policies for stream_layer() (niw_mlp_device.h); all workspace traffic uses buffer addressing.
-// ReLU mask + hand-over + store: the mask source (the activation the forward saved for this layer's
-// input) is fetched one row block ahead; dY is stored feature-major for the dW pass.
+// ReLU mask + hand-over + store.  The masks are the sign bits the forward recorded (niw_common.h kSaveMask):
+// one 1 KiB record per layer and wave, fetched as ONE 16 B/lane load a whole layer ahead, so that nothing with
+// HBM latency sits in the in-order vmcnt queue in front of the weight-fragment ring (re-reading the saved fp32
+// activations for their signs did: 16 loads per row block, 6.8 GB per launch).  The lane's 16 bytes hold its own
+// sign bits: dword nb/2, bit 31 - (16*(nb&1) + r), zeroed for padding samples.  dY is stored feature-major for the dW pass.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NBOUT>
 struct MaskEpilogue {
-    RowWindow act;                       // saved activations of the layer input (mask source)
+    u32x4 mk;                            // this lane's 16 bytes of the mask record of the layer input
     float (&out)[16 * NBOUT];
     RowWindow grad;                      // where dY of the producing layer is stored
-    bool valid;
-    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
-        const rsrc_t r0 = act.rsrc(nb * 32);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) buf[r] = buf_load1(r0, act.voff4, reg_row(r) * act.pitch4);
-    }
-    __device__ __forceinline__ void epi(int nb, int r, float a, float p) {
-        const float g = (valid && p > 0.f) ? a : 0.f;
+    __device__ __forceinline__ void pre(int, float (&)[16]) const {}
+    __device__ __forceinline__ void epi(int nb, int r, float a, float) {
+        // sign-extended 1-bit field = all-ones / zero: the ReLU mask is one AND on the float's bits
+        const int keep = (int)(mk[nb >> 1] << (16 * (nb & 1) + r)) >> 31;
+        const float g = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
         out[nb * 16 + r] = g;
         buf_store1(g, grad.rsrc(nb * 32), grad.voff4, reg_row(r) * grad.pitch4);
     }
@@ -119,6 +120,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     auto swin = [&](int r) { return RowWindow{a.save + (long long)r * P, pitch4, voff4}; };     // activation rows
     auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };     // gradient rows
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
+    // ReLU sign-mask records of this wave: record i = output of layer i (0..6), 7 = feat, 8 = hr; each is loaded while
+    // the layer before its consumer runs
+    const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    const char* mbase = reinterpret_cast<const char*>(a.save + (long long)kSaveMask * P) + wave_id * kMaskRecords * kMaskRecBytes;
+    auto mask_rec = [&](int i) {
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(mbase), lane * 16, i * kMaskRecBytes, 0));
+        return valid ? v : u32x4{0u, 0u, 0u, 0u};
+    };
+    u32x4 mk_cur = mask_rec(8), mk_nxt = mask_rec(7);
 
     float dy[128], nxt[128];
     auto advance = [&]() {
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     float dyr[64];
     {
-        MaskEpilogue<4> ep{swin(kSaveHr), dyr, gwin(kGradRgb0), valid};
+        MaskEpilogue<4> ep{mk_cur, dyr, gwin(kGradRgb0)};
         stream_layer<1, 0, 4, 4>(pw, wp + bwd_pack_off(9) / 4, dy9, none, ep);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = row block 8 of 9)
@@ -149,7 +159,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         stream_layer<16, 0, 1, 9>(pw, wp + bwd_pack_off(8) / 4 + 8 * 64, dyr, none, ep);
     }
     {
-        MaskEpilogue<8> ep{swin(kSaveFeat), dy, gwin(kGradY7), valid};
+        mk_cur = mk_nxt; mk_nxt = mask_rec(6);
+        MaskEpilogue<8> ep{mk_cur, dy, gwin(kGradY7)};
         stream_layer<16, 0, 8, 9>(pw, wp + bwd_pack_off(8) / 4, dyr, none, ep);
     }
     // ---- density head: d sigma_raw (kernel row 256 of layer 7)
@@ -167,14 +178,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
-        MaskEpilogue<8> ep{swin(save_h(7)), nxt, gwin(6 * 256), valid};
+        mk_cur = mk_nxt; mk_nxt = mask_rec(5);
+        MaskEpilogue<8> ep{mk_cur, nxt, gwin(6 * 256)};
         stream_layer<32, 1, 8, 8>(pw, wp + bwd_pack_off(7) / 4, dy, dsig, ep);
         advance();
     }
     // ---- layers 6, 5 transposed: produce dY5, dY4
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
-        MaskEpilogue<8> ep{swin(save_h(l)), nxt, gwin((l - 1) * 256), valid};
+        mk_cur = mk_nxt; mk_nxt = mask_rec(l - 2);       // this layer masks with record l-1 (output of layer l-1)
+        MaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
         stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), dy, none, ep);
         advance();
     }
@@ -184,14 +197,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         stream_layer<32, 0, 2, 10>(pw, wp + bwd_pack_off(4) / 4 + 8 * 64, dy, none, ep);
     }
     {
-        MaskEpilogue<8> ep{swin(save_h(4)), nxt, gwin(3 * 256), valid};
+        mk_cur = mk_nxt; mk_nxt = mask_rec(2);
+        MaskEpilogue<8> ep{mk_cur, nxt, gwin(3 * 256)};
         stream_layer<32, 0, 8, 10>(pw, wp + bwd_pack_off(4) / 4, dy, none, ep);
         advance();
     }
     // ---- layers 3, 2, 1 transposed: produce dY2, dY1, dY0
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
-        MaskEpilogue<8> ep{swin(save_h(l)), nxt, gwin((l - 1) * 256), valid};
+        mk_cur = mk_nxt; mk_nxt = mask_rec(l >= 2 ? l - 2 : 0);
+        MaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
         stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), dy, none, ep);
         advance();
     }

@@ -139,6 +139,9 @@ struct FwdEpilogue {
     float (&out)[16 * NBOUT];
     RowWindow win;                       // where the layer's output rows live in the activation workspace
     float sig_raw;                       // kernel row 256 of layer 7 (row block NBOUT, register 0, half 0)
+    const char* mrec = nullptr;          // this wave's ReLU sign-mask record of the layer (wave-uniform; training only)
+    int lane = 0;
+    unsigned mbits[4] = {0u, 0u, 0u, 0u};   // this lane's sign bits: dword nb/2, bit 31 - (16*(nb&1) + r)  (pushed LSB-first)
 
     __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
 #pragma unroll
@@ -152,6 +155,14 @@ struct FwdEpilogue {
             const float v = RELU ? fmaxf(a + p, 0.f) : a + p;
             out[nb * 16 + r] = v;
             if (SAVE) buf_store1(v, win.rsrc(nb * 32), win.voff4, reg_row(r) * win.pitch4);
+            if (SAVE && RELU) {
+                // v = max(x, 0): v > 0  <=>  its bit pattern, as a signed integer, is >= 1 (-0.0 and +0.0 give 0): med3 + shift-or
+                mbits[nb >> 1] = (mbits[nb >> 1] << 1) | (unsigned)min(max(__builtin_bit_cast(int, v), 0), 1);
+                if (nb == NBOUT - 1 && r == 15) {     // one coalesced 16 B/lane store per layer: the wave's 1 KiB record
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{mbits[0], mbits[1], mbits[2], mbits[3]}, make_rsrc(mrec), lane * 16, 0, 0);
+                }
+            }
         } else if (r == 0) {
             sig_raw = a + p;
         }
@@ -221,6 +232,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const PackedWeights pw = packed_weights(a.packed, lane);
     const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)((4ll * h * a.Mpad + m) * 4), hoff = h * 64;
     auto window = [&](int r) { return RowWindow{SAVE ? a.save + (long long)r * a.Mpad : nullptr, pitch4, voff4}; };
+    // ReLU sign-mask records of this wave (niw_common.h kSaveMask): record i = output of layer i (0..6), 7 = feat, 8 = hr
+    const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    auto mask_rec = [&](int i) {
+        return SAVE ? reinterpret_cast<const char*>(a.save + (long long)kSaveMask * a.Mpad) + (wave_id * kMaskRecords + i) * kMaskRecBytes : nullptr;
+    };
     if (SAVE) {
         const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
 #pragma unroll
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NIW_STAMP(0);
     // ---- layer 0: 63 -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, window(save_h(1)), 0.f};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, window(save_h(1)), 0.f, mask_rec(0), lane};
         stream_layer<8, 0, 8, 8>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep);
         advance();
         NIW_STAMP(1);
@@ -248,14 +264,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- layers 1..3
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, window(save_h(l + 1)), 0.f};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
         stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, l == 2 ? 12 : -1);
         advance();
         NIW_STAMP(1 + l);
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, window(save_h(5)), 0.f};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, window(save_h(5)), 0.f, mask_rec(4), lane};
         stream_layer<32, 8, 8, 8>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep);
         advance();
         NIW_STAMP(5);
@@ -263,14 +279,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- layers 5, 6
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, window(save_h(l + 1)), 0.f};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
         stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep);
         advance();
         NIW_STAMP(1 + l);
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(7), hoff, nxt, window(kSaveFeat), 0.f};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(7), hoff, nxt, window(kSaveFeat), 0.f, mask_rec(7), lane};
         stream_layer<32, 0, 9, 9>(pw, wp + fwd_pack_off(7) / 4, act, none, ep);
         advance();
         NIW_STAMP(8);
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
     float hr[64];
     {
-        FwdEpilogue<4, true, SAVE> ep{pw, 4 * bias_pack_off(8), hoff, hr, window(kSaveHr), 0.f};
+        FwdEpilogue<4, true, SAVE> ep{pw, 4 * bias_pack_off(8), hoff, hr, window(kSaveHr), 0.f, mask_rec(8), lane};
         stream_layer<32, 4, 4, 4>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep);
         NIW_STAMP(9);
     }

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 NERF_PARAM_FLOATS = 530052
-SAVE_ROWS = 2274
+SAVE_ROWS = 2346
 GRAD_ROWS = 2336
 L3D, LVIEW = 10, 4
 ACT = {"relu": 0, "softplus": 1}
