@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libniw_hip.so")
+LIB_PATH = os.environ.get("NIW_LIB_PATH") or os.path.join(_HERE, "libniw_hip.so")   # override: diagnostic builds (tools/)
 
 _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 

@@ -7,6 +7,15 @@
 #define NIW_RING_DEPTH 8
 #endif
 
+// cache policy of the streaming workspace stores (aux of raw_buffer_store: 0 = default, 2 = nt, 16 = sc1).
+// Measured on MI355X, cfg2 step: nt -2 % on the forward and the dX chain (their stores are read again only by the
+// dW pass, gigabytes later); sc1 / sc1+nt no better.  (Also measured: a quad-row workspace layout with 16-byte
+// stores, 4x fewer store instructions for the same bytes, gained 2.4 % on the forward -- the cost of the saves is
+// their bytes, not their instruction count: 119-124 TFLOP/s with them, 140 without.)
+#ifndef NIW_STORE_AUX
+#define NIW_STORE_AUX 2
+#endif
+
 #ifdef NIW_STAMPS
 extern __device__ unsigned long long niw_stamps[8192 * 16];
 #endif
@@ -35,7 +44,7 @@ __device__ __forceinline__ float buf_load1(rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ void buf_store1(float v, rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, NIW_STORE_AUX);
 }
 
 // The packed-weight image of one network (niw_mlp_pack_weights) as seen by a wave.
