@@ -10,11 +10,14 @@ _ARCH = dict(layers_feat=[None, 256, 256, 256, 256, 256, 256, 256, 256], layers_
              posenc=dict(L_3D=10, L_view=4), density_activ="softplus", tf_init=True)
 
 _BASE = dict(
-    model=None, seed=0, device="cuda:0", H=300, W=400, max_iter=200000, barf_c2f=None,
+    model=None, seed=0, device="cuda:0", gpu=0, cpu=False, H=300, W=400, max_iter=200000, barf_c2f=None,
+    group="0_test", name="debug", output_root="output", resume=False, load=None, batch_size=None,
+    freq=dict(scalar=200, vis=1000, val=2000, ckpt=5000),
     arch=_ARCH,
     nerf=dict(view_dep=True, depth=dict(param="inverse", range=[1, 0]), sample_intvs=128, sample_stratified=True,
               fine_sampling=False, sample_intvs_fine=None, rand_rays=2048, density_noise_reg=None, setbg_opaque=None),
-    data=dict(dataset="llff", scene="fern", image_size=[300, 400], bgcolor=None),
+    data=dict(dataset="llff", root=None, scene="fern", image_size=[300, 400], bgcolor=None, center_crop=None, val_ratio=0.1,
+              train_sub=None, val_sub=None, val_on_test=False),
     camera=dict(model="perspective", ndc=False),
     loss_weight=dict(render=0, render_fine=None, global_alignment=None),
     optim=dict(algo="Adam", lr=1e-3, lr_end=1e-4, lr_pose=5e-4, lr_pose_end=1e-8, test_photo=True, test_iter=100),
@@ -70,3 +73,8 @@ def cfg5_barf_inn_dtu(device="cuda:0"):
                data=dict(dataset="dtu", scene="scan65"),
                pose=dict(parameterization="inn", init="noisy_gt", noise=0.15, n_first_fixed_poses=0),
                loss_weight=dict(render=0, global_alignment=3))
+
+
+# yaml name (the reference's --yaml argument) -> builder, for options.set() when no yaml directory is given
+BY_YAML = dict(nerf_llff_repr=cfg1_nerf_llff_repr, nerf_inn_llff=cfg2_nerf_inn_llff_hier, barf_inn_llff=cfg3_barf_inn_llff,
+               barf_inn_dtu=cfg5_barf_inn_dtu)

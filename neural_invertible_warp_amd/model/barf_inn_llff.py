@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from .. import camera
+from ..util import edict
 from . import nerf_inn_llff
 from .nvp import nvp_ndr
 
@@ -95,3 +96,128 @@ class Graph(nerf_inn_llff.Graph):
                 pose = camera.pose.compose([var.pose_refine_test, pose])
             return pose
         return var.pose
+
+
+class Model:
+    """The reference's engine interface for this model (`train.py:21-32` drives it by name: Model(opt);
+    load_dataset; build_networks; setup_optimizer; restore_checkpoint; setup_visualizer; train), reduced to what
+    touches the render path: data to device, graph + warp modules, fused Adam / schedules (engine.INNTrainer),
+    checkpoints in the reference's wire format, pose / view-synthesis evaluation (evaluation.LLFFEvaluator).
+    Logging back-ends (tensorboard, visdom) are outside the path: `log_scalars` prints."""
+
+    def __init__(self, opt):
+        import os
+        self.opt = opt
+        os.makedirs(opt.output_path, exist_ok=True)
+        self.it = self.iter_start = 0
+
+    # ---- reference model/base.py:24-33 / nerf_inn_llff.py:22-32
+    def load_dataset(self, opt, eval_split="val"):
+        import importlib
+        import os
+        name = opt.data.dataset
+        root = opt.data.get("root") or "data/{}".format(name)
+        if name != "synthetic" and not os.path.isdir("{}/{}".format(root, opt.data.scene)):
+            print("[niw] dataset {}/{} not found: using the procedural scene".format(root, opt.data.scene))
+            name = "synthetic"
+        data = importlib.import_module("neural_invertible_warp_amd.data.{}".format(name))
+        if opt.data.get("val_on_test"):
+            eval_split = "test"
+        self.train_data = data.Dataset(opt, split="train", subset=opt.data.get("train_sub"))
+        self.test_data = data.Dataset(opt, split=eval_split, subset=opt.data.get("val_sub"))
+        for d in (self.train_data, self.test_data):
+            d.prefetch_all_data(opt)
+            d.all = edict({k: v.to(opt.device) for k, v in d.all.items()})
+
+    # ---- barf_inn_llff.py:41-75 (+ setup_optimizer :84-104: the trainer owns the flat Adam state and the schedules)
+    def build_networks(self, opt):
+        from .. import engine, parallel
+        rank, world, _ = parallel.init_from_env()
+        self.trainer = engine.INNTrainer(opt, len(self.train_data), rank=rank, world=world, seed=opt.seed or 0)
+        self.graph = self.trainer.graph
+
+    def setup_optimizer(self, opt):
+        assert hasattr(self, "trainer"), "build_networks first"
+
+    def restore_checkpoint(self, opt):
+        from .. import checkpoint
+        ep = it = None
+        if opt.resume:
+            ep, it = checkpoint.restore_checkpoint(opt, self.trainer, resume=opt.resume)
+        elif opt.load is not None:
+            ep, it = checkpoint.restore_checkpoint(opt, self.trainer, load_name=opt.load)
+        self.epoch_start, self.iter_start = ep or 0, it or 0
+
+    def setup_visualizer(self, opt):
+        pass
+
+    # ---- nerf_inn_llff.py:49-100, barf_inn_llff.py:106-120
+    def train(self, opt):
+        self.graph.train()
+        var = self.train_data.all
+        self.it = self.iter_start
+        if self.iter_start == 0:
+            self.validate(opt, 0)
+        while self.it < opt.max_iter:
+            loss = self.train_iteration(opt, var, None)
+            if self.it % opt.freq.scalar == 0:
+                self.log_scalars(opt, var, loss, step=self.it, split="train")
+            if self.it % opt.freq.val == 0:
+                self.validate(opt, self.it)
+            if self.it % opt.freq.ckpt == 0:
+                self.save_checkpoint(opt, ep=None, it=self.it)
+        return self
+
+    def train_iteration(self, opt, var, loader=None):
+        loss = self.trainer.train_iteration(edict(var))
+        self.it = self.trainer.it
+        return loss
+
+    def summarize_loss(self, opt, var, loss):
+        return self.trainer.summarize_loss(loss)
+
+    def log_scalars(self, opt, var, loss, metric=None, step=0, split="train"):
+        msg = " ".join("{}={:.5f}".format(k, float(torch.as_tensor(v).detach())) for k, v in loss.items())
+        print("[{} it {}] {}".format(split, step, msg), flush=True)
+
+    def _evaluator(self, opt):
+        from .. import evaluation
+        return evaluation.LLFFEvaluator(opt, self.graph, self.train_data.get_all_camera_poses(opt).to(opt.device))
+
+    @torch.no_grad()
+    def validate(self, opt, ep=None):
+        """pose errors after the Procrustes pre-alignment + PSNR of the held-out views rendered from their
+        aligned ground-truth poses (nerf_inn_llff.py:130-160, barf_inn_llff.py:122-145)"""
+        self.graph.eval()
+        ev = self._evaluator(opt)
+        pose, pose_GT = ev.get_all_training_poses(opt)
+        pose_aligned, self.graph.sim3 = ev.prealign_cameras(opt, pose, pose_GT)
+        error = ev.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
+        psnr = []
+        allv = self.test_data.all
+        for i in range(len(self.test_data)):
+            var = edict({k: v[i:i + 1] for k, v in allv.items()})
+            var = self.graph.forward(opt, var, mode="val")
+            rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+            psnr.append(-10 * self.graph.MSE_loss(rgb_map, var.image).log10().item())
+        self.graph.train()
+        out = edict(error_R=float(error.R.mean()), error_t=float(error.t.mean()), psnr=sum(psnr) / max(len(psnr), 1))
+        print("[val it {}] rot {:.4f} rad  trans {:.5f}  PSNR {:.2f}".format(ep, out.error_R, out.error_t, out.psnr), flush=True)
+        return out
+
+    def evaluate_full(self, opt):
+        allv = self.test_data.all
+        views = [edict({k: v[i:i + 1] for k, v in allv.items()}) for i in range(len(self.test_data))]
+        out = self._evaluator(opt).evaluate_full(opt, views)
+        with open("{}/quant_pose.txt".format(opt.output_path), "w") as f:
+            for i, (err_R, err_t) in enumerate(zip(out.error.R, out.error.t)):
+                f.write("{} {} {}\n".format(i, err_R.item(), err_t.item()))
+        with open("{}/quant.txt".format(opt.output_path), "w") as f:
+            for i, r in enumerate(out.res):
+                f.write("{} {} {}\n".format(i, r.psnr, r.ssim))
+        return out
+
+    def save_checkpoint(self, opt, ep=0, it=0, latest=False):
+        from .. import checkpoint
+        if self.trainer.rank == 0:
+            checkpoint.save_checkpoint(opt, self.trainer, ep=ep, it=it, latest=latest)

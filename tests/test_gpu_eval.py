@@ -175,3 +175,25 @@ def test_checkpoint_resume_continues_bit_exactly(tmp_path):
         assert torch.equal(a, b), k
     for i in range(len(tr.m)):
         assert torch.equal(tr.m[i], tr2.m[i]) and torch.equal(tr.v[i], tr2.v[i])
+
+
+def test_train_entry_point_runs_resumes_and_evaluates(tmp_path, capsys):
+    """The reference's command line / Model call sequence (train.py:9-32) on the procedural scene: trains, validates
+    (pose alignment + held-out PSNR), writes model.ckpt in the reference's layout, resumes from it, evaluates."""
+    import os
+    from neural_invertible_warp_amd import train
+    args = ["--model=barf_inn_llff", "--yaml=barf_inn_llff", "--barf_c2f=[0.1,0.5]", "--loss_weight.global_alignment=2",
+            "--data.dataset=synthetic", "--data.image_size=[24,32]", "--nerf.rand_rays=288", "--nerf.sample_intvs=32",
+            "--freq.val=3", "--freq.ckpt=3", "--freq.scalar=2", f"--output_root={tmp_path}", "--name=t"]
+    m = train.main(args + ["--max_iter=6"])
+    out = capsys.readouterr().out
+    assert "[val it 3]" in out and "[val it 6]" in out and "[train it 2]" in out
+    path = m.opt.output_path
+    assert os.path.exists(f"{path}/model.ckpt") and os.path.exists(f"{path}/model/3.ckpt") and os.path.exists(f"{path}/model/6.ckpt")
+    ck = torch.load(f"{path}/model.ckpt", weights_only=False)
+    assert ck["iter"] == 6 and "warp_mlp.lin0_a_0.weight_g" in ck["graph"] and "optim_pose" in ck
+    m2 = train.main(args + ["--max_iter=8", "--resume"])
+    assert m2.iter_start == 6 and m2.it == 8
+    res = m2.evaluate_full(m2.opt)
+    assert len(res.res) == len(m2.test_data) and all(r.psnr > 0 for r in res.res)
+    assert os.path.exists(f"{path}/quant.txt") and os.path.exists(f"{path}/quant_pose.txt")
