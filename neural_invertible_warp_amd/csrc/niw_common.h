@@ -134,6 +134,24 @@ constexpr int kGradY7 = 7 * 256, kGradRgb0 = kGradY7 + 288, kGradRgb1 = kGradRgb
 constexpr int kGradStashEnc = kGradRgb1 + 32, kGradStashVenc = kGradStashEnc + 64;
 static_assert(kGradStashVenc + 32 == NIW_GRAD_ROWS, "grad rows");
 
+// Separately rounded fp32 multiply / add / divide, for arithmetic the reference performs as separate tensor ops.
+// hipcc compiles with -ffp-contract=fast and HIP's __fmul_rn / __fadd_rn are plain `*` / `+` in a header, so
+// __fadd_rn(c, __fmul_rn(a, b)) is emitted as ONE v_fma_f32 (single rounding) -- a 1-ulp difference in a sample
+// position that the 2^9*pi encoding band multiplies by 1.6e3.  Without the `contract` flag on these
+// instructions LLVM cannot fuse them, also after inlining.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

@@ -158,6 +158,9 @@ extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const flo
                                  float* rgb, float* depth, float* opacity, float* prob, niw_stream_t stream) {
     NIW_REQUIRE(ray && rgb_s && sigma_s && depth_s && rgb && depth && opacity, "niw_composite_fwd: null pointer");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_composite_fwd: empty input (n_rays=%lld, S=%d)", (long long)n_rays, n_samples);
+    // reference nerf.py:461-462 builds the closing 1e10 interval with empty_like(intervals[..., :1]): with a single sample
+    // that slice is empty, the sample gets NO interval and every output is zero with an empty prob -- not reproduced
+    NIW_REQUIRE(n_samples >= 2, "niw_composite_fwd: needs at least 2 samples per ray (the reference degenerates to all-zero outputs at S=1)");
     const int blocks = (int)((n_rays + 3) / 4);
     composite_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(ray, rgb_s, sigma_s, depth_s, n_rays, n_samples, has_bg, bg,
                                                                  rgb, depth, opacity, prob);
@@ -170,7 +173,7 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
                                  const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_prob,
                                  float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream) {
     NIW_REQUIRE(ray && rgb_s && sigma_s && depth_s && d_rgb_s && d_sigma_s && d_ray, "niw_composite_bwd: null pointer");
-    NIW_REQUIRE(n_rays > 0 && n_samples > 0 && n_samples <= 1024, "niw_composite_bwd: need 0 < S <= 1024 (S=%d)", n_samples);
+    NIW_REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= 1024, "niw_composite_bwd: need 2 <= S <= 1024 (S=%d)", n_samples);
     const int blocks = (int)((n_rays + 3) / 4);
     composite_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(ray, rgb_s, sigma_s, depth_s, n_rays, n_samples, has_bg, bg,
                                                                  d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray);

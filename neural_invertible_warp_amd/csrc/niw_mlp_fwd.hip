@@ -103,7 +103,7 @@ template <int L, int NQ>
 __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* __restrict__ w, int h, float (&enc)[4 * NQ]) {
     double rev[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rev[c] = (double)__fmul_rn(p[c], 3.14159274101257324f) * 0.15915494309189533577;
+    for (int c = 0; c < 3; ++c) rev[c] = (double)mul_rn(p[c], 3.14159274101257324f) * 0.15915494309189533577;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         // combo g = 2q + h; g == 0: raw coordinates; else pairs 2(g-1), 2(g-1)+1
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     {
         const float d = a.depth[mc];
         const float rx = a.ray[ri * 3 + 0], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];
-        p[0] = __fadd_rn(a.center[ri * 3 + 0], __fmul_rn(rx, d));
-        p[1] = __fadd_rn(a.center[ri * 3 + 1], __fmul_rn(ry, d));
-        p[2] = __fadd_rn(a.center[ri * 3 + 2], __fmul_rn(rz, d));
+        p[0] = add_rn(a.center[ri * 3 + 0], mul_rn(rx, d));
+        p[1] = add_rn(a.center[ri * 3 + 1], mul_rn(ry, d));
+        p[2] = add_rn(a.center[ri * 3 + 2], mul_rn(rz, d));
         const float nrm = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
         u[0] = rx / nrm; u[1] = ry / nrm; u[2] = rz / nrm;
     }

@@ -13,8 +13,8 @@ __global__ void sample_stratified_kernel(const float* __restrict__ u, long long 
     const int s = (int)(i % S);
     const float r = (u ? u[i] : 0.5f) + (float)s;
     // rand_samples / S * (max - min) + min, each op rounded on its own
-    float d = __fadd_rn(__fmul_rn(__fdiv_rn(r, (float)S), dmax - dmin), dmin);
-    if (inverse) d = __fdiv_rn(1.f, __fadd_rn(d, 1e-8f));
+    float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)S), dmax - dmin), dmin);
+    if (inverse) d = __fdiv_rn(1.f, niw::add_rn(d, 1e-8f));
     depth[i] = d;
 }
 
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(const float* __re
         }
         const int il = max(lo - 1, 0), ih = min(lo, S);
         const float cl = cdf[il], ch = cdf[ih], dl = bins[il], dh = bins[ih];
-        const float t = __fdiv_rn(uu - cl, __fadd_rn(ch - cl, 1e-8f));
-        const float d = __fadd_rn(dl, __fmul_rn(t, dh - dl));
+        const float t = __fdiv_rn(uu - cl, niw::add_rn(ch - cl, 1e-8f));
+        const float d = niw::add_rn(dl, niw::mul_rn(t, dh - dl));
         val[S + jf] = d;
         if (fine_out) fine_out[r * Sf + jf] = d;
     }

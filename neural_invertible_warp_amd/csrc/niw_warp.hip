@@ -74,7 +74,7 @@ __device__ __forceinline__ void embed(const float (&x)[D], const float* __restri
 #pragma unroll
         for (int dd = 1; dd < D; ++dd) xv = d == dd ? x[dd] : xv;
         sl[t] = cl[t] = 0.f;
-        if (n < N) sincosf(__fmul_rn(xv, kPi32 * (float)(1 << i)), &sl[t], &cl[t]);
+        if (n < N) sincosf(niw::mul_rn(xv, kPi32 * (float)(1 << i)), &sl[t], &cl[t]);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) e[d] = ps * x[d];

@@ -62,3 +62,44 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.NiwError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
+    """Error behaviour of the boundary: status code < 0, message in niw_last_error_string, no exception,
+    no launch.  Dummy non-null pointers are never dereferenced because the host-side checks fail first."""
+    import ctypes
+    from neural_invertible_warp_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    err = lambda: lib.niw_last_error_string().decode()
+    # null pointers
+    cases = {
+        "niw_mlp_pack_weights": (None, None, None),
+        "niw_mlp_fwd": (None,) * 6 + (4, 8, None, None, 1, None, None, None, None),
+        "niw_mlp_bwd_dx": (None,) * 4 + (4, 8, 1) + (None,) * 8,
+        "niw_mlp_bwd_dw": (None, None, 4, 8, None, None, None),
+        "niw_composite_bwd": (None,) * 4 + (4, 8, 0, 0.0) + (None,) * 8,
+        "niw_sample_stratified": (None, 4, 8, 0.0, 1.0, 0, None, None),
+        "niw_raygen": (None, None, None, 2, 4, 8, 8, 0, None, None, None),
+        "niw_convert_ndc": (None, None, None, 2, 4, 1.0, None, None, None),
+        "niw_warp_fwd": (None,) * 4 + (2, 4, None, None, None, 0, None, None),
+        "niw_warp_prep_fwd": (None, None, 2, None, None, None, None, None),
+        "niw_warp_prep_bwd": (None, None, 2) + (None,) * 7,
+        "niw_mse_fwd_bwd": (None, None, None, 2, 4, 64, 1.0, 1.0, None, None, None),
+        "niw_adam_step": (None,) * 4 + (8, 1e-3, 0.9, 0.999, 1e-8, 1, None),
+    }
+    for name, args in cases.items():
+        assert len(args) == len(_lib.SIGNATURES[name][1]), name
+        rc = getattr(lib, name)(*args)
+        assert rc == -1 and err(), (name, rc, err())
+    # sizes / enums (pointers non-null)
+    assert lib.niw_mlp_fwd(p, p, p, p, p, None, 0, 8, None, None, 1, p, p, None, None) == -1 and "positive" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, p, None, 4, 8, None, None, 7, p, p, None, None) == -1 and "activation" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, p, None, 1 << 20, 64, None, None, 1, p, p, None, None) == -1 and "too many samples" in err()
+    assert lib.niw_warp_prep_fwd(p, p, 65, p, p, p, p, None) == -1 and "views" in err()
+    assert lib.niw_warp_prep_fwd(p, p, 0, p, p, p, p, None) == -1
+    # workspace queries are pure host arithmetic
+    assert lib.niw_warp_prep_fwd_workspace_floats(18) == 3 * 18 * 128
+    assert lib.niw_mlp_bwd_workspace_floats(4, 8) == 512 * (256 * 256 + 256)
+    assert lib.niw_mlp_packed_floats() > 2 * 527872

@@ -1,0 +1,140 @@
+"""Edge cases of the HIP path against the oracle: degenerate sizes (one ray, one sample, one point, one view), sizes
+that are no multiple of any tile, the 64-view limit, empty / uniform pdfs, inverse-depth extremes, and the error
+behaviour of the reference-style classes.  Same tolerances as test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import niw_oracle as O
+from tests.test_gpu_parity import DEV, close, g, load_nerf, relclose
+from tests.util import t
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(seed):
+    from neural_invertible_warp_amd import ops
+    p = O.make_nerf_params(seed)
+    names = [f"{n}.{k}" for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]
+    flat = torch.cat([p[n].reshape(-1) for n in names]).to(DEV)
+    params, off = [], 0
+    for n in names:
+        params.append(flat[off:off + p[n].numel()].view(p[n].shape).requires_grad_(True))
+        off += p[n].numel()
+    return p, names, ops.FieldState(flat), params
+
+
+@pytest.mark.parametrize("N,S", [(1, 1), (1, 33), (3, 5), (129, 1)])
+def test_mlp_degenerate_shapes_forward_and_backward(N, S):
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(N * 100 + S)
+    p, names, st, params = _field(8)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    center, ray = t(rng.uniform(-1, 1, (N, 3))).requires_grad_(True), t(rng.standard_normal((N, 3))).requires_grad_(True)
+    depth = t(np.sort(rng.uniform(0.5, 4, (N, S)), axis=1))
+    ones3, ones4 = [1.0] * 10, [1.0] * 4
+    rgb_ref, sig_ref = O.forward_samples(pr, center[None], ray[None], depth[None, :, :, None], density_activ="softplus")
+    (rgb_ref.sum() + 2 * sig_ref.sum()).backward()
+    c2, r2 = g(center.detach()).requires_grad_(True), g(ray.detach()).requires_grad_(True)
+    rgb, sig = ops.field_mlp(st, params, c2, r2, g(depth), ones3, ones4, "softplus")
+    assert rgb.shape == (N, S, 3) and sig.shape == (N, S)
+    close(rgb, rgb_ref[0]); close(sig, sig_ref[0], atol=5e-5, rtol=2e-4)
+    (rgb.sum() + 2 * sig.sum()).backward()
+    for n, prm in zip(names, params):
+        relclose(prm.grad, pr[n].grad, 5e-3)
+    relclose(c2.grad, center.grad, 5e-3); relclose(r2.grad, ray.grad, 5e-3)
+
+
+def test_mlp_inverse_depth_extremes_stay_finite_and_match():
+    """inverse-depth sampling reaches 1/(0+1e-8) = 1e8 (nerf.py:343): the band arguments are ~1e11 rad"""
+    from neural_invertible_warp_amd import ops
+    p, names, st, _ = _field(9)
+    center, ray = torch.tensor([[0.1, -0.2, 0.3]]), torch.tensor([[0.3, 0.2, 0.9]])
+    depth = torch.tensor([[1.0, 7.5, 3.2e3, 4.0e5, 1.0e8]])
+    rgb_ref, sig_ref = O.forward_samples(p, center[None], ray[None], depth[None, :, :, None], density_activ="softplus")
+    with torch.no_grad():
+        rgb, sig = ops.field_mlp(st, [], g(center), g(ray), g(depth), [1.0] * 10, [1.0] * 4, "softplus")
+    assert torch.isfinite(rgb).all() and torch.isfinite(sig).all()
+    # up to 3.2e3 the fp32 argument x*2^9*pi is still resolved to ~0.1 rad or better on both sides
+    close(rgb[:, :2], rgb_ref[0][:, :2]); close(sig[:, :2], sig_ref[0][:, :2], atol=5e-5, rtol=2e-4)
+
+
+def test_composite_single_sample_is_rejected():
+    """reference nerf.py:461-462: the closing 1e10 interval is empty_like(intervals[..., :1]); with S = 1 that slice is
+    empty, so the reference returns all-zero outputs and an EMPTY prob.  The boundary refuses S = 1 instead."""
+    from neural_invertible_warp_amd import ops
+    from neural_invertible_warp_amd._lib import NiwError
+    ref = O.composite(torch.randn(1, 2, 3), torch.rand(1, 2, 1, 3), torch.rand(1, 2, 1), torch.rand(1, 2, 1, 1))
+    assert ref[3].numel() == 0 and float(ref[0].abs().max()) == 0.0
+    with pytest.raises(NiwError, match="at least 2 samples"):
+        ops.composite(torch.randn(2, 3, device=DEV), torch.rand(2, 1, 3, device=DEV), torch.rand(2, 1, device=DEV), torch.rand(2, 1, device=DEV))
+
+
+@pytest.mark.parametrize("S", [2, 3, 65])
+def test_composite_tiny_and_chunk_boundary(S):
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(S)
+    N = 5
+    ray, rgb_s = t(rng.standard_normal((1, N, 3))), t(rng.uniform(0, 1, (1, N, S, 3)))
+    sig, dep = t(rng.uniform(0, 3, (1, N, S))), t(np.sort(rng.uniform(0.5, 6, (1, N, S, 1)), axis=2))
+    ref = O.composite(ray, rgb_s, sig, dep)
+    out = ops.composite(g(ray[0]), g(rgb_s[0]), g(sig[0]), g(dep[0, :, :, 0]))
+    close(out[0], ref[0][0]); close(out[1], ref[1][0, :, 0], atol=1e-4); close(out[2], ref[2][0, :, 0]); close(out[3], ref[3][0, :, :, 0])
+
+
+def test_pdf_resampling_zero_and_uniform_pdf():
+    """zero pdf: every quantile lies beyond the cdf -> all fine samples clamp to the far bound; uniform pdf: the
+    mid-point quantiles land on the bin centres' lerp (reference nerf.py:346-365)"""
+    from neural_invertible_warp_amd import ops
+    S, Sf, rng_ = 16, 24, [1.0, 0.0]
+    for pdf in (torch.zeros(3, S), torch.full((3, S), 1.0 / S), torch.rand(3, S) * (torch.rand(3, S) > 0.5)):
+        coarse = O.sample_depth(0.5, S, rng_, "inverse")[0, :1].repeat(3, 1, 1, 1)[..., 0].reshape(3, S)
+        fine_ref = O.sample_depth_from_pdf(pdf[None], S, Sf, rng_)[0, :, :, 0]
+        fine, merged = ops.sample_pdf_merge(g(pdf), g(coarse), Sf, rng_)
+        close(fine, fine_ref, atol=1e-6)
+        assert (merged[:, 1:] >= merged[:, :-1]).all() and merged.shape == (3, S + Sf)
+        close(merged, torch.cat([coarse, fine_ref], 1).sort(dim=1).values, atol=1e-6)
+    fine0, _ = ops.sample_pdf_merge(g(torch.zeros(2, S)), g(coarse[:2]), Sf, rng_)
+    assert (fine0 == rng_[1]).all()
+
+
+def _warp_net(exact=True):
+    from neural_invertible_warp_amd.model.nvp import nvp_ndr
+    net = nvp_ndr.DeformNetwork(d_feature=128, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3, d_hidden=128, n_layers=1, skip_in=[],
+                                multires=6, weight_norm=True, actfn="softplus", reference_exact=exact).to(DEV)
+    wp = O.make_warp_params(77, 0.02)
+    load_nerf(net, wp)
+    return net, wp
+
+
+@pytest.mark.parametrize("B,P", [(1, 1), (2, 17), (5, 3)])
+def test_warp_tiny_point_sets(B, P):
+    net, wp = _warp_net()
+    code, pts = O.make_latent(5, B), torch.randn(B, P, 1, 3, generator=torch.Generator().manual_seed(P))
+    cg = g(code).requires_grad_(True)
+    y = net.forward(cg, g(pts), alpha_ratio=0.6)
+    p64 = {k: v.double().requires_grad_(True) for k, v in wp.items()}
+    c64 = code.double().requires_grad_(True)
+    y64 = O.warp_forward(p64, c64, pts.double(), 0.6, reference_exact=True)
+    close(y, y64.float(), atol=1e-4)
+    y.sum().backward(); y64.sum().backward()
+    for k, prm in net.named_parameters():
+        relclose(prm.grad, p64[k].grad.float(), 1e-2)
+    relclose(cg.grad, c64.grad.float(), 1e-2)
+    close(net.inverse(cg.detach(), y.detach(), 0.6), pts, atol=2e-4)
+
+
+def test_warp_view_limit_and_shape_errors():
+    from neural_invertible_warp_amd._lib import NiwError
+    net, _ = _warp_net(exact=False)
+    y = net.forward(torch.randn(64, 128, device=DEV) * 0.1, torch.randn(64, 8, 1, 3, device=DEV), alpha_ratio=1.0)      # the maximum
+    assert torch.isfinite(y).all() and y.shape == (64, 8, 1, 3)
+    with pytest.raises(NiwError, match="views"):
+        net.forward(torch.randn(65, 128, device=DEV), torch.randn(65, 8, 1, 3, device=DEV), alpha_ratio=1.0)
+    with pytest.raises(NiwError, match="input_pts"):
+        net.forward(torch.randn(2, 128, device=DEV), torch.randn(2, 8, 3, device=DEV), alpha_ratio=1.0)
+    with pytest.raises(NiwError, match="deformation_code"):
+        net.forward(torch.randn(3, 128, device=DEV), torch.randn(2, 8, 1, 3, device=DEV), alpha_ratio=1.0)
+    from neural_invertible_warp_amd.model.nvp import nvp_ndr
+    with pytest.raises(NiwError, match="configuration"):
+        nvp_ndr.DeformNetwork(d_feature=64, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3, d_hidden=128, n_layers=1, skip_in=[], multires=6)

@@ -251,18 +251,18 @@ def test_render_cfg1_golden():
     idx = g(torch.from_numpy(gd["ray_idx"]))
     with _capture_rng(g(t(gd["u"])), idx):
         ret = graph.render(opt, g(t(gd["pose"])), intr=g(t(gd["intr"])), ray_idx=idx, mode="train")
-    # end to end from poses: a 1-ulp difference in a generated ray (6e-8) is multiplied by the top
-    # encoding band 2^9*pi ~ 1.6e3 before the MLP, and the fine pass re-samples through the inverse
-    # CDF of the coarse weights -- hence 1e-4 here vs 2e-5 for the MLP on identical rays
+    # end to end from poses, all ten encoding bands on: holds at the MLP tolerance because sample positions are
+    # formed with the reference's two roundings (niw_common.h mul_rn / add_rn); a fused multiply-add there is a 1-ulp
+    # position difference that the 2^9*pi band multiplies by 1.6e3 (it cost a factor 20 in this comparison)
     for k in ("rgb", "depth", "opacity", "rgb_fine", "depth_fine", "opacity_fine"):
-        close(ret[k], gd[k], atol=1e-4, rtol=1e-3)
+        close(ret[k], gd[k])
     var = edict(idx=torch.arange(3), image=g(t(gd["image"])), ray_idx=idx)
     var.update(ret)
     loss = graph.compute_loss(opt, var, mode="train")
     close(loss.render, gd["loss_render"], atol=1e-6); close(loss.render_fine, gd["loss_render_fine"], atol=1e-6)
     (loss.render + loss.render_fine).backward()
     for k, prm in graph.named_parameters():
-        check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=2e-2)      # same amplification as the outputs above
+        check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=5e-3)
 
 
 def test_inn_train_step_dtu_golden():
@@ -285,7 +285,7 @@ def test_inn_train_step_dtu_golden():
         var = graph.forward(opt, var, mode="train", iter=int(gd["it"]))
     close(var.center_init, gd["center_init"], atol=2e-6); close(var.grid_init, gd["grid_init"], atol=2e-6)
     close(var.center_local, gd["center"], atol=2e-5); close(var.grid_local, gd["grid_3D"], atol=2e-5)
-    close(var.rgb, gd["rgb"], atol=5e-5, rtol=5e-4); close(var.opacity, gd["opacity"], atol=5e-5, rtol=5e-4)
+    close(var.rgb, gd["rgb"]); close(var.opacity, gd["opacity"])
     relclose(var.depth, gd["depth"], 2e-4)
     loss = graph.compute_loss(opt, var, mode="train")
     close(loss.render, gd["loss_render"], atol=1e-6)
