@@ -117,7 +117,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     const long long P = a.Mpad;
     const PackedWeights pw = packed_weights(a.packed, lane);
     const int pitch4 = (int)(P * 4), voff4 = (int)((4ll * h * P + m) * 4);
-    auto swin = [&](int r) { return RowWindow{a.save + (long long)r * P, pitch4, voff4}; };     // activation rows
     auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };     // gradient rows
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
     // ReLU sign-mask records of this wave: record i = output of layer i (0..6), 7 = feat, 8 = hr; each is loaded while

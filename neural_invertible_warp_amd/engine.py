@@ -13,16 +13,6 @@ from .model import barf_inn_llff
 from .util import edict
 
 
-def _flatten_params(params):
-    """Re-point the parameters at views of one contiguous buffer (values preserved)."""
-    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
-    off = 0
-    for p in params:
-        p.data = flat[off:off + p.numel()].view(p.shape)
-        off += p.numel()
-    return flat
-
-
 class INNTrainer:
     def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0):
         self.opt, self.rank, self.world = opt, rank, world

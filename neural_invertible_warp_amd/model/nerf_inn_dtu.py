@@ -5,7 +5,7 @@ sample_depth; the alignment loss uses the detached Kabsch pose kept by the pose 
 (:410-414); the inverse-CDF bins still use the yaml range (:549), as in the reference."""
 import torch
 
-from .. import camera, ops
+from .. import camera
 from ..util import edict
 from . import nerf, nerf_inn_llff
 

@@ -4,7 +4,7 @@ loss adds the Kabsch global-alignment term.
 """
 import torch
 
-from .. import camera, ops
+from .. import camera
 from ..util import edict
 from . import nerf
 

@@ -12,7 +12,6 @@ import math
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from ... import ops
 from ..._lib import NiwError
