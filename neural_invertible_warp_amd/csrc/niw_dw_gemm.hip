@@ -115,6 +115,10 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(NiwGemmOperand op
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[x][y] = mfma32(af[kb & 1][x][t], bf[kb & 1][y][t], acc[x][y]);
             __builtin_amdgcn_sched_barrier(0);
+            // the next slice goes to the OTHER LDS buffer (free since the barrier that ended the previous step): write it
+            // under the MFMAs of the last k-block instead of between the last MFMA and the barrier, where all eight waves
+            // would queue 64 KB of ds_write with the matrix pipe idle
+            if (kb == 2 && s + 1 < nsteps) lstore(buf ^ 1);
         }
         if (bias_side) {
             // row sums of the dY operand: thread t < rows sums its row of the staged slice
@@ -128,7 +132,6 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(NiwGemmOperand op
                 }
             }
         }
-        if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
     // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
