@@ -158,8 +158,10 @@ int niw_convert_ndc(const float* center, const float* ray, const float* intr, in
  *   w_emb   [3 blocks][ part a: 128x26 | part b: 128x13 ]   effective first-layer weights (embedding columns)
  *   view_b  [n_views][3][2][128]                            W[:,emb:] . code_b + bias   (per view)
  *   w_head  [3][ a: 1x128 + 1 | b: 3x128 + 3 ]              second-layer weights and biases
- * pts [n_views, n_pts, 3]; chan_w[6] per-band window, pt_scale [n_pts] per-point scale (the
- * dim-1 slicing of model/nvp/embedder.py:47) or NULL.
+ * pts [n_views, n_pts, 3]; chan_w[6] (host) per-band window or NULL; index_window[6] (host) or NULL: the
+ * reference's dim-1 slicing of model/nvp/embedder.py:47 on 4-D input -- window value i scales ALL
+ * channels of the points (2i+1)d .. (2i+3)d-1 (d = 2 for the 2-D embedding, 1 for the 1-D one), passed by value
+ * with the launch; pt_scale_a / pt_scale_b [n_pts] (device) optional additional per-point scales.
  * inverse != 0 evaluates .inverse.  xin_save [n_views,n_pts,3,3] (block inputs) may be NULL. */
 #define NIW_WARP_WEMB_FLOATS (3 * (128 * 26 + 128 * 13))
 #define NIW_WARP_WHEAD_FLOATS (3 * (128 + 1 + 3 * 128 + 3))
@@ -179,17 +181,25 @@ int niw_warp_prep_fwd(const float* params, const float* code, int n_views, float
 int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
                       const float* d_w_head, float* workspace, float* d_params, float* d_code, niw_stream_t stream);
 int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                 int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
-                 int inverse, float* out, niw_stream_t stream);
+                 int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* pt_scale_a,
+                 const float* pt_scale_b, int inverse, float* out, niw_stream_t stream);
 
 /* Backward of the forward warp.  d_out [n_views,n_pts,3] -> d_w_emb, d_view_b, d_w_head (same
  * shapes as the inputs, overwritten) and d_pts [n_views,n_pts,3] (may be NULL).
  * workspace: niw_warp_bwd_workspace_floats() floats of scratch.  n_views <= 64 per call. */
 int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts);
 int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                 int n_views, int64_t n_pts, const float* chan_w, const float* pt_scale_a, const float* pt_scale_b,
-                 const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                 int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* pt_scale_a,
+                 const float* pt_scale_b, const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
                  niw_stream_t stream);
+
+/* ------------------------------------------------------------------ global-alignment loss
+ * Rotation of the rigid registration (Kabsch with reflection fix) behind `roma.rigid_points_registration`
+ * (reference model/nerf_inn_llff.py:569, model/pose_models/inn.py:100): for n moment matrices M [n,3,3] = sum (y - ym)(x - xm)^T
+ * returns R [n,3,3] = U diag(1,1,det(U V^T)) V^T, plus what the backward needs: Us = U diag(1,1,d) [n,3,3], V [n,3,3],
+ * S [n,3] = (s0, s1, d s2).  Backward: dR [n,3,3] -> dM [n,3,3].  No host synchronisation. */
+int niw_kabsch_rotation_fwd(const float* M, int n, float* R, float* Us, float* V, float* S, niw_stream_t stream);
+int niw_kabsch_rotation_bwd(const float* Us, const float* V, const float* S, const float* dR, int n, float* dM, niw_stream_t stream);
 
 /* ------------------------------------------------------------------ loss and optimizer
  * Graph.compute_loss photometric part + MSE_loss (model/nerf_inn_llff.py:548-559,

@@ -30,13 +30,15 @@ SIGNATURES = {
     "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "niw_raygen": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "niw_convert_ndc": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
-    "niw_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp]),
+    "niw_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "niw_warp_bwd_workspace_floats": (_i64, [_i, _i64]),
-    "niw_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_warp_prep_fwd_workspace_floats": (_i64, [_i]),
     "niw_warp_prep_bwd_workspace_floats": (_i64, [_i]),
     "niw_warp_prep_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "niw_warp_prep_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_kabsch_rotation_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "niw_kabsch_rotation_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _d, _f, _vp, _vp, _vp]),
     "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
 }

@@ -25,7 +25,7 @@ class Graph(nerf_inn_llff.Graph):
     def forward(self, opt, var, mode=None, iter=None):
         """reference nerf_inn_dtu.py:371-396"""
         batch_size = len(var.idx)
-        depth_range = opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else [float(x) for x in var.depth_range[0]]
+        depth_range = opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else self._host_depth_range(var.depth_range)
         if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
             var.ray_idx = self.draw_ray_idx(opt, batch_size)
             ray, center, grid_3d = self.get_pose(opt, var, mode=mode, iter=iter)
@@ -37,6 +37,14 @@ class Graph(nerf_inn_llff.Graph):
                 self.render(opt, pose_w2c, intr=var.intr, mode=mode, depth_range=depth_range)
         var.update(ret)
         return var
+
+    def _host_depth_range(self, depth_range):
+        """var.depth_range[0] as two Python floats (the kernels take the range by value).  The device->host read is a
+        synchronisation point, so it is done once per tensor, not once per step (the range is a per-scene constant)."""
+        key = (depth_range.data_ptr(), depth_range._version)
+        if getattr(self, "_dr_key", None) != key:
+            self._dr_key, self._dr_val = key, [float(x) for x in depth_range[0]]
+        return self._dr_val
 
     def compute_loss(self, opt, var, mode=None):
         """reference nerf_inn_dtu.py:398-415"""

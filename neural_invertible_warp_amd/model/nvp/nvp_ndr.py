@@ -107,17 +107,12 @@ class DeformNetwork(torch.nn.Module):
         flat = self._ensure_flat()
         return ops.warp_prepare(flat, list(self.parameters()), code)
 
-    def _anneal(self, n_pts, alpha_ratio, device):
-        """-> (chan_w[6], pt_scale_a [P] | None, pt_scale_b [P] | None).  reference_exact: the
-        window multiplies whole points (2i+1)d..(2i+3)d-1 along dim 1 (embedder.py:47 on 4-D input)."""
+    def _anneal(self, alpha_ratio):
+        """-> (chan_w[6], index_window[6] | None).  reference_exact: the window multiplies whole points
+        (2i+1)d..(2i+3)d-1 along dim 1 (embedder.py:47 on 4-D input); the kernel derives the per-point scale from the
+        point index, so the six values travel by value with the launch."""
         w = anneal_window(alpha_ratio)
-        if not self.reference_exact:
-            return w, None, None
-        sa, sb = np.ones(n_pts, np.float32), np.ones(n_pts, np.float32)
-        for i in range(_NF):
-            sa[(2 * i + 1) * 2:(2 * i + 3) * 2] *= w[i]
-            sb[(2 * i + 1):(2 * i + 3)] *= w[i]
-        return [1.0] * _NF, torch.from_numpy(sa).to(device), torch.from_numpy(sb).to(device)
+        return ([1.0] * _NF, w) if self.reference_exact else (w, None)
 
     def _apply_warp(self, deformation_code, input_pts, alpha_ratio, inverse):
         if input_pts.dim() != 4 or input_pts.shape[2] != 1 or input_pts.shape[3] != 3:
@@ -126,8 +121,8 @@ class DeformNetwork(torch.nn.Module):
         if deformation_code.shape != (B, _LAT):
             raise NiwError(f"DeformNetwork: deformation_code must be [{B},{_LAT}], got {tuple(deformation_code.shape)}")
         w_emb, view_b, w_head = self._operands(deformation_code)
-        chan_w, ps_a, ps_b = self._anneal(P, float(alpha_ratio), input_pts.device)
-        out = ops.warp_points(w_emb, view_b, w_head, input_pts.reshape(B, P, 3), chan_w, ps_a, ps_b, inverse)
+        chan_w, index_window = self._anneal(float(alpha_ratio))
+        out = ops.warp_points(w_emb, view_b, w_head, input_pts.reshape(B, P, 3), chan_w, index_window, inverse=inverse)
         return out.view(B, P, 1, 3)
 
     def forward(self, deformation_code, input_pts, alpha_ratio=0):

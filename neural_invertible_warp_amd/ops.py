@@ -313,15 +313,16 @@ def composite(ray, rgb_s, sigma_s, depth_s, bg=None):
 
 class _Warp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w_emb, view_b, w_head, pts, chan_w, ps_a, ps_b, inverse):
+    def forward(ctx, w_emb, view_b, w_head, pts, chan_w, index_window, ps_a, ps_b, inverse):
         w_emb, view_b, w_head, pts = _f32(w_emb, "w_emb"), _f32(view_b, "view_b"), _f32(w_head, "w_head"), _f32(pts, "pts")
         B, P = pts.shape[0], pts.shape[1]
         out = torch.empty_like(pts)
         cw = _farr(chan_w, 6)
-        _lib.call("niw_warp_fwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, cw, _p(ps_a), _p(ps_b), 1 if inverse else 0,
+        iw = None if index_window is None else _farr(index_window, 6)       # by value with the launch: no H2D copy, no sync
+        _lib.call("niw_warp_fwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, cw, iw, _p(ps_a), _p(ps_b), 1 if inverse else 0,
                   _p(out), _stream())
         ctx.save_for_backward(w_emb, view_b, w_head, pts, ps_a, ps_b)
-        ctx.cw, ctx.inverse = cw, inverse
+        ctx.cw, ctx.iw, ctx.inverse = cw, iw, inverse
         return out
 
     @staticmethod
@@ -334,9 +335,9 @@ class _Warp(torch.autograd.Function):
         ws = torch.empty(lib.niw_warp_bwd_workspace_floats(B, P), device=pts.device, dtype=torch.float32)
         d_w_emb, d_view_b, d_w_head = torch.zeros_like(w_emb), torch.zeros_like(view_b), torch.zeros_like(w_head)
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[3] else None
-        _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, _p(ps_a), _p(ps_b),
+        _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, ctx.iw, _p(ps_a), _p(ps_b),
                   _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
-        return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None
+        return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None, None
 
 
 WARP_PARAM_FLOATS = 165900
@@ -389,9 +390,37 @@ def warp_prepare(flat, params, code):
     return _WarpPrep.apply(flat, code, *params)
 
 
-def warp_points(w_emb, view_b, w_head, pts, chan_w, ps_a=None, ps_b=None, inverse=False):
+def warp_points(w_emb, view_b, w_head, pts, chan_w, index_window=None, ps_a=None, ps_b=None, inverse=False):
     """pts [B,P,3] -> warped [B,P,3]; see include/niw.h niw_warp_fwd for the operand layout."""
-    return _Warp.apply(w_emb, view_b, w_head, pts, chan_w, ps_a, ps_b, inverse)
+    return _Warp.apply(w_emb, view_b, w_head, pts, chan_w, index_window, ps_a, ps_b, inverse)
+
+
+# ------------------------------------------------------------------------------------------
+# global-alignment loss: rotation of the rigid registration
+# ------------------------------------------------------------------------------------------
+
+class _KabschRotation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, M):
+        M = _f32(M, "M")
+        n = M.shape[0]
+        R, Us, V = torch.empty_like(M), torch.empty_like(M), torch.empty_like(M)
+        S = torch.empty(n, 3, device=M.device)
+        _lib.call("niw_kabsch_rotation_fwd", _p(M), n, _p(R), _p(Us), _p(V), _p(S), _stream())
+        ctx.save_for_backward(Us, V, S)
+        return R
+
+    @staticmethod
+    def backward(ctx, dR):
+        Us, V, S = ctx.saved_tensors
+        dM = torch.empty_like(Us)
+        _lib.call("niw_kabsch_rotation_bwd", _p(Us), _p(V), _p(S), _p(_f32(dR, "dR")), Us.shape[0], _p(dM), _stream())
+        return dM
+
+
+def kabsch_rotation(M):
+    """M [n,3,3] -> R [n,3,3] = U diag(1,1,det(UV^T)) V^T of M = U S V^T, differentiable, no host sync."""
+    return _KabschRotation.apply(M)
 
 
 # ------------------------------------------------------------------------------------------

@@ -138,3 +138,29 @@ def test_warp_view_limit_and_shape_errors():
     from neural_invertible_warp_amd.model.nvp import nvp_ndr
     with pytest.raises(NiwError, match="configuration"):
         nvp_ndr.DeformNetwork(d_feature=64, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3, d_hidden=128, n_layers=1, skip_in=[], multires=6)
+
+
+def test_kabsch_rotation_matches_svd_and_its_autograd():
+    """niw_kabsch_rotation_fwd/_bwd vs U diag(1,1,det) V^T from torch.linalg.svd (float64) incl. reflections, a rank-2 and a
+    near-degenerate matrix; gradient vs autograd through the float64 SVD."""
+    from neural_invertible_warp_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    M = torch.randn(40, 3, 3, generator=gen)
+    M[1] = torch.diag(torch.tensor([2.0, 1.0, -0.5]))                     # det < 0: reflection fix
+    M[2] = torch.outer(torch.tensor([1.0, 2, 3]), torch.tensor([0.5, -1, 2])) + torch.outer(torch.tensor([0.0, 1, -1]), torch.tensor([1.0, 1, 0]))   # rank 2
+    M[3] = torch.eye(3) * 3 + 1e-3 * torch.randn(3, 3, generator=gen)     # nearly equal singular values
+    Md = M.double().requires_grad_(True)
+    U, _, Vt = torch.linalg.svd(Md)
+    det = torch.det(U @ Vt)
+    Rref = U @ torch.diag_embed(torch.stack([torch.ones_like(det), torch.ones_like(det), det], dim=-1)) @ Vt
+    G = torch.randn(40, 3, 3, generator=gen)
+    keep = [i for i in range(40) if i != 2]                               # rank-deficient: R is not unique, only check orthogonality
+    (Rref[keep] * G[keep].double()).sum().backward()
+    Mg = M.to(DEV).requires_grad_(True)
+    R = ops.kabsch_rotation(Mg)
+    close(R[keep], Rref[keep].float(), atol=2e-6, rtol=1e-5)
+    eye = torch.eye(3, device=DEV).expand(40, 3, 3)
+    close(R @ R.transpose(1, 2), eye, atol=1e-6)
+    assert (torch.det(R) > 0.999).all()
+    (R[keep] * G[keep].to(DEV)).sum().backward()
+    relclose(Mg.grad[keep], Md.grad[keep].float(), 1e-4)

@@ -112,9 +112,17 @@ def _ga_points(seed=3):
     return src, tgt
 
 
+def _torch_rotation(M):
+    """U diag(1,1,det(UV^T)) V^T by torch.linalg.svd: stands in for the HIP solver in this CPU-only test of the moments' all-reduce"""
+    U, _, Vt = torch.linalg.svd(M)
+    det = torch.det(U @ Vt)
+    return U @ torch.diag_embed(torch.stack([torch.ones_like(det), torch.ones_like(det), det], dim=-1)) @ Vt
+
+
 def _ga_worker(rank, world, port, q):
     from neural_invertible_warp_amd import parallel
     from neural_invertible_warp_amd.model import nerf_inn_llff
+    nerf_inn_llff.ROTATION_SOLVER = _torch_rotation
     from neural_invertible_warp_amd.util import edict
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
@@ -141,7 +149,9 @@ def _ga_worker(rank, world, port, q):
 
 def test_sharded_kabsch_alignment_loss_matches_single_process():
     from neural_invertible_warp_amd import camera
+    from neural_invertible_warp_amd.model import nerf_inn_llff
     from neural_invertible_warp_amd.model.nerf_inn_llff import rigid_points_registration
+    nerf_inn_llff.ROTATION_SOLVER = _torch_rotation
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
