@@ -164,3 +164,17 @@ def test_kabsch_rotation_matches_svd_and_its_autograd():
     assert (torch.det(R) > 0.999).all()
     (R[keep] * G[keep].to(DEV)).sum().backward()
     relclose(Mg.grad[keep], Md.grad[keep].float(), 1e-4)
+
+
+def test_c_program_calls_the_boundary(tmp_path):
+    """examples/composite_c_abi.c: a plain C11 program (gcc, HIP runtime C API for memory) linked against libniw_hip.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "neural_invertible_warp_amd")
+    exe = str(tmp_path / "composite_c_abi")
+    subprocess.run(["gcc", "-std=c11", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "composite_c_abi.c"), "-I" + os.path.join(root, "include"),
+                    "-I/opt/rocm/include", "-L" + pkg, "-L/opt/rocm/lib", "-lniw_hip", "-lamdhip64", "-lm", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
