@@ -85,15 +85,20 @@ class Graph(nerf.Graph):
         return var
 
     def draw_ray_idx(self, opt, batch_size):
-        """reference :510 -- one pixel set shared by every view.  Under ray sharding
-        (..parallel.shard_ray_idx) every rank draws the same permutation and keeps its slice."""
+        """reference :510 -- one pixel set shared by every view.  Under ray sharding (..parallel.shard_ray_idx) every
+        rank draws the same permutation and keeps its slice; the permutation then comes from a generator of its own,
+        seeded alike on all ranks, because the ranks' default generators drift apart as soon as their stratified
+        draws differ in size (rays per rank differ by one when the ray count is not a multiple of the world size)."""
         n = opt.nerf.rand_rays // batch_size
-        idx = torch.randperm(opt.H * opt.W, device=opt.device)[:n]
         shard = getattr(opt, "ray_shard", None)
-        if shard is not None:
-            rank, world = shard
-            idx = idx[rank::world]
-        return idx
+        if shard is None:
+            return torch.randperm(opt.H * opt.W, device=opt.device)[:n]
+        gen = getattr(self, "_ray_idx_gen", None)
+        if gen is None:
+            gen = self._ray_idx_gen = torch.Generator(device=opt.device)
+            gen.manual_seed(1234567 + int(getattr(opt, "seed", 0) or 0))
+        rank, world = shard
+        return torch.randperm(opt.H * opt.W, device=opt.device, generator=gen)[:n][rank::world]
 
     def get_pose_init(self, opt, var, mode=None, ind=None, iter=None):
         return None

@@ -168,3 +168,49 @@ def test_sharded_kabsch_alignment_loss_matches_single_process():
     loss.backward()
     assert abs(float(lsum) - float(loss)) < 1e-6 * max(1.0, float(loss))
     assert (tgt.grad - torch.from_numpy(grad2)).abs().max() <= 1e-4 * tgt.grad.abs().max()
+
+
+def _idx_worker(rank, world, port, q):
+    from neural_invertible_warp_amd import parallel
+    from neural_invertible_warp_amd.model import nerf_inn_llff
+    from neural_invertible_warp_amd.util import edict
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    g = nerf_inn_llff.Graph.__new__(nerf_inn_llff.Graph)
+    torch.nn.Module.__init__(g)
+    opt = edict(H=12, W=16, device="cpu", seed=0, nerf=edict(rand_rays=3 * 37), ray_shard=(rank, world))     # 37 rays per view: 19 + 18
+    out = []
+    for _ in range(4):
+        idx = g.draw_ray_idx(opt, 3)
+        torch.rand(len(idx), 5 + rank)                 # rank-dependent consumption of the default generator (stratified draws)
+        pad = torch.full((19,), -1, dtype=torch.int64)
+        pad[:len(idx)] = idx
+        both = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(both, pad)
+        out.append(torch.stack(both).numpy())
+    if rank == 0:
+        q.put(out)
+    dist.destroy_process_group()
+
+
+def test_sharded_ray_indices_stay_a_partition_when_ranks_hold_different_ray_counts():
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_idx_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    steps = q.get(timeout=90)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    seen = []
+    for both in steps:
+        a, b = both[0][both[0] >= 0], both[1][both[1] >= 0]
+        assert len(a) == 19 and len(b) == 18
+        merged = np.concatenate([a, b])
+        assert len(set(merged.tolist())) == 37                      # disjoint, together the 37 pixels of ONE permutation prefix
+        seen.append(tuple(sorted(merged.tolist())))
+    assert len(set(seen)) == len(seen)                              # and a fresh draw every step
