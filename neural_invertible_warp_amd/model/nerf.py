@@ -271,3 +271,124 @@ class Graph(_BaseGraph):
         dummy = torch.zeros(B * R, S, device=pdf.device)
         fine, _ = ops.sample_pdf_merge(pdf.reshape(B * R, S), dummy, opt.nerf.sample_intvs_fine, opt.nerf.depth.range)
         return fine.view(B, R, -1, 1)
+
+
+class Model:
+    """The reference's engine interface for the vanilla model (model/nerf.py:20-160, driven by train.py:21-32), ground-truth
+    poses: torch.optim.Adam with one param group per network and ExponentialLR exactly as the reference builds them
+    (the parameters are ordinary nn.Parameters, views of the flat buffers the kernels read); checkpoints are the
+    reference's model.ckpt dict.  Logging back-ends are outside the path."""
+
+    def __init__(self, opt):
+        import os
+        self.opt = opt
+        os.makedirs(opt.output_path, exist_ok=True)
+        self.it = self.iter_start = 0
+
+    def load_dataset(self, opt, eval_split="val"):
+        import importlib
+        import os
+        name = opt.data.dataset
+        root = opt.data.get("root") or "data/{}".format(name)
+        if name != "synthetic" and not os.path.isdir("{}/{}".format(root, opt.data.scene)):
+            print("[niw] dataset {}/{} not found: using the procedural scene".format(root, opt.data.scene))
+            name = "synthetic"
+        data = importlib.import_module("neural_invertible_warp_amd.data.{}".format(name))
+        self.train_data = data.Dataset(opt, split="train", subset=opt.data.get("train_sub"))
+        self.test_data = data.Dataset(opt, split="test" if opt.data.get("val_on_test") else eval_split, subset=opt.data.get("val_sub"))
+        for d in (self.train_data, self.test_data):
+            d.prefetch_all_data(opt)
+            d.all = edict({k: v.to(opt.device) for k, v in d.all.items()})
+
+    def build_networks(self, opt):
+        torch.manual_seed(opt.seed or 0)
+        self.graph = Graph(opt).to(opt.device)
+
+    def setup_optimizer(self, opt):
+        optimizer = getattr(torch.optim, opt.optim.algo)
+        self.optim = optimizer([dict(params=self.graph.nerf.parameters(), lr=opt.optim.lr)])
+        if opt.nerf.fine_sampling:
+            self.optim.add_param_group(dict(params=self.graph.nerf_fine.parameters(), lr=opt.optim.lr))
+        gamma = (opt.optim.lr_end / opt.optim.lr) ** (1. / opt.max_iter) if opt.optim.get("lr_end") else 1.0
+        self.sched = torch.optim.lr_scheduler.ExponentialLR(self.optim, gamma=gamma)
+
+    def restore_checkpoint(self, opt):
+        import os
+        self.epoch_start = self.iter_start = 0
+        name = None
+        if opt.resume:
+            name = "{0}/model.ckpt".format(opt.output_path) if opt.resume is True else "{0}/model/{1}.ckpt".format(opt.output_path, opt.resume)
+        elif opt.load is not None:
+            name = opt.load
+        if name is None:
+            return
+        ck = torch.load(name, map_location=opt.device, weights_only=False)
+        for child_name, child in self.graph.named_children():
+            sd = {".".join(k.split(".")[1:]): v for k, v in ck["graph"].items() if k.startswith(child_name + ".")}
+            if sd:
+                child.load_state_dict(sd)
+        if opt.resume:
+            self.optim.load_state_dict(ck["optim"])
+            self.sched.load_state_dict(ck["sched"])
+            self.epoch_start, self.iter_start = ck["epoch"] or 0, ck["iter"] or 0
+
+    def setup_visualizer(self, opt):
+        pass
+
+    def train(self, opt):
+        self.graph.train()
+        var = self.train_data.all
+        self.it = self.iter_start
+        if self.iter_start == 0:
+            self.validate(opt, 0)
+        while self.it < opt.max_iter:
+            loss = self.train_iteration(opt, var, None)
+            self.sched.step()
+            if self.it % opt.freq.scalar == 0:
+                print("[train it {}] {}".format(self.it, " ".join("{}={:.5f}".format(k, float(v.detach())) for k, v in loss.items())), flush=True)
+            if self.it % opt.freq.val == 0:
+                self.validate(opt, self.it)
+            if self.it % opt.freq.ckpt == 0:
+                self.save_checkpoint(opt, ep=None, it=self.it)
+        return self
+
+    def summarize_loss(self, opt, var, loss):
+        total = 0.
+        for key in loss:
+            if opt.loss_weight[key] is not None:
+                total = total + 10 ** float(opt.loss_weight[key]) * loss[key]
+        loss.update(all=total)
+        return loss
+
+    def train_iteration(self, opt, var, loader=None):
+        self.optim.zero_grad(set_to_none=True)
+        var = self.graph.forward(opt, edict(var), mode="train")
+        loss = self.summarize_loss(opt, var, self.graph.compute_loss(opt, var, mode="train"))
+        loss.all.backward()
+        self.optim.step()
+        self.it += 1
+        return loss
+
+    @torch.no_grad()
+    def validate(self, opt, ep=None):
+        self.graph.eval()
+        psnr = []
+        allv = self.test_data.all
+        for i in range(len(self.test_data)):
+            var = self.graph.forward(opt, edict({k: v[i:i + 1] for k, v in allv.items()}), mode="val")
+            rgb = var.rgb_fine if opt.nerf.fine_sampling else var.rgb
+            rgb_map = rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+            psnr.append(-10 * self.graph.MSE_loss(rgb_map, var.image).log10().item())
+        self.graph.train()
+        out = edict(psnr=sum(psnr) / max(len(psnr), 1))
+        print("[val it {}] PSNR {:.2f}".format(ep, out.psnr), flush=True)
+        return out
+
+    def save_checkpoint(self, opt, ep=0, it=0, latest=False):
+        import os
+        import shutil
+        os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
+        ck = dict(epoch=ep, iter=it, graph=self.graph.state_dict(), optim=self.optim.state_dict(), sched=self.sched.state_dict())
+        torch.save(ck, "{0}/model.ckpt".format(opt.output_path))
+        if not latest:
+            shutil.copy("{0}/model.ckpt".format(opt.output_path), "{0}/model/{1}.ckpt".format(opt.output_path, ep or it))

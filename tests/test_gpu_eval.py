@@ -197,3 +197,19 @@ def test_train_entry_point_runs_resumes_and_evaluates(tmp_path, capsys):
     res = m2.evaluate_full(m2.opt)
     assert len(res.res) == len(m2.test_data) and all(r.psnr > 0 for r in res.res)
     assert os.path.exists(f"{path}/quant.txt") and os.path.exists(f"{path}/quant_pose.txt")
+
+
+def test_train_entry_point_vanilla_nerf(tmp_path, capsys):
+    """--model=nerf --yaml=nerf_llff_repr (BASELINE configs[0] shape family: GT poses, coarse + fine networks, torch Adam)"""
+    import os
+    from neural_invertible_warp_amd import train
+    args = ["--model=nerf", "--yaml=nerf_llff_repr", "--data.dataset=synthetic", "--data.image_size=[24,32]", "--nerf.rand_rays=288",
+            "--nerf.sample_intvs=16", "--nerf.sample_intvs_fine=16", "--freq.val=4", "--freq.ckpt=4", "--freq.scalar=2",
+            f"--output_root={tmp_path}", "--name=v"]
+    m = train.main(args + ["--max_iter=4"])
+    out = capsys.readouterr().out
+    assert "[val it 0]" in out and "[val it 4]" in out and "render_fine=" in out
+    ck = torch.load(f"{m.opt.output_path}/model.ckpt", weights_only=False)
+    assert ck["iter"] == 4 and "nerf_fine.mlp_rgb.1.bias" in ck["graph"] and len(ck["optim"]["param_groups"]) == 2
+    m2 = train.main(args + ["--max_iter=6", "--resume"])
+    assert m2.iter_start == 4 and m2.it == 6 and os.path.exists(f"{m.opt.output_path}/model/4.ckpt")
