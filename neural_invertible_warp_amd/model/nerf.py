@@ -243,15 +243,27 @@ class Graph(_BaseGraph):
             center, ray = camera.convert_NDC(opt, center, ray, intr=intr)
         return self._render_rays(opt, center, ray, mode=mode)
 
+    def _hold_weights(self):
+        """context: pack the networks' weights once for a loop of gradient-free renders (ops.FieldState.hold)"""
+        import contextlib
+        stack = contextlib.ExitStack()
+        if not torch.is_grad_enabled():
+            for net in (self.nerf, getattr(self, "nerf_fine", None)):
+                if net is not None:
+                    net._ensure_flat()
+                    stack.enter_context(net._state.hold())
+        return stack
+
     def render_by_slices(self, opt, pose, intr=None, mode=None):
         """reference nerf.py:321-332"""
         ret_all = edict(rgb=[], depth=[], opacity=[])
         if opt.nerf.fine_sampling:
             ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
-        for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
-            ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
-            ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode)
-            for k in ret: ret_all[k].append(ret[k])
+        with self._hold_weights():
+            for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
+                ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
+                ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode)
+                for k in ret: ret_all[k].append(ret[k])
         for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)
         return ret_all
 

@@ -68,10 +68,11 @@ class Graph(nerf_inn_llff.Graph):
         ret_all = edict(rgb=[], depth=[], opacity=[])
         if opt.nerf.fine_sampling:
             ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
-        for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
-            ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
-            ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode, depth_range=depth_range)
-            for k in ret: ret_all[k].append(ret[k])
+        with self._hold_weights():
+            for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
+                ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
+                ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode, depth_range=depth_range)
+                for k in ret: ret_all[k].append(ret[k])
         for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)
         return ret_all
 
