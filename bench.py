@@ -178,7 +178,7 @@ def main():
                config=dict(workload="cfg2: nerf_inn_llff.yaml fern 300x400, 18 views x 227 rays x (64 coarse + 192 fine) per GPU, "
                                     "NVP-warped rays, fwd+bwd+Adam", rays_per_gpu=B * R, samples_per_ray="64+192",
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=f"ray-shard dp{world}", precision="exact fp32 MFMA"),
-               loss=float(loss.all), roofline=roofline, kernels=kernels)
+               loss=float(loss.all.detach()), roofline=roofline, kernels=kernels)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, S, Sf, opt.H, opt.W)
     print(json.dumps(out))
