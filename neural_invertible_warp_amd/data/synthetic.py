@@ -19,6 +19,8 @@ class Dataset(torch.utils.data.Dataset):
         self.intr = torch.tensor([[0.8 * opt.W, 0, opt.W / 2], [0, 0.8 * opt.W, opt.H / 2], [0, 0, 1]], dtype=torch.float32).repeat(n, 1, 1)
         self.poses = camera.lie.se3_to_SE3(torch.randn(n, 6, generator=gen) * 0.05)
         self.list = list(range(n))
+        # DTU-style samples carry the metric depth range of the scene (data/dtu.py); the DTU graphs read var.depth_range[0]
+        self.depth_range = torch.tensor(opt.nerf.depth.range, dtype=torch.float32).repeat(n, 1) if opt.data.get("dataset") == "dtu" else None
 
     def __len__(self):
         return len(self.list)
@@ -31,4 +33,6 @@ class Dataset(torch.utils.data.Dataset):
 
     def prefetch_all_data(self, opt):
         self.all = edict(idx=torch.arange(len(self)), image=self.images, intr=self.intr, pose=self.poses)
+        if self.depth_range is not None:
+            self.all.depth_range = self.depth_range
         return self.all

@@ -20,8 +20,25 @@ from .align_trajectories import align_ate_c2b_use_a2b
 from .util import edict
 
 
+class _TestTimeRefinement:
+    def evaluate_test_time_photometric_optim(self, opt, var):
+        """Absorb the remaining pose error of a test view in an se(3) correction optimised photometrically
+        (barf_inn_llff.py:218-234, barf_inn_dtu.py:467-483)"""
+        var.se3_refine_test = torch.nn.Parameter(torch.zeros(1, 6, device=opt.device))
+        optim_pose = getattr(torch.optim, opt.optim.algo)([dict(params=[var.se3_refine_test], lr=opt.optim.lr_pose)])
+        with torch.enable_grad():
+            for _ in range(opt.optim.test_iter):
+                optim_pose.zero_grad()
+                var.pose_refine_test = camera.lie.se3_to_SE3(var.se3_refine_test)
+                var = self.graph.forward(opt, var, mode="test-optim")
+                loss = self.graph.compute_loss(opt, var, mode="test-optim")
+                loss.render.backward()
+                optim_pose.step()
+        return var
+
+
 # ------------------------------------------------------------------------------------------ LLFF
-class LLFFEvaluator:
+class LLFFEvaluator(_TestTimeRefinement):
     def __init__(self, opt, graph, pose_GT):
         """pose_GT: ground-truth w2c poses of the training views [N,3,4] (train_data.get_all_camera_poses)"""
         self.opt, self.graph, self.pose_GT = opt, graph, pose_GT.to(opt.device)
@@ -53,20 +70,6 @@ class LLFFEvaluator:
         R_GT, t_GT = pose_GT.split([3, 1], dim=-1)
         return edict(R=camera.rotation_distance(R_aligned, R_GT), t=(t_aligned - t_GT)[..., 0].norm(dim=-1))
 
-    def evaluate_test_time_photometric_optim(self, opt, var):
-        """Absorb the remaining pose error of a test view in an se(3) correction optimised photometrically"""
-        var.se3_refine_test = torch.nn.Parameter(torch.zeros(1, 6, device=opt.device))
-        optim_pose = getattr(torch.optim, opt.optim.algo)([dict(params=[var.se3_refine_test], lr=opt.optim.lr_pose)])
-        with torch.enable_grad():
-            for _ in range(opt.optim.test_iter):
-                optim_pose.zero_grad()
-                var.pose_refine_test = camera.lie.se3_to_SE3(var.se3_refine_test)
-                var = self.graph.forward(opt, var, mode="test-optim")
-                loss = self.graph.compute_loss(opt, var, mode="test-optim")
-                loss.render.backward()
-                optim_pose.step()
-        return var
-
     def evaluate_full(self, opt, test_views, eps=1e-10):
         """test_views: iterable of var dicts (idx, image [1,3,H,W], intr, pose) -> edict(error=pose errors,
         res=[edict(psnr, ssim)], rgb / invdepth maps of the last view)"""
@@ -90,7 +93,7 @@ class LLFFEvaluator:
 
 
 # ------------------------------------------------------------------------------------------ DTU
-class DTUEvaluator:
+class DTUEvaluator(_TestTimeRefinement):
     def __init__(self, opt, graph, pose_GT):
         """graph: barf_inn_dtu.Graph (poses live on graph.pose_net); pose_GT: training w2c poses [N,3,4]"""
         self.opt, self.graph, self.pose_GT = opt, graph, pose_GT.to(opt.device)
@@ -181,6 +184,8 @@ class DTUEvaluator:
         res = []
         for var in test_views:
             var = edict(var)
+            if opt.optim.test_photo:
+                var = self.evaluate_test_time_photometric_optim(opt, var)
             with torch.no_grad():
                 var = self.graph.forward(opt, var, mode="eval")
                 rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2).contiguous()

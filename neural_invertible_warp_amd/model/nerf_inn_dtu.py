@@ -26,11 +26,16 @@ class Graph(nerf_inn_llff.Graph):
         """reference nerf_inn_dtu.py:371-396"""
         batch_size = len(var.idx)
         depth_range = opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else self._host_depth_range(var.depth_range)
-        if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
+        if opt.nerf.rand_rays and mode == "train":
             var.ray_idx = self.draw_ray_idx(opt, batch_size)
             ray, center, grid_3d = self.get_pose(opt, var, mode=mode, iter=iter)
             ret = self.render_local(opt, ray, center, intr=var.intr, mode=mode, depth_range=depth_range)
             ret.update(grid_local=grid_3d, center_local=center, grid_init=self.pose_net.grid_init, center_init=self.pose_net.center_init)
+        elif opt.nerf.rand_rays and mode == "test-optim":
+            # test-time pose refinement: random rays of the back-aligned (and refined) test pose.  The reference's DTU forward
+            # unpacks that pose as (ray, center, grid) in this mode (nerf_inn_dtu.py:385) and cannot run; rendered properly here.
+            var.ray_idx = self.draw_ray_idx(opt, batch_size)
+            ret = self.render(opt, self.get_pose(opt, var, mode=mode), intr=var.intr, ray_idx=var.ray_idx, mode=mode, depth_range=depth_range)
         else:
             pose_w2c = self.get_pose(opt, var, mode=mode)
             ret = self.render_by_slices(opt, pose_w2c, intr=var.intr, mode=mode, depth_range=depth_range) if opt.nerf.rand_rays else \

@@ -213,3 +213,22 @@ def test_train_entry_point_vanilla_nerf(tmp_path, capsys):
     assert ck["iter"] == 4 and "nerf_fine.mlp_rgb.1.bias" in ck["graph"] and len(ck["optim"]["param_groups"]) == 2
     m2 = train.main(args + ["--max_iter=6", "--resume"])
     assert m2.iter_start == 4 and m2.it == 6 and os.path.exists(f"{m.opt.output_path}/model/4.ckpt")
+
+
+def test_train_entry_point_dtu_with_learnable_poses(tmp_path, capsys):
+    """--model=barf_inn_dtu --yaml=barf_inn_dtu (BASELINE cfg 5 family): noisy initial poses, INNPoseParams, two optimizers,
+    validation through the pairwise pose alignment + back-aligned test poses, resume."""
+    from neural_invertible_warp_amd import train
+    args = ["--model=barf_inn_dtu", "--yaml=barf_inn_dtu", "--data.dataset=dtu", "--data.image_size=[24,32]", "--nerf.rand_rays=192",
+            "--nerf.sample_intvs=32", "--data.train_sub=3", "--freq.val=3", "--freq.ckpt=3", "--freq.scalar=1", "--optim.test_iter=3",
+            f"--output_root={tmp_path}", "--name=d"]
+    m = train.main(args + ["--max_iter=3"])
+    out = capsys.readouterr().out
+    assert "[val it 3]" in out and "rot " in out and "global_alignment=" in out
+    ck = torch.load(f"{m.opt.output_path}/model.ckpt", weights_only=False)
+    assert "pose_net.pose_embedding.lin0_a_0.weight_g" in ck["graph"] and "optim_pose" in ck and ck["iter"] == 3
+    assert hasattr(m.pose_net, "sim3_est_to_gt_c2w")
+    m2 = train.main(args + ["--max_iter=5", "--resume"])
+    assert m2.iter_start == 3 and m2.it == 5
+    res = m2.evaluate_full(m2.opt)
+    assert all(r.psnr > 0 for r in res.res)
