@@ -179,6 +179,24 @@ def main():
                                     "NVP-warped rays, fwd+bwd+Adam", rays_per_gpu=B * R, samples_per_ray="64+192",
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=f"ray-shard dp{world}", precision="exact fp32 MFMA"),
                loss=float(loss.all.detach()), roofline=roofline, kernels=kernels)
+    if world == 1:
+        # forward-only figure of SURVEY section 8d: one full 300x400 image through the eval path of the same graph
+        # (render_by_slices: slices of rand_rays rays, coarse + fine networks), outside the timed training region
+        with torch.no_grad():
+            g = trainer.graph
+            pose1, intr1 = torch.eye(3, 4, device=dev)[None], var0.intr[:1]
+            g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+            torch.cuda.synchronize()
+            t_img = (time.perf_counter() - t1) / 2
+        n_eval = opt.H * opt.W * (S + S + Sf)
+        out["forward_only"] = dict(value=n_eval / t_img, unit="ray-samples/s", ms_per_image=round(t_img * 1e3, 2),
+                                   workload=f"one {opt.H}x{opt.W} image, {S} coarse + {S + Sf} fine samples per ray, "
+                                            f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} slices of {opt.nerf.rand_rays} rays",
+                                   frac_of_fwd_roofline=round(n_eval / t_img * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, S, Sf, opt.H, opt.W)
     print(json.dumps(out))
