@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256, 1) void k(const f32x4* __restrict__ w, float* 
     const int lane = threadIdx.x & 63;
     float b[128];
 #pragma unroll
-    for (int i = 0; i < 128; ++i) b[i] = (float)(lane + i) * 1e-3f;
+    for (int i = 0; i < 128; ++i) b[i] = (float)((lane * 131 + i * 71) % 257 - 128) * 3e-3f;
     f32x16 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -112,7 +112,12 @@ int main() {
     const long long pitch = (long long)blocks * 256;
     f32x4* w; float *out, *sink;
     hipMalloc(&w, sizeof(f32x4) * LAYERS * KB * NBLK * 64);
-    hipMemset(w, 0, sizeof(f32x4) * LAYERS * KB * NBLK * 64);
+    {   // random weights: all-zero operands let the chip hold a higher clock (MI355X_MICROARCH.md, DVFS give-back)
+        std::vector<float> h((size_t)LAYERS * KB * NBLK * 64 * 4);
+        unsigned s = 12345u;
+        for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((float)(s >> 9) * (1.0f / 8388608.0f) - 0.5f) * 0.1f; }
+        hipMemcpy(w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     hipMalloc(&out, sizeof(float) * pitch * LAYERS * 256);
     hipMalloc(&sink, 16);
     run<0>(w, out, sink, blocks, pitch);
