@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_trains_a_consistent_scene():
+    import os
     import sys
-    sys.path.insert(0, "tools")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import teacher_student_demo as demo
     hist = demo.run(steps=500, views=6, size=(40, 56), log_every=100, quiet=True)
     psnr = [h[1] for h in hist]

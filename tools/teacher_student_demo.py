@@ -10,7 +10,9 @@ import argparse
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from neural_invertible_warp_amd import camera, configs, engine, evaluation, ops
