@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_invertible_warp_amd import ops
 from oracle import niw_oracle as O

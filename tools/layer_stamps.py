@@ -1,4 +1,4 @@
-import os, sys, ctypes; sys.path.insert(0,'.')
+import os, sys, ctypes; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from neural_invertible_warp_amd import _lib
 _lib.LIB_PATH = os.environ.get('NIW_STAMP_LIB', 'scratch/stampbuild/libniw_hip.so')

@@ -1,7 +1,7 @@
 """Functional run of every BASELINE config shape on one GPU (a few steps each): losses finite and decreasing,
 ray-samples/s printed.  Not the headline benchmark (bench.py is)."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_invertible_warp_amd import configs, engine, ops
 from neural_invertible_warp_amd.model import nerf, barf_inn_dtu
