@@ -71,9 +71,6 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="run the dW GEMM group on a side stream (+2.3 %% ray-samples/s on MI355X); off by default because the "
-                         "per-kernel device-event timings of the roofline table are then no longer isolated")
     args = ap.parse_args()
 
     import torch
@@ -89,7 +86,6 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = f"cuda:{local}"
 
-    ops.SIDE.enabled = args.overlap
     B, rays_per_gpu = 18, 4096
     opt = configs.cfg2_nerf_inn_llff_hier(device=dev)
     opt.nerf.rand_rays = rays_per_gpu * world                # global draw; each rank keeps idx[rank::world]

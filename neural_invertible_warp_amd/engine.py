@@ -60,7 +60,6 @@ class INNTrainer:
         var = self.graph.forward(opt, var, mode="train", iter=self.it)
         loss = self.summarize_loss(self.graph.compute_loss(opt, var, mode="train"))
         loss.all.backward()
-        ops.SIDE.join()                     # weight-gradient GEMMs may run on a side stream (ops.SIDE.enabled)
         self.bucket.gather()
         self.bucket.all_reduce()
         for i, flat in enumerate(self.flats):

@@ -73,29 +73,6 @@ class timed:
         return False
 
 
-class _SideStream:
-    """Optional second HIP stream for the weight-gradient GEMMs (see _FieldMLP.backward).  Off by
-    default: with it on, parameter gradients are only valid after SIDE.join()."""
-
-    def __init__(self):
-        self.enabled = False
-        self._streams = {}
-
-    def stream(self, device):
-        key = str(device)
-        if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=device)
-        return self._streams[key]
-
-    def join(self):
-        """Make the current stream wait for everything launched on the side stream(s)."""
-        for s in self._streams.values():
-            torch.cuda.current_stream().wait_stream(s)
-
-
-SIDE = _SideStream()
-
-
 def _farr(vals, n):
     vals = [float(v) for v in vals]
     assert len(vals) == n
@@ -250,22 +227,10 @@ class _FieldMLP(torch.autograd.Function):
         with timed("mlp_bwd_dx", n_rays * S):
             _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], _p(rgb),
                       _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(d_center), _p(d_ray), _stream())
-        side = SIDE.stream(dev) if SIDE.enabled else None
-        if side is None:
-            with timed("mlp_bwd_dw", n_rays * S):
-                _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, _p(partial), _p(d_params), _stream())
-        else:
-            # dW depends only on what the dX chain just wrote; nothing downstream of this node needs it
-            # before the optimizer.  Launch it on a side stream so that the rest of the backward (compositing,
-            # the coarse network's dX chain, the warp, the host-side glue kernels) runs in its shadow;
-            # SIDE.join() makes the consumer stream wait for it.
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                with timed("mlp_bwd_dw", n_rays * S):
-                    _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, _p(partial), _p(d_params), _stream())
-            for t in (ctx.save_ws, gradws, partial, d_params):
-                t.record_stream(side)
+        # (running this group on a second stream beside the rest of the backward was tried: once the seven 256 x 256
+        # pieces became one 511-workgroup launch it fills the chip by itself and the overlap cost 40 %)
+        with timed("mlp_bwd_dw", n_rays * S):
+            _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, _p(partial), _p(d_params), _stream())
         ctx.save_ws = None
         grads, off = [], 0
         for shp in ctx.param_shapes:
