@@ -188,11 +188,23 @@ def main():
                 g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
             torch.cuda.synchronize()
             t_img = (time.perf_counter() - t1) / 2
+            # the same image in the largest slices one launch takes (nerf.eval_slice_rays; results are slice-independent)
+            opt.nerf.eval_slice_rays = opt.H * opt.W
+            g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+            torch.cuda.synchronize()
+            t_big = (time.perf_counter() - t1) / 2
+            opt.nerf.eval_slice_rays = None
         n_eval = opt.H * opt.W * (S + S + Sf)
         out["forward_only"] = dict(value=n_eval / t_img, unit="ray-samples/s", ms_per_image=round(t_img * 1e3, 2),
                                    workload=f"one {opt.H}x{opt.W} image, {S} coarse + {S + Sf} fine samples per ray, "
                                             f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} slices of {opt.nerf.rand_rays} rays",
-                                   frac_of_fwd_roofline=round(n_eval / t_img * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4))
+                                   frac_of_fwd_roofline=round(n_eval / t_img * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4),
+                                   largest_slices=dict(value=n_eval / t_big, ms_per_image=round(t_big * 1e3, 2),
+                                                       frac_of_fwd_roofline=round(n_eval / t_big * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4)))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, S, Sf, opt.H, opt.W)
     print(json.dumps(out))

@@ -12,6 +12,14 @@ from ..util import edict
 _SUPPORTED_ARCH = dict(layers_feat=[None, 256, 256, 256, 256, 256, 256, 256, 256], layers_rgb=[None, 128, 3], skip=[4])
 
 
+def _slice_rays(opt):
+    """Rays per slice of a full-image render.  The reference slices by `nerf.rand_rays` (nerf.py:325) to bound its memory;
+    `nerf.eval_slice_rays` overrides it (the HIP path takes up to 2^24 samples per launch: a 300x400 image in one go)."""
+    n = opt.nerf.get("eval_slice_rays") or opt.nerf.rand_rays
+    s = opt.nerf.sample_intvs + (opt.nerf.sample_intvs_fine or 0 if opt.nerf.fine_sampling else 0)
+    return max(1, min(int(n), ((1 << 24) - 128) // max(s, 1)))
+
+
 def _layer_dims(layers):
     return list(zip(layers[:-1], layers[1:]))
 
@@ -260,8 +268,9 @@ class Graph(_BaseGraph):
         if opt.nerf.fine_sampling:
             ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
         with self._hold_weights():
-            for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
-                ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
+            step = _slice_rays(opt)
+            for c in range(0, opt.H * opt.W, step):
+                ray_idx = torch.arange(c, min(c + step, opt.H * opt.W), device=opt.device)
                 ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode)
                 for k in ret: ret_all[k].append(ret[k])
         for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)

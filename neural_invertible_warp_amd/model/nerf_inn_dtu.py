@@ -8,6 +8,7 @@ import torch
 from .. import camera
 from ..util import edict
 from . import nerf, nerf_inn_llff
+from .nerf import _slice_rays
 
 
 class NeRF(nerf.NeRF):
@@ -74,8 +75,9 @@ class Graph(nerf_inn_llff.Graph):
         if opt.nerf.fine_sampling:
             ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
         with self._hold_weights():
-            for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
-                ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
+            step = _slice_rays(opt)
+            for c in range(0, opt.H * opt.W, step):
+                ray_idx = torch.arange(c, min(c + step, opt.H * opt.W), device=opt.device)
                 ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode, depth_range=depth_range)
                 for k in ret: ret_all[k].append(ret[k])
         for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)

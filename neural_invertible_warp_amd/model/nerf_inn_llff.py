@@ -7,6 +7,7 @@ import torch
 from .. import camera, ops
 from ..util import edict
 from . import nerf
+from .nerf import _slice_rays
 
 
 def _all_reduce_sum(t):
@@ -140,8 +141,9 @@ class Graph(nerf.Graph):
         if opt.nerf.fine_sampling:
             ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
         with self._hold_weights():
-            for c in range(0, opt.H * opt.W, opt.nerf.rand_rays):
-                ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, opt.H * opt.W), device=opt.device)
+            step = _slice_rays(opt)
+            for c in range(0, opt.H * opt.W, step):
+                ray_idx = torch.arange(c, min(c + step, opt.H * opt.W), device=opt.device)
                 ret = self.render_local(opt, ray, center, intr=intr, ray_idx=ray_idx, mode=mode)
                 for k in ret: ret_all[k].append(ret[k])
         for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)

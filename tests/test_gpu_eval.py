@@ -232,3 +232,20 @@ def test_train_entry_point_dtu_with_learnable_poses(tmp_path, capsys):
     assert m2.iter_start == 3 and m2.it == 5
     res = m2.evaluate_full(m2.opt)
     assert all(r.psnr > 0 for r in res.res)
+
+
+def test_full_image_render_is_independent_of_the_slice_size():
+    """nerf.eval_slice_rays (bigger slices than the reference's rand_rays) must not change a deterministic render"""
+    from neural_invertible_warp_amd.model import nerf
+    H, W = 20, 24
+    opt = mk_opt("cfg1_nerf_llff_repr", H=H, W=W, **{"nerf.sample_intvs": 16, "nerf.sample_intvs_fine": 16, "nerf.rand_rays": 64,
+                                                     "nerf.sample_stratified": False, "nerf.density_noise_reg": None})
+    graph = nerf.Graph(opt)
+    load_nerf(graph.nerf, O.make_nerf_params(3)); load_nerf(graph.nerf_fine, O.make_nerf_params(4))
+    pose, intr = g(_poses(1, torch.Generator().manual_seed(2))), g(_intr(H, W))
+    with torch.no_grad():
+        a = graph.render_by_slices(opt, pose, intr=intr, mode="eval")
+        opt.nerf.eval_slice_rays = H * W
+        b = graph.render_by_slices(opt, pose, intr=intr, mode="eval")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
