@@ -241,8 +241,21 @@ class _FieldMLP(torch.autograd.Function):
 
 
 def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None):
-    """NeRF.forward_samples on flattened rays: center, ray [N,3], depth [N,S] -> rgb [N,S,3], sigma [N,S]."""
-    return _FieldMLP.apply(state, band3d, bandview, activ, noise, center, ray, depth, *params)
+    """NeRF.forward_samples on flattened rays: center, ray [N,3], depth [N,S] -> rgb [N,S,3], sigma [N,S].
+    One launch takes fewer than 2^24 padded samples (32-bit byte offsets into the workspaces, niw_mlp_device.h); larger
+    batches are split over the rays (autograd sums the parameter gradients of the pieces)."""
+    n_rays, S = depth.shape
+    max_rays = ((1 << 24) - 256) // S
+    if n_rays <= max_rays:
+        return _FieldMLP.apply(state, band3d, bandview, activ, noise, center, ray, depth, *params)
+    rgb, sigma = [], []
+    with (state.hold() if not params else contextlib.nullcontext()):
+        for a in range(0, n_rays, max_rays):
+            b = min(a + max_rays, n_rays)
+            r, s_ = _FieldMLP.apply(state, band3d, bandview, activ, None if noise is None else noise[a:b], center[a:b], ray[a:b], depth[a:b], *params)
+            rgb.append(r)
+            sigma.append(s_)
+    return torch.cat(rgb), torch.cat(sigma)
 
 
 # ------------------------------------------------------------------------------------------

@@ -116,3 +116,23 @@ def test_full_train_step_cfg2_finite_and_learns():
         assert torch.isfinite(tr.bucket.flat).all()
     assert all(l == l and l < 1 for l in losses)
     assert losses[-1] < losses[0]
+
+
+def test_mlp_batches_beyond_one_launch_are_split_over_rays():
+    """> 2^24 samples in one call (here 70,000 rays x 256): the wrapper splits over the rays; the pieces must agree with direct
+    calls on sub-ranges (size-independent property: per-ray independence)."""
+    from neural_invertible_warp_amd import ops
+    from oracle import niw_oracle as O
+    p = O.make_nerf_params(2)
+    flat = torch.cat([p[f"{n}.{k}"].reshape(-1) for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]).to(DEV)
+    st = ops.FieldState(flat)
+    N, S = 70000, 256
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    center, ray = torch.randn(N, 3, device=DEV, generator=gen), torch.randn(N, 3, device=DEV, generator=gen)
+    depth = torch.rand(N, S, device=DEV, generator=gen).sort(dim=1).values * 4 + 0.5
+    with torch.no_grad():
+        rgb, sig = ops.field_mlp(st, [], center, ray, depth, [1.0] * 10, [1.0] * 4, "softplus")
+        assert rgb.shape == (N, S, 3) and torch.isfinite(rgb).all() and torch.isfinite(sig).all()
+        for a, b in ((0, 100), (65000, 65600), (N - 50, N)):                    # across and beyond the split point
+            r2, s2 = ops.field_mlp(st, [], center[a:b], ray[a:b], depth[a:b], [1.0] * 10, [1.0] * 4, "softplus")
+            assert torch.equal(rgb[a:b], r2) and torch.equal(sig[a:b], s2)
