@@ -178,3 +178,23 @@ def test_c_program_calls_the_boundary(tmp_path):
                     "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+def test_composite_with_opaque_background():
+    """`nerf.setbg_opaque` (nerf.py:470-472): rgb += bgcolor * (1 - opacity); forward and backward vs the oracle"""
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(4)
+    N, S = 11, 40
+    ray = t(rng.standard_normal((1, N, 3))).requires_grad_(True)
+    rgb_s = t(rng.uniform(0, 1, (1, N, S, 3))).requires_grad_(True)
+    sig = t(rng.uniform(0, 0.6, (1, N, S))).requires_grad_(True)          # thin medium: the background shows through
+    dep = t(np.sort(rng.uniform(0.5, 3, (1, N, S, 1)), axis=2))
+    dep[..., -1, :] = dep[..., -2, :]                                      # zero-length last interval: opacity stays < 1
+    ref = O.composite(ray, rgb_s, sig * 0 + sig, dep, bgcolor=0.8)
+    gs = t(rng.standard_normal((N, 3)))
+    (ref[0][0] * gs).sum().backward()
+    r2, c2, s2 = g(ray.detach()[0]).requires_grad_(True), g(rgb_s.detach()[0]).requires_grad_(True), g(sig.detach()[0]).requires_grad_(True)
+    out = ops.composite(r2, c2, s2, g(dep[0, :, :, 0]), bg=0.8)
+    close(out[0], ref[0][0]); close(out[2], ref[2][0, :, 0])
+    (out[0] * g(gs)).sum().backward()
+    relclose(r2.grad, ray.grad[0], 2e-4); relclose(c2.grad, rgb_s.grad[0], 1e-5); relclose(s2.grad, sig.grad[0], 2e-4)
