@@ -198,3 +198,25 @@ def test_composite_with_opaque_background():
     close(out[0], ref[0][0]); close(out[2], ref[2][0, :, 0])
     (out[0] * g(gs)).sum().backward()
     relclose(r2.grad, ray.grad[0], 2e-4); relclose(c2.grad, rgb_s.grad[0], 1e-5); relclose(s2.grad, sig.grad[0], 2e-4)
+
+
+def test_density_noise_regularisation_path():
+    """cfg 1 trains with `nerf.density_noise_reg = 1` (nerf.py:428-429): sigma = relu(raw + noise); the noise tensor enters the
+    kernel per sample, forward and backward vs the oracle with the same draw."""
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(21)
+    N, S = 7, 24
+    p, names, st, params = _field(12)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    center, ray = t(rng.uniform(-1, 1, (N, 3))), t(rng.standard_normal((N, 3)))
+    depth, noise = t(np.sort(rng.uniform(0.5, 4, (N, S)), axis=1)), t(rng.standard_normal((N, S)))
+    w3, wv = O.c2f_weights(0.3, (0.1, 0.5), 10), O.c2f_weights(0.3, (0.1, 0.5), 4)
+    rgb_ref, sig_ref = O.forward_samples(pr, center[None], ray[None], depth[None, :, :, None], density_activ="relu", w3d=w3, wview=wv,
+                                         density_noise=noise[None])
+    (rgb_ref.sum() + sig_ref.sum()).backward()
+    rgb, sig = ops.field_mlp(st, params, g(center), g(ray), g(depth), w3.tolist(), wv.tolist(), "relu", noise=g(noise))
+    close(rgb, rgb_ref[0]); close(sig, sig_ref[0], atol=5e-5, rtol=2e-4)
+    assert (sig == 0).any() and (sig > 0).any()                     # the noise moves samples across the ReLU threshold
+    (rgb.sum() + sig.sum()).backward()
+    for n, prm in zip(names, params):
+        relclose(prm.grad, pr[n].grad, 5e-3)
