@@ -64,6 +64,11 @@ int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples);
  * NIW_NERF_PARAM_FLOATS floats) into MFMA A-fragment order for the forward and the
  * transposed order for the backward.  Call after every optimizer step. */
 int niw_mlp_pack_weights(const float* params, float* packed, niw_stream_t stream);
+/* The same re-ordering through a gather table: niw_mlp_pack_index fills `index` [niw_mlp_packed_floats()] once (it depends
+ * only on the architecture constants; -1 = zero padding), niw_mlp_pack_weights_indexed then is a plain gather (~4x faster
+ * than decoding the fragment layout per element; a training step packs two networks). */
+int niw_mlp_pack_index(int32_t* index, niw_stream_t stream);
+int niw_mlp_pack_weights_indexed(const float* params, const int32_t* index, float* packed, niw_stream_t stream);
 
 /* NeRF.forward_samples (model/nerf.py:449-456) = get_3D_points_from_depth (camera.py:517-521)
  * + F.normalize + NeRF.forward (model/nerf.py:416-447) incl. positional_encoding

@@ -20,6 +20,8 @@ SIGNATURES = {
     "niw_mlp_packed_floats": (_i64, []),
     "niw_mlp_bwd_workspace_floats": (_i64, [_i64, _i]),
     "niw_mlp_pack_weights": (_i, [_vp, _vp, _vp]),
+    "niw_mlp_pack_index": (_i, [_vp, _vp]),
+    "niw_mlp_pack_weights_indexed": (_i, [_vp, _vp, _vp, _vp]),
     "niw_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "niw_mlp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_mlp_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -20,10 +20,8 @@ using namespace niw;
 // ---------------------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ packed) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= kPackedFloats) return;
-    float val = 0.f;
+// index of the parameter float that lands in packed float `idx` (-1: zero padding)
+__device__ __forceinline__ int pack_source(int idx) {
     if (idx < kFwdPackFloats) {
         int l = 0;
         while (l + 1 < kLayers && idx >= fwd_pack_off(l + 1)) ++l;
@@ -32,8 +30,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
         int nb = blk % fwd_nb(l), q = blk / fwd_nb(l);
         int i = lane & 31, h = lane >> 5;
         int row = out_row(l, nb * 32 + i), col = fwd_slot_col(l, 8 * q + 4 * h + t);
-        if (row >= 0 && col >= 0) val = params[weight_off(l) + row * layer_k(l) + col];
-    } else if (idx < kBiasPackOff) {
+        return (row >= 0 && col >= 0) ? weight_off(l) + row * layer_k(l) + col : -1;
+    }
+    if (idx < kBiasPackOff) {
         int l = 0;
         while (l + 1 < kLayers && idx >= bwd_pack_off(l + 1)) ++l;
         int local = idx - bwd_pack_off(l);
@@ -41,17 +40,36 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, float* __r
         int ob = blk % bwd_ob(l), rb = blk / bwd_ob(l);
         int i = lane & 31, h = lane >> 5;
         int row = out_row(l, rb * 8 + 4 * h + t), col = fwd_slot_col(l, ob * 32 + i);
-        if (row >= 0 && col >= 0) val = params[weight_off(l) + row * layer_k(l) + col];
-    } else {
-        int l = 0;
-        while (l + 1 < kLayers && idx >= bias_pack_off(l + 1)) ++l;
-        int local = idx - bias_pack_off(l);
-        int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
-        int row = out_row(l, nb * 32 + acc_row(r, h));
-        if (row >= 0) val = params[bias_off(l) + row];
+        return (row >= 0 && col >= 0) ? weight_off(l) + row * layer_k(l) + col : -1;
     }
-    packed[idx] = val;
+    int l = 0;
+    while (l + 1 < kLayers && idx >= bias_pack_off(l + 1)) ++l;
+    int local = idx - bias_pack_off(l);
+    int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
+    int row = out_row(l, nb * 32 + acc_row(r, h));
+    return row >= 0 ? bias_off(l) + row : -1;
 }
+
+__global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ packed) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kPackedFloats) return;
+    const int src = pack_source(idx);
+    packed[idx] = src >= 0 ? params[src] : 0.f;
+}
+
+__global__ void pack_index_kernel(int* __restrict__ index) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < kPackedFloats) index[idx] = pack_source(idx);
+}
+
+// four packed floats per thread: 16-byte index load, four L2-resident gathers, 16-byte store
+__global__ void pack_gather_kernel(const float* __restrict__ params, const int4* __restrict__ index, f32x4* __restrict__ packed) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kPackedFloats / 4) return;
+    const int4 s = index[i];
+    packed[i] = f32x4{s.x >= 0 ? params[s.x] : 0.f, s.y >= 0 ? params[s.y] : 0.f, s.z >= 0 ? params[s.z] : 0.f, s.w >= 0 ? params[s.w] : 0.f};
+}
+static_assert(kPackedFloats % 4 == 0, "packed image is a whole number of float4");
 
 // ---------------------------------------------------------------------------------------
 // positional encoding in MFMA slot order
@@ -338,6 +356,21 @@ extern "C" int niw_mlp_pack_weights(const float* params, float* packed, niw_stre
     const int threads = 256, blocks = (kPackedFloats + threads - 1) / threads;
     pack_weights_kernel<<<blocks, threads, 0, (hipStream_t)stream>>>(params, packed);
     NIW_LAUNCH_CHECK("niw_mlp_pack_weights");
+    return NIW_OK;
+}
+
+extern "C" int niw_mlp_pack_index(int32_t* index, niw_stream_t stream) {
+    NIW_REQUIRE(index, "niw_mlp_pack_index: null pointer");
+    pack_index_kernel<<<(kPackedFloats + 255) / 256, 256, 0, (hipStream_t)stream>>>(index);
+    NIW_LAUNCH_CHECK("niw_mlp_pack_index");
+    return NIW_OK;
+}
+
+extern "C" int niw_mlp_pack_weights_indexed(const float* params, const int32_t* index, float* packed, niw_stream_t stream) {
+    NIW_REQUIRE(params && index && packed, "niw_mlp_pack_weights_indexed: null pointer");
+    pack_gather_kernel<<<(kPackedFloats / 4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, reinterpret_cast<const int4*>(index),
+                                                                                            reinterpret_cast<f32x4*>(packed));
+    NIW_LAUNCH_CHECK("niw_mlp_pack_weights_indexed");
     return NIW_OK;
 }
 

@@ -175,7 +175,20 @@ class FieldState:
         forward used."""
         return self._held if self._held is not None else self._pack()
 
+    _index = {}          # device -> gather table of the packed layout (architecture constant, built once)
+
     def _pack(self):
+        n = _lib.load().niw_mlp_packed_floats()
+        key = str(self.flat.device)
+        if key not in FieldState._index:
+            idx = torch.empty(n, device=self.flat.device, dtype=torch.int32)
+            _lib.call("niw_mlp_pack_index", _p(idx), _stream())
+            FieldState._index[key] = idx
+        packed = torch.empty(n, device=self.flat.device, dtype=torch.float32)
+        _lib.call("niw_mlp_pack_weights_indexed", _p(self.flat), _p(FieldState._index[key]), _p(packed), _stream())
+        return packed
+
+    def _pack_decode(self):
         n = _lib.load().niw_mlp_packed_floats()
         packed = torch.empty(n, device=self.flat.device, dtype=torch.float32)
         _lib.call("niw_mlp_pack_weights", _p(self.flat), _p(packed), _stream())

@@ -220,3 +220,11 @@ def test_density_noise_regularisation_path():
     (rgb.sum() + sig.sum()).backward()
     for n, prm in zip(names, params):
         relclose(prm.grad, pr[n].grad, 5e-3)
+
+
+def test_indexed_weight_packing_equals_the_direct_packing():
+    from neural_invertible_warp_amd import ops
+    _, _, st, _ = _field(31)
+    assert torch.equal(st._pack(), st._pack_decode())
+    idx = ops.FieldState._index[str(st.flat.device)]
+    assert int((idx >= 0).sum()) >= 2 * 527872 and int(idx.max()) < st.flat.numel()      # every weight appears in both packings
