@@ -3,15 +3,15 @@ import numpy as np, torch
 from neural_invertible_warp_amd import _lib
 _lib.LIB_PATH = os.environ.get('NIW_STAMP_LIB', 'scratch/stampbuild/libniw_hip.so')
 from neural_invertible_warp_amd import ops
-from oracle import niw_oracle as O
 dev='cuda:0'
-p=O.make_nerf_params(1)
-flat=torch.cat([p[f"{n}.{k}"].reshape(-1) for n,_,_ in O.nerf_layer_shapes() for k in ("weight","bias")]).to(dev)
+SHAPES=[(256,63),(256,256),(256,256),(256,256),(256,319),(256,256),(256,256),(257,256),(128,283),(3,128)]   # nn.Linear [out,in] of the 10 layers
+g=torch.Generator().manual_seed(1)
+flat=torch.cat([torch.cat([(torch.rand(o*i,generator=g)*2-1)*(6/(o+i))**0.5, (torch.rand(o,generator=g)-0.5)*0.1]) for o,i in SHAPES]).to(dev)
 st=ops.FieldState(flat)
 N,S=4086,192
 center=torch.randn(N,3,device=dev); ray=torch.randn(N,3,device=dev); depth=torch.rand(N,S,device=dev).sort(dim=1).values*4+0.5
 params=[]; off=0
-for n,ko,ki in O.nerf_layer_shapes():
+for ko,ki in SHAPES:
     for shp in ((ko,ki),(ko,)):
         m=shp[0]*(shp[1] if len(shp)>1 else 1)
         params.append(flat[off:off+m].view(shp).requires_grad_(True)); off+=m
