@@ -249,3 +249,28 @@ def test_full_image_render_is_independent_of_the_slice_size():
         b = graph.render_by_slices(opt, pose, intr=intr, mode="eval")
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_no_grad_renders_use_the_non_saving_kernel():
+    """Under torch.no_grad() the MLP must not run in training mode (saving 9.4 KB per sample) just because its
+    parameters require grad: needs_input_grad ignores the grad mode."""
+    from neural_invertible_warp_amd import ops
+    from neural_invertible_warp_amd.model import nerf
+    opt = mk_opt("cfg1_nerf_llff_repr", H=16, W=20, **{"nerf.sample_intvs": 16, "nerf.sample_intvs_fine": 16, "nerf.rand_rays": 64})
+    graph = nerf.Graph(opt)
+    pose, intr = g(_poses(1, torch.Generator().manual_seed(2))), g(_intr(16, 20))
+    ops.TIMING.enabled = True
+    ops.TIMING.reset()
+    try:
+        with torch.no_grad():
+            graph.render_by_slices(opt, pose, intr=intr, mode="eval")
+        torch.cuda.synchronize()
+        names = set(ops.TIMING.summary())
+        assert "mlp_fwd" in names and "mlp_fwd_train" not in names, names
+        ops.TIMING.reset()
+        graph.render(opt, pose, intr=intr, ray_idx=torch.arange(32, device=DEV), mode="train")
+        torch.cuda.synchronize()
+        assert "mlp_fwd_train" in set(ops.TIMING.summary())
+    finally:
+        ops.TIMING.enabled = False
+        ops.TIMING.reset()
