@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the full-image eval render (e.g. when profiling the train step)")
     args = ap.parse_args()
 
     import torch
@@ -175,7 +176,7 @@ def main():
                                     "NVP-warped rays, fwd+bwd+Adam", rays_per_gpu=B * R, samples_per_ray="64+192",
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=f"ray-shard dp{world}", precision="exact fp32 MFMA"),
                loss=float(loss.all.detach()), roofline=roofline, kernels=kernels)
-    if world == 1:
+    if world == 1 and not args.no_forward_only:
         # forward-only figure of SURVEY section 8d: one full 300x400 image through the eval path of the same graph
         # (render_by_slices: slices of rand_rays rays, coarse + fine networks), outside the timed training region
         with torch.no_grad():
