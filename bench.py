@@ -15,6 +15,12 @@ Exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32); nothing is skipped or cache
 ray-samples = MLP evaluations per step = rays x (64 + 192), coarse and fine both counted
 (SURVEY section 8d).  Weak scaling: per-GPU work is fixed, rank r renders pixels idx[r::N] of a
 global draw N times larger.  Prints ONE JSON line on rank 0.
+
+Besides the contract fields the line carries `roofline` (dominant single MLP kernel: algorithmic FLOPs / mean launch time
+from device events on the launch stream vs the fp32-MFMA peak; `traffic` from the PMC passes in profiles/), `kernels` (per-kernel
+device-event averages of the timed steps), at N = 1 `forward_only` (one full 300x400 image through the eval path of the same
+graph, timed outside the training region; skip with --no-forward-only) and `cpu_baseline` (the CPU oracle's identical step on
+the host cores, bounded sample; skip with --no-cpu-baseline).
 """
 import argparse
 import json
