@@ -221,6 +221,7 @@ class _FieldMLP(torch.autograd.Function):
                       b3, bv, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
         ctx.save_ws, ctx.packed = save, packed
+        ctx.set_materialize_grads(False)
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(center, ray, depth, rgb)
         ctx.mark_non_differentiable()
@@ -294,6 +295,7 @@ class _Composite(torch.autograd.Function):
                       0.0 if bg is None else float(bg), _p(rgb), _p(depth), _p(opacity), _p(prob), _stream())
         ctx.save_for_backward(ray, rgb_s, sigma_s, depth_s)
         ctx.bg = bg
+        ctx.set_materialize_grads(False)      # unused outputs (depth, opacity, prob) arrive as None instead of zero-filled tensors
         return rgb, depth, opacity, prob
 
     @staticmethod
@@ -340,7 +342,7 @@ class _Warp(torch.autograd.Function):
         B, P = pts.shape[0], pts.shape[1]
         lib = _lib.load()
         ws = torch.empty(lib.niw_warp_bwd_workspace_floats(B, P), device=pts.device, dtype=torch.float32)
-        d_w_emb, d_view_b, d_w_head = torch.zeros_like(w_emb), torch.zeros_like(view_b), torch.zeros_like(w_head)
+        d_w_emb, d_view_b, d_w_head = torch.empty_like(w_emb), torch.empty_like(view_b), torch.empty_like(w_head)   # fully overwritten
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[3] else None
         _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, ctx.iw, _p(ps_a), _p(ps_b),
                   _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
@@ -370,6 +372,7 @@ class _WarpPrep(torch.autograd.Function):
         ctx.flat = flat
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(code)
+        ctx.set_materialize_grads(False)
         return w_emb, view_b, w_head
 
     @staticmethod
