@@ -52,9 +52,7 @@ class Graph(nerf_inn_llff.Graph):
         latent): warp_latent Embedding(n,128), warp_mlp DeformNetwork, global_rigid Embedding(n,12)."""
         assert opt.warp_latent.enc_type == "l2fbarf"
         self.warp_latent = torch.nn.Embedding(n_views, opt.warp_latent.embed_dim).to(opt.device)
-        self.warp_mlp = nvp_ndr.DeformNetwork(d_feature=opt.warp_latent.embed_dim, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3,
-                                              d_hidden=opt.inn.real_nvp.d_hidden, n_layers=1, skip_in=[],
-                                              multires=opt.inn.real_nvp.multires, weight_norm=True, actfn=opt.inn.actfn).to(opt.device)
+        self.warp_mlp = nvp_ndr.build_warp_network(opt, opt.warp_latent.embed_dim)
         pose = self.pose_eye[None].repeat(n_views, 1, 1)
         self.global_rigid = torch.nn.Embedding(n_views, 12, _weight=pose.reshape(-1, 12).clone()).to(opt.device)
         return self
@@ -73,17 +71,10 @@ class Graph(nerf_inn_llff.Graph):
             else:
                 grid_cam = var.grid_cam
             center_cam, grid_cam = center_cam.detach(), grid_cam.detach()
-            feat = self.warp_latent.weight                                   # whole table, not indexed by var.idx (:334)
-            if opt.inn.real_nvp.c2f == True:  # noqa: E712  (reference :351)
-                alpha_ratio = max(min(iter / opt.inn.real_nvp.max_pe_iter, 1), 0)
-            else:
-                alpha_ratio = 1
-            n = grid_cam.shape[1]
-            camera_coords_3D = torch.cat([grid_cam, center_cam], dim=1)
-            warped = self.warp_mlp.forward(feat, camera_coords_3D.unsqueeze(2), alpha_ratio=alpha_ratio)
-            grid_3D, center_3D = warped[:, :n], warped[:, n:]
-            ray = grid_3D - center_3D
-            return ray.squeeze(2), center_3D.squeeze(2), grid_3D.squeeze(2), alpha_ratio
+            # the whole latent table is used, not var.idx rows of it (reference :334)
+            alpha_ratio = nvp_ndr.embedding_anneal_ratio(opt, iter)
+            ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.warp_mlp, self.warp_latent.weight, grid_cam, center_cam, alpha_ratio)
+            return ray, center_3D, grid_3D, alpha_ratio
         if mode in ["val", "eval", "test-optim"]:
             sim3 = self.sim3
             center = torch.zeros(1, 1, 3, device=opt.device)

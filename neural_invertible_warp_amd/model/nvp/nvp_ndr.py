@@ -133,3 +133,33 @@ class DeformNetwork(torch.nn.Module):
         """reference nvp_ndr.py:471-567 (gradient-free: only debug helpers call it)"""
         with torch.no_grad():
             return self._apply_warp(deformation_code, input_pts, alpha_ratio, inverse=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Helpers shared by the two users of the warp: the LLFF graph (barf_inn_llff.Graph.attach_warp / get_pose) and the DTU
+# pose network (pose_models.inn.INNPoseParams).  Both build the same network, anneal its embedding the same way and
+# push [grid ; centre] points through it per view.
+# ---------------------------------------------------------------------------------------------------------------
+
+def build_warp_network(opt, latent_dim):
+    """The DeformNetwork every INN model instantiates (barf_inn_llff.py:54-55, pose_models/inn.py:23-27)."""
+    nvp = opt.inn.real_nvp
+    return DeformNetwork(d_feature=latent_dim, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3, d_hidden=nvp.d_hidden, n_layers=1, skip_in=[],
+                         multires=nvp.multires, weight_norm=True, actfn=opt.inn.actfn).to(opt.device)
+
+
+def embedding_anneal_ratio(opt, it):
+    """alpha of the warp's annealed embedder: it / max_pe_iter clamped to [0,1] under c2f, else 1 (barf_inn_llff.py:351-354)"""
+    nvp = opt.inn.real_nvp
+    if nvp.c2f == True:  # noqa: E712  (the reference compares with == True; yaml may hold None)
+        return max(min(it / nvp.max_pe_iter, 1), 0)
+    return 1
+
+
+def warp_grid_and_center(net, code, grid, center, alpha_ratio):
+    """grid, center [B,R,3] (gradient-free inputs) -> (ray, center_3D, grid_3D), each [B,R,3]: the points of every view go
+    through the view's warp as ONE batch [grid ; centre], rays are re-formed from the warped end points."""
+    n = grid.shape[1]
+    warped = net.forward(code, torch.cat([grid, center], dim=1).unsqueeze(2), alpha_ratio=alpha_ratio).squeeze(2)
+    grid_3D, center_3D = warped[:, :n], warped[:, n:]
+    return grid_3D - center_3D, center_3D, grid_3D

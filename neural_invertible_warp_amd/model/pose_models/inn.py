@@ -1,7 +1,12 @@
-"""Mirror of the reference's INNPoseParams (model/pose_models/inn.py:9-102): the DTU wrapper of
-the NVP warp.  Camera-frame grid / centre points are first moved to the world by the (noisy)
-initial poses (camera.py:382-384), then warped per view; the Kabsch registration of the result
-is stored, detached, in `pose_global` (inn.py:96-102)."""
+"""Pose parameterisation of the DTU INN model: the interface of the reference's `INNPoseParams`
+(model/pose_models/inn.py:9-102 -- constructor arguments, `pose_latent` / `pose_embedding` / `pose_global` modules and their
+state-dict keys, `get_w2c_poses`, `get_warped_rays_in_world`, `forward_inn`, `solve_for_global_transformation`,
+`grid_init` / `center_init`), expressed with the helpers the LLFF graph uses too (..nvp.nvp_ndr).
+
+Camera-frame pixel grid and centre points are first placed in the world by the (noisy) initial poses inside the ray
+generator (camera.py:382-384), then warped view by view; the rigid registration of the warped onto the initial points is
+kept, detached, as the current world-to-camera correction `pose_global` (what pose evaluation and the alignment loss read).
+"""
 import torch
 
 from ... import camera
@@ -12,51 +17,39 @@ from ..nvp import nvp_ndr
 class INNPoseParams(torch.nn.Module):
     def __init__(self, opt, num_poses, initial_poses_w2c, device="cuda"):
         super().__init__()
-        self.opt = opt
-        self.num_poses = num_poses
-        self.device = opt.device
+        dim = opt.inn.real_nvp.latent_dim
+        self.opt, self.num_poses, self.device = opt, num_poses, opt.device
         self.initial_poses_w2c = initial_poses_w2c
-        self.init_poses_embed()
+        self.grid_init = self.center_init = None          # refreshed by every get_warped_rays_in_world (the DTU graph's loss reads them)
+        self.pose_latent = torch.nn.Embedding(num_poses, dim).to(self.device)          # per-view code of the warp
+        self.pose_embedding = nvp_ndr.build_warp_network(opt, dim)                    # the warp itself
+        self.pose_global = torch.nn.Embedding(num_poses, 12).to(self.device)           # registered [R|t] per view, not trained
 
-    def init_poses_embed(self):
-        """reference inn.py:19-31"""
-        o = self.opt
-        self.pose_latent = torch.nn.Embedding(self.num_poses, o.inn.real_nvp.latent_dim).to(o.device)
-        self.pose_embedding = nvp_ndr.DeformNetwork(d_feature=o.inn.real_nvp.latent_dim, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3,
-                                                    d_hidden=o.inn.real_nvp.d_hidden, n_layers=1, skip_in=[],
-                                                    multires=o.inn.real_nvp.multires, weight_norm=True, actfn=o.inn.actfn).to(o.device)
-        self.pose_global = torch.nn.Embedding(self.num_poses, 12).to(o.device)
+    def _alpha(self, it):
+        return nvp_ndr.embedding_anneal_ratio(self.opt, it)
 
     def get_w2c_poses(self):
-        """reference inn.py:34-43"""
-        return self.pose_global.weight.data.detach().clone().view(-1, 3, 4)
-
-    def get_warped_rays_in_world(self, var, mode=None, iter=None):
-        """reference inn.py:63-77 -> ray, center_3D, grid_3D, each [B,R,3]"""
-        assert mode == "train"
-        self.center_init, self.grid_init = camera.get_unwarped_center_and_ray(self.opt, intr=var.intr, ray_idx=var.ray_idx,
-                                                                              pose_init=self.initial_poses_w2c)
-        center_init, grid_init = self.center_init.detach(), self.grid_init.detach()
-        out = self.forward_inn(center_init, grid_init, iter)
-        n = len(var.ray_idx)
-        grid_3D_pred = out[:, :n].squeeze(2)
-        center_3D_pred = out[:, n:].squeeze(2)
-        ray_pred = grid_3D_pred - center_3D_pred
-        self.solve_for_global_transformation(grid_3D_pred, center_3D_pred)
-        return ray_pred, center_3D_pred, grid_3D_pred
+        """[N,3,4] copy of the registered global correction"""
+        return self.pose_global.weight.detach().clone().reshape(self.num_poses, 3, 4)
 
     def forward_inn(self, centers, grids, iter):
-        """reference inn.py:81-93"""
-        feat = self.pose_latent.weight
-        o = self.opt.inn.real_nvp
-        alpha_ratio = max(min(iter / o.max_pe_iter, 1), 0) if o.c2f == True else 1  # noqa: E712
-        input_coords = torch.cat([grids, centers], dim=1).unsqueeze(2)
-        return self.pose_embedding.forward(feat, input_coords, alpha_ratio=alpha_ratio)
+        """[B,R,3] x 2 -> warped [B,2R,1,3], grid points first"""
+        stacked = torch.cat([grids, centers], dim=1)[:, :, None]
+        return self.pose_embedding(self.pose_latent.weight, stacked, alpha_ratio=self._alpha(iter))
+
+    def get_warped_rays_in_world(self, var, mode=None, iter=None):
+        """-> ray, center_3D, grid_3D, each [B,R,3] (training only)"""
+        if mode != "train":
+            raise AssertionError("INNPoseParams renders warped rays in training mode only")
+        self.center_init, self.grid_init = camera.get_unwarped_center_and_ray(self.opt, intr=var.intr, ray_idx=var.ray_idx,
+                                                                              pose_init=self.initial_poses_w2c)
+        ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.pose_embedding, self.pose_latent.weight, self.grid_init.detach(),
+                                                               self.center_init.detach(), self._alpha(iter))
+        self.solve_for_global_transformation(grid_3D, center_3D)
+        return ray, center_3D, grid_3D
 
     def solve_for_global_transformation(self, grid_pred, center_pred):
-        """reference inn.py:96-102"""
-        source = torch.cat([self.grid_init, self.center_init], dim=1)
-        target = torch.cat([grid_pred, center_pred], dim=1)
-        R_global, t_global = rigid_points_registration(target, source)
-        svd_poses = torch.cat((R_global, t_global[..., None]), -1)
-        self.pose_global.weight.data = svd_poses.detach().clone().view(-1, 12)
+        """Kabsch registration of the initial onto the warped points, kept detached in pose_global (reference :96-102)"""
+        R, t = rigid_points_registration(torch.cat([grid_pred, center_pred], dim=1), torch.cat([self.grid_init, self.center_init], dim=1))
+        with torch.no_grad():
+            self.pose_global.weight.data = torch.cat([R, t.unsqueeze(-1)], dim=-1).reshape(self.num_poses, 12).clone()

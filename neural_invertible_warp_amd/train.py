@@ -1,11 +1,13 @@
-"""Training entry point with the reference's command line and call sequence (train.py:9-32):
+"""Training entry point: the reference's command line and engine call sequence (train.py:9-32).
 
     python -m neural_invertible_warp_amd.train --model=barf_inn_llff --yaml=barf_inn_llff \\
         --barf_c2f=[0.1,0.5] --loss_weight.global_alignment=4 --data.scene=fern [--max_iter=N] [--options_dir=DIR]
 
-Multi-GPU: `python -m torch.distributed.run --nproc-per-node N -m neural_invertible_warp_amd.train ...` (rays are
-sharded over the ranks, gradients all-reduced; parallel.py).  Model modules are located by name like the reference does.
+Multi-GPU: `python -m torch.distributed.run --nproc-per-node N -m neural_invertible_warp_amd.train ...` (rays are sharded over the
+ranks, gradients all-reduced; parallel.py).  The engine class is looked up by model name, like the reference does, and driven
+through the same stages in the same order.
 """
+import contextlib
 import importlib
 import sys
 
@@ -13,22 +15,29 @@ import torch
 
 from . import options
 
+# the reference engine's stages, in call order; every `Model` class of this package implements them with (opt) arguments
+STAGES = ("load_dataset", "build_networks", "setup_optimizer", "restore_checkpoint", "setup_visualizer", "train")
+
+
+def build_options(argv):
+    opt = options.set(options.parse_arguments(argv))
+    options.save_options_file(opt)
+    return opt
+
+
+def run(opt):
+    """-> the engine object after training (its .graph / .it / .test_data are what callers inspect)"""
+    engine_cls = importlib.import_module("{}.model.{}".format(__package__, opt.model)).Model
+    on_gpu = opt.device != "cpu"
+    with (torch.cuda.device(opt.device) if on_gpu else contextlib.nullcontext()):
+        engine = engine_cls(opt)
+        for stage in STAGES:
+            getattr(engine, stage)(opt)
+    return engine
+
 
 def main(argv=None):
-    opt_cmd = options.parse_arguments(sys.argv[1:] if argv is None else argv)
-    opt = options.set(opt_cmd)
-    options.save_options_file(opt)
-    ctx = torch.cuda.device(opt.device) if opt.device != "cpu" else torch.device("cpu")
-    with ctx:
-        model = importlib.import_module("neural_invertible_warp_amd.model.{}".format(opt.model))
-        m = model.Model(opt)
-        m.load_dataset(opt)
-        m.build_networks(opt)
-        m.setup_optimizer(opt)
-        m.restore_checkpoint(opt)
-        m.setup_visualizer(opt)
-        m.train(opt)
-    return m
+    return run(build_options(sys.argv[1:] if argv is None else argv))
 
 
 if __name__ == "__main__":
