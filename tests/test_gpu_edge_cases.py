@@ -228,3 +228,36 @@ def test_indexed_weight_packing_equals_the_direct_packing():
     assert torch.equal(st._pack(), st._pack_decode())
     idx = ops.FieldState._index[str(st.flat.device)]
     assert int((idx >= 0).sum()) >= 2 * 527872 and int(idx.max()) < st.flat.numel()      # every weight appears in both packings
+
+
+def test_warp_operand_preparation_against_float64_autograd():
+    """niw_warp_prep_fwd / _bwd (weight norm, code projection, latent folding) directly against the same formulas in float64
+    torch with autograd: outputs 1e-6, every parameter / latent gradient 1e-5 of its scale."""
+    from neural_invertible_warp_amd import ops
+    net, wp = _warp_net()
+    B = 7
+    code = O.make_latent(9, B)
+    cg = g(code).requires_grad_(True)
+    w_emb, view_b, w_head = ops.warp_prepare(net.flat_params, list(net.parameters()), cg)
+    p = {k: v.double().requires_grad_(True) for k, v in wp.items()}
+    c64 = code.double().requires_grad_(True)
+    emb, vb, head = [], [], []
+    for b in range(3):
+        cb = c64 @ p[f"lin{b}_c.weight"].t() + p[f"lin{b}_c.bias"] + c64
+        per_view = []
+        for part, E in (("a", 26), ("b", 13)):
+            v_, g_ = p[f"lin{b}_{part}_0.weight_v"], p[f"lin{b}_{part}_0.weight_g"]
+            w = v_ * (g_ / v_.norm(dim=1, keepdim=True))
+            emb.append(w[:, :E].reshape(-1))
+            per_view.append(cb @ w[:, E:].t() + p[f"lin{b}_{part}_0.bias"])                 # [B,128]
+            head += [p[f"lin{b}_{part}_1.weight"].reshape(-1), p[f"lin{b}_{part}_1.bias"].reshape(-1)]
+        vb.append(torch.stack(per_view, dim=1))                                           # [B,2,128]
+    emb64, vb64, head64 = torch.cat(emb), torch.stack(vb, dim=1), torch.cat(head)         # vb64 [B,3,2,128]
+    close(w_emb, emb64.float(), atol=1e-6, rtol=1e-5); close(view_b, vb64.float(), atol=1e-6, rtol=1e-5); close(w_head, head64.float(), atol=0, rtol=0)
+    gen = torch.Generator().manual_seed(1)
+    ge, gv, gh = torch.randn(emb64.shape, generator=gen), torch.randn(vb64.shape, generator=gen), torch.randn(head64.shape, generator=gen)
+    ((emb64 * ge.double()).sum() + (vb64 * gv.double()).sum() + (head64 * gh.double()).sum()).backward()
+    ((w_emb * g(ge)).sum() + (view_b * g(gv)).sum() + (w_head * g(gh)).sum()).backward()
+    for k, prm in net.named_parameters():
+        relclose(prm.grad, p[k].grad.float(), 1e-5)
+    relclose(cg.grad, c64.grad.float(), 1e-5)
