@@ -261,3 +261,21 @@ def test_warp_operand_preparation_against_float64_autograd():
     for k, prm in net.named_parameters():
         relclose(prm.grad, p[k].grad.float(), 1e-5)
     relclose(cg.grad, c64.grad.float(), 1e-5)
+
+
+def test_fused_adam_matches_torch_adam():
+    """niw_adam_step over a flat buffer vs torch.optim.Adam on the CPU with the same gradients, 20 steps, odd length"""
+    from neural_invertible_warp_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    n = 100003
+    p0 = torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-3)
+    flat, m, v = g(p0.clone()), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for it in range(1, 21):
+        grad = torch.randn(n, generator=gen) * (1.0 if it % 3 else 1e-3)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step(flat, g(grad), m, v, 3e-3, it)
+    relclose(flat, ref.detach(), 2e-6)
+    relclose(m, opt.state[ref]["exp_avg"], 2e-6); relclose(v, opt.state[ref]["exp_avg_sq"], 2e-6)      # fma vs mul + add: last-bit differences
