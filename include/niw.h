@@ -218,7 +218,7 @@ int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx
 
 /* torch.optim.Adam step (model/nerf.py:34-38 uses it with default betas/eps) on a flat buffer. */
 int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                  float lr, float beta1, float beta2, float eps, int step, niw_stream_t stream);
+                  double lr, double beta1, double beta2, double eps, int step, niw_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ SIGNATURES = {
     "niw_kabsch_rotation_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "niw_kabsch_rotation_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _d, _f, _vp, _vp, _vp]),
-    "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
+    "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp]),
 }
 
 _lib = None

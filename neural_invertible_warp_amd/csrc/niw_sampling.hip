@@ -154,15 +154,15 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb,
 
 // ---------------------------------------------------------------- torch.optim.Adam (single tensor, no amsgrad / weight decay)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                            long long n, float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;        // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float mi = m[i] + w1 * (gi - m[i]);                 // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (w2 * gi) * gi;              // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;           // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+    p[i] -= step_size * (mi / denom);                         // addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
 }
 
 }  // namespace
@@ -224,11 +224,13 @@ extern "C" int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64
 }
 
 extern "C" int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                             float lr, float beta1, float beta2, float eps, int step, niw_stream_t stream) {
+                             double lr, double beta1, double beta2, double eps, int step, niw_stream_t stream) {
     NIW_REQUIRE(param && grad && exp_avg && exp_avg_sq, "niw_adam_step: null pointer");
     NIW_REQUIRE(n > 0 && step >= 1, "niw_adam_step: n=%lld step=%d", (long long)n, step);
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    adam_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+    // the scalars are formed in double like torch.optim.Adam forms them in Python floats, and rounded to fp32 once
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    adam_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
+                                                                        (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
     NIW_LAUNCH_CHECK("niw_adam_step");
     return NIW_OK;
 }

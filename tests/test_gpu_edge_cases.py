@@ -278,4 +278,4 @@ def test_fused_adam_matches_torch_adam():
         opt.step()
         ops.adam_step(flat, g(grad), m, v, 3e-3, it)
     relclose(flat, ref.detach(), 2e-6)
-    relclose(m, opt.state[ref]["exp_avg"], 2e-6); relclose(v, opt.state[ref]["exp_avg_sq"], 2e-6)      # fma vs mul + add: last-bit differences
+    relclose(m, opt.state[ref]["exp_avg"], 1e-6); relclose(v, opt.state[ref]["exp_avg_sq"], 1e-6)      # fma vs mul + add: last-bit differences
