@@ -279,3 +279,28 @@ def test_fused_adam_matches_torch_adam():
         ops.adam_step(flat, g(grad), m, v, 3e-3, it)
     relclose(flat, ref.detach(), 2e-6)
     relclose(m, opt.state[ref]["exp_avg"], 1e-6); relclose(v, opt.state[ref]["exp_avg_sq"], 1e-6)      # fma vs mul + add: last-bit differences
+
+
+def test_photometric_loss_kernel_direct():
+    """niw_mse_fwd_bwd vs torch: gather of image[:, :, ray_idx], mean over 3*B*R (or the global count under sharding), gradient"""
+    from neural_invertible_warp_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    B, H, W, R = 3, 10, 12, 17
+    image, rgb = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, R, 3, generator=gen).requires_grad_(True)
+    idx = torch.randperm(H * W, generator=gen)[:R]
+    target = image.view(B, 3, H * W).permute(0, 2, 1)[:, idx]
+    ref = ((rgb - target) ** 2).mean()
+    ref.backward()
+    r2 = g(rgb.detach()).requires_grad_(True)
+    loss = ops.mse_gather(r2, g(image), g(idx))
+    close(loss, ref, atol=1e-7, rtol=1e-6)
+    loss.backward()
+    relclose(r2.grad, rgb.grad, 1e-6)
+    # global normaliser of a sharded batch (twice the local element count): loss and gradient halve
+    r3 = g(rgb.detach()).requires_grad_(True)
+    half = ops.mse_gather(r3, g(image), g(idx), n_norm=2 * 3 * B * R)
+    half.backward()
+    close(half, ref / 2, atol=1e-7, rtol=1e-6); relclose(r3.grad, rgb.grad / 2, 1e-6)
+    # full image, no ray_idx (val / eval)
+    full = torch.rand(B, H * W, 3, generator=gen)
+    close(ops.mse_gather(g(full), g(image)), ((full - image.view(B, 3, H * W).permute(0, 2, 1)) ** 2).mean(), atol=1e-7, rtol=1e-6)
