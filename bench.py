@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: ray-samples/sec through the full warp -> MLP -> composite path.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg4-<scene>|cfg5] [--scaling weak|strong] [--shard-of K]
+    (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1]): nerf_inn_llff.yaml hyper-parameters on a 300x400 LLFF-fern
-shaped scene, 18 views x 227 rays (4096 // 18) per GPU, 64 coarse + 128 fine hierarchical
-samples (the fine network evaluates 192), rays produced by the NVP warp (barf_inn_llff get_pose).
-One step = the reference's train iteration on one batch: ray generation, warp, sampling, both
-MLPs, both composites, inverse-CDF resampling, photometric loss, full backward (NeRF, fine NeRF,
-warp, latents), gradient all-reduce (N > 1) and the Adam updates.  Synthetic images, reference
-initialisation (+ N(0, 0.02) on the warp's zero-initialised layers so the warp is non-trivial).
+Default workload = BASELINE.json configs[1] ("cfg2"): nerf_inn_llff.yaml hyper-parameters on a 300x400 LLFF-fern shaped scene,
+18 views x 227 rays (4096 // 18) per GPU, 64 coarse + 128 fine hierarchical samples (the fine network evaluates 192), rays
+produced by the NVP warp (barf_inn_llff get_pose).  The other BASELINE configs are selectable:
+    cfg3          scripts/train_llff.sh:1   barf_inn_llff fern: 18 views x 113 rays x 128 samples, c2f encoding, Kabsch alignment loss x 1e4
+    cfg4-<scene>  scripts/train_llff.sh:1-8 the same for one of the 8 LLFF scenes (18 ... 56 train views, 2048 // B rays per view)
+    cfg4          all 8 scenes, one train iteration of each per step (8 resident trainers)
+    cfg5          scripts/train_dtu.sh:6    barf_inn_dtu: 3 views x 682 rays x 128 samples, metric depth [1.2, 5.2], noisy initial poses,
+                                            alignment loss x 1e3
+One step = the reference's train iteration on one batch: ray generation, warp, sampling, MLP(s), composite(s), inverse-CDF
+resampling (cfg2), losses, full backward (NeRF, fine NeRF, warp, latents), gradient all-reduce (N > 1) and the Adam updates.
+Synthetic images, reference initialisation (+ N(0, 0.02) on the warp's zero-initialised layers so the warp is non-trivial).
 Exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32); nothing is skipped or cached.
 
-ray-samples = MLP evaluations per step = rays x (64 + 192), coarse and fine both counted
-(SURVEY section 8d).  Weak scaling: per-GPU work is fixed, rank r renders pixels idx[r::N] of a
-global draw N times larger.  Prints ONE JSON line on rank 0.
+ray-samples = MLP evaluations per step (coarse and fine both counted).  Scaling: `weak` (default) keeps the
+per-GPU ray count fixed (rank r renders pixels idx[r::N] of a global draw N times larger); `strong` keeps the reference's GLOBAL
+batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
+on one GPU: a proxy of what one rank of a K-GPU strong-scaled job executes (no collective).  Prints ONE JSON line on rank 0.
 
-Besides the contract fields the line carries `roofline` (dominant single MLP kernel: algorithmic FLOPs / mean launch time
-from device events on the launch stream vs the fp32-MFMA peak; `traffic` from the PMC passes in profiles/), `kernels` (per-kernel
-device-event averages of the timed steps), at N = 1 `forward_only` (one full 300x400 image through the eval path of the same
-graph, timed outside the training region; skip with --no-forward-only) and `cpu_baseline` (the CPU oracle's identical step on
-the host cores, bounded sample; skip with --no-cpu-baseline).
+Besides the contract fields the line carries `roofline` (dominant single MLP kernel: algorithmic FLOPs / mean launch time from
+device events on the launch stream vs the fp32-MFMA peak; `traffic` from the PMC passes in profiles/), `kernels` (per-kernel
+device-event averages of the timed steps), and at N = 1: `composite_scan` (the compositing kernels alone at full-image size: achieved
+HBM GB/s), `forward_only` (one full 300x400 image through the eval path), `psnr_parity` (HIP path vs CPU oracle, bounded run) and
+`cpu_baseline` (the CPU oracle's identical step on the host cores, bounded sample).  Each can be skipped with --no-<name>.
 """
 import argparse
 import json
@@ -33,10 +39,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_FWD = 2 * 527872           # algorithmic GEMM FLOPs per MLP evaluation
 PEAK_FP32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md chip table
-PEAK_HBM = 8000.0               # GB/s spec
+PEAK_HBM = 8000.0               # GB/s spec (6290 GB/s measured streaming copy)
 
 
-def cpu_baseline(B, S, Sf, H, W):
+def cpu_baseline(B, S, Sf, H, W, ga_weight=None):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to golden vectors) timed on
     this box's host cores on a bounded sample of the same workload: same views / resolution / samples per
     ray, fewer rays per view."""
@@ -49,9 +55,10 @@ def cpu_baseline(B, S, Sf, H, W):
         threads = os.cpu_count() or 1
     threads = max(1, min(threads, 64))
     torch.set_num_threads(threads)
-    R = 16                                                  # rays per view in the sample
+    R = max(2, 288 // B)                                    # rays per view in the sample (16 at 18 views)
     req = lambda d: {k: v.requires_grad_(True) for k, v in d.items()}
-    pc, pf, wp = req(O.make_nerf_params(1)), req(O.make_nerf_params(2)), req(O.make_warp_params(3, 0.02))
+    pc, wp = req(O.make_nerf_params(1)), req(O.make_warp_params(3, 0.02))
+    pf = req(O.make_nerf_params(2)) if Sf else None
     lat = O.make_latent(4, B).requires_grad_(True)
     gen = torch.Generator().manual_seed(0)
     image = torch.rand(B, 3, H, W, generator=gen)
@@ -62,13 +69,91 @@ def cpu_baseline(B, S, Sf, H, W):
         ray_idx = torch.randperm(H * W, generator=gen)[:R]
         u = torch.rand(B, R, S, 1, generator=gen)
         t0 = time.perf_counter()
-        out = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", 0.3, nerf_fine_p=pf, Sf=Sf, w3d=w3, wview=wv)
+        out = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", 0.3, nerf_fine_p=pf, Sf=Sf,
+                               ga_weight=ga_weight, w3d=w3, wview=wv)
         out["loss"].backward()
         times.append(time.perf_counter() - t0)
-    evals = B * R * (S + S + Sf)
+    evals = B * R * (S + (S + Sf if Sf else 0))
     best = min(times[1:])
     return dict(value=evals / best, unit="ray-samples/s", cores=threads, kind="port",
-                sample=f"{B} views x {R} rays x ({S}+{S + Sf}) samples = {evals} MLP evals per step, fwd+bwd, best of 2 after 1 warm-up, torch CPU {threads} threads")
+                sample=f"{B} views x {R} rays x ({S}" + (f"+{S + Sf}" if Sf else "") + f") samples = {evals} MLP evals per step, fwd+bwd, "
+                       f"best of 2 after 1 warm-up, torch CPU {threads} threads")
+
+
+def composite_scan(dev, iters=10):
+    """The compositing kernels alone at the size where they reach HBM (one 300x400 image: 120,000 rays x 192 samples, 0.55 GB forward):
+    achieved ALGORITHMIC bytes per second from device events.  tools/composite_bench.py is the stand-alone version the rocprofv3 PMC
+    passes of profiles/r2_composite_traffic.json run."""
+    import torch
+    from neural_invertible_warp_amd import ops
+    N, S = 120000, 192
+    gen = torch.Generator(device=dev).manual_seed(5)
+    ray = torch.randn(N, 3, device=dev, generator=gen)
+    rgb_s = torch.rand(N, S, 3, device=dev, generator=gen).requires_grad_(True)
+    sig = (torch.rand(N, S, device=dev, generator=gen) * 2).requires_grad_(True)
+    dep = (torch.rand(N, S, device=dev, generator=gen) * 0.9 / S + torch.arange(S, device=dev) / S + 1.0).contiguous()
+    g_rgb = torch.randn(N, 3, device=dev, generator=gen)
+    tf, tb = [], []
+    for i in range(iters + 2):
+        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        rgb_s.grad = sig.grad = None
+        a.record()
+        rgb = ops.composite(ray, rgb_s, sig, dep)[0]
+        b.record()
+        rgb.backward(g_rgb)
+        c.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            tf.append(a.elapsed_time(b))
+            tb.append(b.elapsed_time(c))
+    med = lambda v: sorted(v)[len(v) // 2]
+    bf, bb = N * S * 24 + N * 32, N * S * 36 + N * 36
+    return dict(workload=f"{N} rays x {S} samples (one 300x400 image, fine pass)", bound="hbm", unit="GB/s", peak=PEAK_HBM, achievable=6290.0,
+                fwd=dict(bytes=bf, us=round(med(tf) * 1e3, 1), achieved=round(bf / med(tf) / 1e6, 1), frac_of_peak=round(bf / med(tf) / 1e6 / PEAK_HBM, 4)),
+                bwd=dict(bytes=bb, us=round(med(tb) * 1e3, 1), achieved=round(bb / med(tb) / 1e6, 1), frac_of_peak=round(bb / med(tb) / 1e6 / PEAK_HBM, 4)),
+                bytes_per_sample=dict(fwd="12 rgb + 4 sigma + 4 depth in, 4 prob out", bwd="20 in, 12 d_rgb + 4 d_sigma out"))
+
+
+def build_workloads(name, dev, rank, world, scaling, shard_of):
+    """-> (list of (trainer, var0, B, R_local, S, Sf), description, rays of the global batch per scene)"""
+    from neural_invertible_warp_amd import configs, engine
+    eff_world, eff_rank = (shard_of, 0) if shard_of else (world, rank)
+    out, desc = [], None
+
+    def mk(opt, B, rays, warp_perturb=0.02, dtu=False):
+        opt.nerf.rand_rays = rays * (eff_world if scaling == "weak" else 1)        # global draw; each rank keeps idx[rank::world]
+        if dtu:
+            var0, init = engine.synthetic_dtu_scene(opt, B)
+            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, initial_poses_w2c=init)
+        else:
+            var0 = engine.synthetic_scene(opt, B)
+            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb)
+        R = (opt.nerf.rand_rays // B + eff_world - 1 - eff_rank) // eff_world       # rays per view on this rank
+        S = opt.nerf.sample_intvs
+        Sf = opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0
+        out.append((tr, var0, B, R, S, Sf))
+        return opt
+
+    if name == "cfg2":
+        mk(configs.cfg2_nerf_inn_llff_hier(device=dev), 18, 4096)
+        desc = "cfg2: nerf_inn_llff.yaml fern 300x400, 18 views x 227 rays x (64 coarse + 192 fine), NVP-warped rays, fwd+bwd+Adam"
+    elif name == "cfg3":
+        mk(configs.cfg3_barf_inn_llff(device=dev), 18, 2048)
+        desc = "cfg3: barf_inn_llff.yaml fern 300x400 (scripts/train_llff.sh:1), 18 views x 113 rays x 128, c2f PE, Kabsch alignment 1e4, fwd+bwd+Adam"
+    elif name.startswith("cfg4"):
+        scenes = list(configs.LLFF_TRAIN_VIEWS) if name == "cfg4" else [name.split("-", 1)[1]]
+        for sc in scenes:
+            if sc not in configs.LLFF_TRAIN_VIEWS:
+                raise SystemExit(f"unknown LLFF scene {sc!r}; choose from {list(configs.LLFF_TRAIN_VIEWS)}")
+            mk(configs.cfg3_barf_inn_llff(device=dev), configs.LLFF_TRAIN_VIEWS[sc], 2048)
+        desc = ("cfg4: barf_inn_llff.yaml, LLFF scenes " + ",".join(f"{s}({configs.LLFF_TRAIN_VIEWS[s]} views)" for s in scenes) +
+                ", 2048 // views rays per view x 128, one train iteration of every scene per step")
+    elif name == "cfg5":
+        mk(configs.cfg5_barf_inn_dtu(device=dev), 3, 2048, dtu=True)
+        desc = "cfg5: barf_inn_dtu.yaml scan65-shaped 300x400 (scripts/train_dtu.sh:6), 3 views x 682 rays x 128, metric depth [1.2,5.2], noisy_gt poses, alignment 1e3"
+    else:
+        raise SystemExit(f"unknown --config {name}")
+    return out, desc
 
 
 def main():
@@ -76,13 +161,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--shard-of", type=int, default=0, help="N=1 only: run rank 0's 1/K shard of the global batch (strong-scaling proxy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the full-image eval render (e.g. when profiling the train step)")
+    ap.add_argument("--no-composite-scan", action="store_true")
+    ap.add_argument("--no-psnr-parity", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="train step only: all four --no-* switches")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = args.no_forward_only = args.no_composite_scan = args.no_psnr_parity = True
 
     import torch
     import torch.distributed as dist
-    from neural_invertible_warp_amd import configs, engine, ops, parallel
+    from neural_invertible_warp_amd import ops, parallel
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # NIW_DIST_BACKEND=gloo + fewer GPUs than ranks is a logic test of the N>1 path on a 1-GPU box
@@ -91,20 +184,18 @@ def main():
     torch.cuda.set_device(local)
     rank, world, _ = parallel.init_from_env(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert not (args.shard_of and world > 1), "--shard-of is a single-GPU proxy"
     dev = f"cuda:{local}"
+    scaling = "strong" if args.shard_of else args.scaling
 
-    B, rays_per_gpu = 18, 4096
-    opt = configs.cfg2_nerf_inn_llff_hier(device=dev)
-    opt.nerf.rand_rays = rays_per_gpu * world                # global draw; each rank keeps idx[rank::world]
-    S, Sf = opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
-    trainer = engine.INNTrainer(opt, B, rank=rank, world=world, warp_perturb=0.02)
-    var0 = engine.synthetic_scene(opt, B)
-    R = (opt.nerf.rand_rays // B + world - 1 - rank) // world   # rays per view on this rank
-    evals_local = B * R * (S + S + Sf)
+    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of)
+    evals_local = sum(B * R * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
 
     def step():
-        var = type(var0)(var0)
-        return trainer.train_iteration(var)
+        loss = None
+        for tr, var0, *_ in loads:
+            loss = tr.train_iteration(type(var0)(var0))
+        return loss
 
     def fence():
         if world > 1:
@@ -142,18 +233,14 @@ def main():
     kernels = {}
     for name, (n, ms, units) in kern.items():
         entry = dict(launches=n, avg_ms=round(ms, 4), samples_per_launch=units)
-        if name.startswith("mlp_fwd"):
-            entry["tflops"] = units * FLOP_FWD / (ms * 1e-3) / 1e12
-        elif name == "mlp_bwd_dx":
-            entry["tflops"] = units * FLOP_FWD / (ms * 1e-3) / 1e12          # dX chain: same MAC count as the forward
-        elif name == "mlp_bwd_dw":
-            entry["tflops"] = units * FLOP_FWD / (ms * 1e-3) / 1e12          # dW: same MAC count (incl. reduce kernels)
+        if name.startswith("mlp_fwd") or name in ("mlp_bwd_dx", "mlp_bwd_dw"):
+            entry["tflops"] = units * FLOP_FWD / (ms * 1e-3) / 1e12          # dX chain and dW (incl. its reduce kernels): the forward's MAC count each
         elif name == "composite_fwd":
-            entry["gbps"] = units * 24.2 / (ms * 1e-3) / 1e9                  # 20 B/sample in + 4 B/sample prob + 20 B/ray out
+            entry["gbps"] = units * 24.2 / (ms * 1e-3) / 1e9                  # 20 B/sample in + 4 B/sample prob + 32 B/ray
         elif name == "composite_bwd":
-            entry["gbps"] = units * 40.2 / (ms * 1e-3) / 1e9                  # re-reads 20 + 4 (d_prob) B, writes 16 B per sample
+            entry["gbps"] = units * 36.2 / (ms * 1e-3) / 1e9                  # 20 B in, 16 B out per sample
         kernels[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in entry.items()}
-    # roofline: the dominant SINGLE kernel (mlp_bwd_dw is a group of 12 GEMM + 12 reduce launches and is listed
+    # roofline: the dominant SINGLE kernel (mlp_bwd_dw is a group of GEMM + reduce launches and is listed
     # under `kernels` only), so that its average can be checked against one row of the rocprofv3 summary
     rocprof_name = {"mlp_fwd_train": "mlp_fwd_kernel<true>", "mlp_fwd": "mlp_fwd_kernel<false>", "mlp_bwd_dx": "mlp_bwd_dx_kernel"}
     mlp = {k: v for k, v in kernels.items() if k in rocprof_name}
@@ -161,59 +248,77 @@ def main():
     roofline = None
     if dom:
         a = kernels[dom]["tflops"]
-        # HBM bytes per launch of that kernel: rocprofv3 PMC passes recorded in profiles/r1_traffic.json
-        # (FETCH_SIZE x2 + WRITE_SIZE, bytes per sample) times the samples one launch processes
+        # HBM bytes per launch of that kernel: rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE, bytes per
+        # sample) times the samples one launch processes; a pointer to the committed measurement, not measured in this run
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-                t = json.load(f)["bytes_per_sample"].get(dom)
-            if t:
-                traffic = dict(value=round((t["fetch_corrected"] + t["write"]) * kernels[dom]["samples_per_launch"] / 1e9, 3), unit="GB",
-                               source="profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
-        except (OSError, KeyError, ValueError):
-            pass
+        for fname in ("r2_traffic.json", "r1_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    t = json.load(f)["bytes_per_sample"].get(dom)
+                if t:
+                    traffic = dict(value=round((t["fetch_corrected"] + t["write"]) * kernels[dom]["samples_per_launch"] / 1e9, 3), unit="GB",
+                                   source=f"profiles/{fname} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         roofline = dict(bound="mfma", kernel=rocprof_name[dom], achieved=a, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=round(a / PEAK_FP32_MFMA, 4), traffic=traffic)
 
+    ms_step = dt / args.steps * 1e3
+    value = evals_total * args.steps / dt
+    par = f"ray-shard dp{world}" + (f" ({scaling} scaling)" if world > 1 else "") + (f"; 1/{args.shard_of} shard of the global batch" if args.shard_of else "")
     out = dict(metric="ray-samples/sec (warp+MLP+composite) on LLFF-fern, 1/2/4/8 GPUs + PSNR parity",
-               value=evals_total * args.steps / dt, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-               data="synthetic",
-               config=dict(workload="cfg2: nerf_inn_llff.yaml fern 300x400, 18 views x 227 rays x (64 coarse + 192 fine) per GPU, "
-                                    "NVP-warped rays, fwd+bwd+Adam", rays_per_gpu=B * R, samples_per_ray="64+192",
-                           mlp_evals_per_step_per_gpu=evals_local, parallelism=f"ray-shard dp{world}", precision="exact fp32 MFMA"),
+               value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=desc, name=args.config, rays_per_gpu=sum(B * R for _, _, B, R, _, _ in loads),
+                           samples_per_ray="+".join(str(x) for x in ((loads[0][4], loads[0][4] + loads[0][5]) if loads[0][5] else (loads[0][4],))),
+                           mlp_evals_per_step_per_gpu=evals_local, parallelism=par, precision="exact fp32 MFMA"),
+               frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4),
                loss=float(loss.all.detach()), roofline=roofline, kernels=kernels)
-    if world == 1 and not args.no_forward_only:
+    g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]
+    S, Sf = loads[0][4], loads[0][5]
+    if world == 1 and not args.no_composite_scan:
+        out["composite_scan"] = composite_scan(dev)
+    if world == 1 and not args.no_forward_only and not args.shard_of:
         # forward-only figure of SURVEY section 8d: one full 300x400 image through the eval path of the same graph
-        # (render_by_slices: slices of rand_rays rays, coarse + fine networks), outside the timed training region
+        # (render_by_slices: slices of rand_rays rays), outside the timed training region
         with torch.no_grad():
-            g = trainer.graph
             pose1, intr1 = torch.eye(3, 4, device=dev)[None], var0.intr[:1]
-            g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+            kw = dict(depth_range=[1.2, 5.2]) if args.config == "cfg5" else {}
+            g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(2):
-                g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+                g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
             torch.cuda.synchronize()
             t_img = (time.perf_counter() - t1) / 2
             # the same image in the largest slices one launch takes (nerf.eval_slice_rays; results are slice-independent)
             opt.nerf.eval_slice_rays = opt.H * opt.W
-            g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+            g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(2):
-                g.render_by_slices(opt, pose1, intr=intr1, mode="eval")
+                g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
             torch.cuda.synchronize()
             t_big = (time.perf_counter() - t1) / 2
             opt.nerf.eval_slice_rays = None
-        n_eval = opt.H * opt.W * (S + S + Sf)
+        n_eval = opt.H * opt.W * (S + (S + Sf if Sf else 0))
         out["forward_only"] = dict(value=n_eval / t_img, unit="ray-samples/s", ms_per_image=round(t_img * 1e3, 2),
-                                   workload=f"one {opt.H}x{opt.W} image, {S} coarse + {S + Sf} fine samples per ray, "
+                                   workload=f"one {opt.H}x{opt.W} image, {S} coarse" + (f" + {S + Sf} fine" if Sf else "") + " samples per ray, "
                                             f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} slices of {opt.nerf.rand_rays} rays",
                                    frac_of_fwd_roofline=round(n_eval / t_img * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4),
                                    largest_slices=dict(value=n_eval / t_big, ms_per_image=round(t_big * 1e3, 2),
                                                        frac_of_fwd_roofline=round(n_eval / t_big * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4)))
+    if world == 1 and not args.no_psnr_parity:
+        # the "+ PSNR parity" half of the metric, bounded: 10 identical optimisation steps on the HIP path and on the CPU oracle
+        from oracle import parity
+        pg, pc = parity.psnr_trajectories(dev, steps=10)
+        out["psnr_parity"] = dict(steps=len(pg), max_abs_diff_db=round(max(abs(a - b) for a, b in zip(pg, pc)), 5),
+                                  final_psnr_hip=round(pg[-1], 4), final_psnr_oracle=round(pc[-1], 4),
+                                  sample="barf_inn_llff, 3 views x 16 rays x 32 samples on 12x16 images, identical weights / pixel draws / stratified draws, "
+                                         "photometric PSNR of every step, HIP engine vs CPU oracle (autograd + torch.optim.Adam)")
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, S, Sf, opt.H, opt.W)
+        ga = {"cfg3": 4, "cfg5": 3}.get(args.config, 4 if args.config.startswith("cfg4") else None)
+        out["cpu_baseline"] = cpu_baseline(loads[0][2], S, Sf, opt.H, opt.W, ga_weight=ga)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -73,14 +73,17 @@ int niw_mlp_pack_weights_indexed(const float* params, const int32_t* index, floa
 /* NeRF.forward_samples (model/nerf.py:449-456) = get_3D_points_from_depth (camera.py:517-521)
  * + F.normalize + NeRF.forward (model/nerf.py:416-447) incl. positional_encoding
  * (model/nerf.py:476-483) with the BARF c2f band weights (model/barf_inn_llff.py:427-442).
- *   center, ray  [n_rays,3]; depth [n_rays,n_samples]; band_w3d[10], band_wview[4] host arrays
+ *   center, ray  [n_rays,3]; depth [n_rays,n_samples]
+ *   band_w3d[10], band_wview[4]  HOST arrays, copied into the launch (NULL = all ones)
+ *   band_dev     DEVICE array of 14 floats {w3d[10], wview[4]} or NULL; when given it overrides the host arrays and is
+ *                read by the kernel at run time, so a captured HIP graph replays with whatever the buffer then holds
  *   noise        [n_rays*n_samples] or NULL (density_noise_reg * randn, nerf.py:428-429)
  *   rgb [n_rays,n_samples,3], sigma [n_rays,n_samples]  (outputs)
  *   save         [NIW_SAVE_ROWS, Mpad] or NULL; non-NULL = training mode (activations kept
  *                for niw_mlp_bwd). */
-int niw_mlp_fwd(const float* packed, const float* params, const float* center, const float* ray,
+int niw_mlp_fwd(const float* packed, const float* center, const float* ray,
                 const float* depth, const float* noise, int64_t n_rays, int n_samples,
-                const float* band_w3d, const float* band_wview, int density_activ,
+                const float* band_w3d, const float* band_wview, const float* band_dev, int density_activ,
                 float* rgb, float* sigma, float* save, niw_stream_t stream);
 
 /* Backward of niw_mlp_fwd (autograd of model/nerf.py:416-456).
@@ -91,9 +94,8 @@ int niw_mlp_fwd(const float* packed, const float* params, const float* center, c
  *   d_center, d_ray [n_rays,3] or both NULL: ACCUMULATED (+=) gradients w.r.t. the rays
  *   (three routes of SURVEY section 8a: sample points and view directions; the ray-length
  *   route belongs to niw_composite_bwd). */
-int niw_mlp_bwd(const float* packed, const float* params, const float* center, const float* ray,
-                const float* depth, int64_t n_rays, int n_samples,
-                const float* band_w3d, const float* band_wview, int density_activ,
+int niw_mlp_bwd(const float* packed, const float* center, const float* ray,
+                const float* depth, int64_t n_rays, int n_samples, int density_activ,
                 const float* rgb, const float* d_rgb, const float* d_sigma,
                 const float* save, float* gradws, float* partial,
                 float* d_params, float* d_center, float* d_ray, niw_stream_t stream);

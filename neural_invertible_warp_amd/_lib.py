@@ -22,8 +22,8 @@ SIGNATURES = {
     "niw_mlp_pack_weights": (_i, [_vp, _vp, _vp]),
     "niw_mlp_pack_index": (_i, [_vp, _vp]),
     "niw_mlp_pack_weights_indexed": (_i, [_vp, _vp, _vp, _vp]),
-    "niw_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "niw_mlp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "niw_mlp_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_mlp_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_mlp_bwd_dw": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "niw_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -24,23 +24,22 @@ def get_child_state_dict(state_dict, key):
     return {".".join(k.split(".")[1:]): v for k, v in state_dict.items() if k.startswith("{}.".format(key))}
 
 
-def _gamma(lr0, lr_end, max_iter):
-    return (lr_end / lr0) ** (1.0 / max_iter) if lr_end else 1.0
-
-
 def _optimizers(trainer):
     """torch.optim.Adam / ExponentialLR shells with the reference's group layout -> dict(optim, optim_pose,
     sched, sched_pose) plus, per optimizer, the trainer group index behind each param group."""
-    opt, g = trainer.opt, trainer.graph
+    opt = trainer.opt
     n_nets = len(trainer.nets)
     o = opt.optim
     optim = torch.optim.Adam([dict(params=list(net.parameters()), lr=o.lr) for net in trainer.nets])
-    optim_pose = torch.optim.Adam([dict(params=list(g.warp_mlp.parameters()), lr=o.lr_pose),
-                                   dict(params=list(g.warp_latent.parameters()), lr=o.lr_pose)])
-    sched = torch.optim.lr_scheduler.ExponentialLR(optim, gamma=_gamma(o.lr, o.lr_end, opt.max_iter))
-    sched_pose = torch.optim.lr_scheduler.ExponentialLR(optim_pose, gamma=_gamma(o.lr_pose, o.lr_pose_end, opt.max_iter))
+    # optim_pose: group 0 = warp network, group 1 = latent table; a group the options switch off
+    # (inn.optimize.enabled / warp_latent.optimize.enabled, barf_inn_llff.py:88-93) is absent, as in the reference
+    pose_modules = [(n_nets, trainer.warp_mlp), (n_nets + 1, trainer.warp_latent)]
+    pose_modules = [(gi, m) for gi, m in pose_modules if trainer.trainable[gi]]
+    optim_pose = torch.optim.Adam([dict(params=list(m.parameters()), lr=o.lr_pose) for _, m in pose_modules])
+    sched = torch.optim.lr_scheduler.ExponentialLR(optim, gamma=trainer.gammas[0])
+    sched_pose = torch.optim.lr_scheduler.ExponentialLR(optim_pose, gamma=trainer.gammas[n_nets])
     return dict(optim=optim, optim_pose=optim_pose, sched=sched, sched_pose=sched_pose), \
-        dict(optim=list(range(n_nets)), optim_pose=[n_nets, n_nets + 1])
+        dict(optim=list(range(n_nets)), optim_pose=[gi for gi, _ in pose_modules])
 
 
 def _param_slices(trainer, gi):
@@ -60,8 +59,8 @@ def optimizer_state_dicts(trainer):
         optim = objs[name]
         for pg, gi in zip(optim.param_groups, groups[name]):
             where = _param_slices(trainer, gi)
-            lr0, lr_end = trainer.lrs[gi]
-            pg["lr"] = lr0 * _gamma(lr0, lr_end, trainer.opt.max_iter) ** it
+            lr0 = trainer.lrs[gi][0]
+            pg["lr"] = lr0 * trainer.gammas[gi] ** it
             pg["initial_lr"] = lr0
             if it == 0:
                 continue

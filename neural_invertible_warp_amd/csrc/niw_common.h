@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "niw.h"
 
 void niw_set_error(const char* fmt, ...);
@@ -23,6 +24,22 @@ void niw_set_error(const char* fmt, ...);
             return NIW_ERR_LAUNCH;                                                   \
         }                                                                            \
     } while (0)
+
+// Raise a kernel's dynamic-LDS limit once per device.  `cache` is a function-local static of the caller: one bit per device
+// ordinal, write-once (the only process-global state of the library: a read-mostly kernel-attribute cache; two threads racing
+// here both set the attribute, which is harmless).
+inline int niw_ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<unsigned long long>& cache, const char* what) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (cache.load(std::memory_order_acquire) & bit) return NIW_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        niw_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, bytes);
+        return NIW_ERR_LAUNCH;
+    }
+    cache.fetch_or(bit, std::memory_order_release);
+    return NIW_OK;
+}
 
 // Operand of the NT GEMM (niw_dw_gemm.hip): rows of samples, possibly blocked along the sample axis.
 struct NiwGemmOperand {

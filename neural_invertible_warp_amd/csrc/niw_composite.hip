@@ -1,11 +1,268 @@
 // Alpha compositing along rays: NeRF.composite (reference model/nerf.py:458-474), forward and
-// closed-form backward.  One 64-lane wave per ray; the transmittance
-// T_i = exp(-sum_{j<i} sigma_j delta_j) is a wave-level exclusive scan (shuffle ladder) with a
-// running carry across 64-sample chunks, the backward a suffix scan.  HBM-bound: 20 B/sample in.
+// closed-form backward.  HBM-bound: 20 B/sample in (+4 B/sample prob out) forward,
+// 20 (+4) B in and 16 B out per sample backward.
+//
+// Vector kernels (S % 4 == 0, 16-byte aligned rows -- every shipped configuration): a ray is owned by a GROUP of
+// G = 8 / 16 / 32 / 64 lanes (G = S/4 rounded up to a power of two), so a wave carries 64/G rays at once (four rays of
+// 64 samples, two of 128, one of 192 ...).  Every lane owns FOUR consecutive samples: sigma, depth and prob move as one
+// 16-byte access per lane, rgb as three (either directly, lane stride 48 B, or -- RGB_LDS -- as three fully coalesced
+// wave accesses transposed through LDS: 3 KiB per wave, conflict-free ds_read_b128 at a 12-dword lane stride).
+// The transmittance T_i = exp(-sum_{j<i} sigma_j delta_j) is a segmented wave scan: a serial exclusive prefix over the
+// lane's four samples plus a shuffle ladder of width G over the lane totals (shift-then-scan: an inclusive-minus-self
+// form would cancel catastrophically against the 1e10 closing interval); rays longer than 4G = 256 samples run in
+// chunks with a running carry.  The backward is the mirrored suffix scan of g_k w_k.
+// Any other shape (S % 4 != 0, unaligned views) takes the scalar one-wave-per-ray kernels at the end of the file.
 #include "niw_common.h"
 
 namespace {
 
+constexpr int kMaxChunks = 64;      // backward: LDS table of chunk prefixes, 256 samples per chunk -> S <= 16384
+
+template <int G>
+__device__ __forceinline__ float group_excl_scan_up(float v, int gl) {
+    // exclusive prefix over the G lanes of a group: shift by one lane, then an inclusive ladder
+    float s = __shfl_up(v, 1, G);
+    if (gl == 0) s = 0.f;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+        const float t = __shfl_up(s, o, G);
+        if (gl >= o) s += t;
+    }
+    return s;
+}
+template <int G>
+__device__ __forceinline__ float group_excl_scan_down(float v, int gl) {
+    float s = __shfl_down(v, 1, G);
+    if (gl == G - 1) s = 0.f;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+        const float t = __shfl_down(s, o, G);
+        if (gl + o < G) s += t;
+    }
+    return s;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+struct Quad {
+    float sig[4], dep[4], itv[4], sd[4], col[4][3];
+};
+
+// The lane's four samples of chunk `k` of its ray: sigma, depth, the interval to the next sample (1e10 after the
+// last one, nerf.py:461-462), sigma * (interval * |ray|) (nerf.py:463-464) and, when WITH_RGB, the colours.
+template <int G, bool RGB_LDS, bool WITH_RGB>
+__device__ __forceinline__ bool load_quad(Quad& q, const float* __restrict__ sg, const float* __restrict__ d, const float* __restrict__ c,
+                                          int S, int k, int gl, float len, float* __restrict__ lds_wave, int lane,
+                                          const float* __restrict__ c_wave, long long wave_span) {
+    const int s0 = k * 4 * G + 4 * gl;
+    const bool v = s0 < S;
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, d4 = s4;
+    if (v) {
+        s4 = *reinterpret_cast<const f32x4*>(sg + s0);
+        d4 = *reinterpret_cast<const f32x4*>(d + s0);
+    }
+    if (WITH_RGB) {
+        f32x4 c4[3];
+        if (RGB_LDS) {
+            // the wave's colours of this chunk are ONE contiguous span (wave_span floats from c_wave): three coalesced
+            // 1 KiB accesses -> LDS -> every lane reads back its own 12 floats
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const long long e = 4ll * (lane + 64 * j);
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (e < wave_span) t = *reinterpret_cast<const f32x4*>(c_wave + e);
+                *reinterpret_cast<f32x4*>(lds_wave + e) = t;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c4[j] = *reinterpret_cast<const f32x4*>(lds_wave + 12 * lane + 4 * j);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c4[j] = v ? *reinterpret_cast<const f32x4*>(c + 3 * s0 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) q.col[t / 3][t % 3] = c4[t / 4][t % 4];
+    }
+    // depth of the sample after the lane's last one: the next lane's first (the group's last lane: next chunk, if any)
+    float dn = __shfl_down(d4[0], 1, G);
+    if (gl == G - 1) dn = (s0 + 4 < S) ? d[s0 + 4] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        q.sig[t] = s4[t];
+        q.dep[t] = d4[t];
+    }
+    q.itv[0] = d4[1] - d4[0];
+    q.itv[1] = d4[2] - d4[1];
+    q.itv[2] = d4[3] - d4[2];
+    q.itv[3] = (s0 + 4 >= S) ? 1e10f : dn - d4[3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q.sd[t] = v ? q.sig[t] * (q.itv[t] * len) : 0.f;
+    return v;
+}
+
+template <int G, bool RGB_LDS>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                            const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                            long long n_rays, int S, int has_bg, float bg,
+                                                            float* __restrict__ rgb, float* __restrict__ depth,
+                                                            float* __restrict__ opacity, float* __restrict__ prob) {
+    __shared__ __attribute__((aligned(16))) float lds[RGB_LDS ? 4 * 768 : 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x % G;
+    constexpr int RPW = 64 / G;                                  // rays per wave
+    const long long r_wave = ((long long)blockIdx.x * 4 + wave) * RPW;
+    if (r_wave >= n_rays) return;                               // wave-uniform: no ray left for this wave
+    const long long r_raw = r_wave + lane / G;
+    const bool live = r_raw < n_rays;
+    const long long r = live ? r_raw : n_rays - 1;              // idle groups shadow the last ray (no stores)
+    const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
+    const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float* d = depth_s + r * S;
+    const float* sg = sigma_s + r * S;
+    const float* c = rgb_s + r * S * 3;
+    const int n_chunks = (S + 4 * G - 1) / (4 * G);
+    float carry = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, ao = 0.f;
+    for (int k = 0; k < n_chunks; ++k) {
+        Quad q;
+        // RGB_LDS: the colours of the wave's rays of this chunk start at ray r_wave, sample k*4G and run on contiguously
+        const float* c_wave = rgb_s + (r_wave * S + (long long)k * 4 * G) * 3;
+        const long long span_rays = n_rays - r_wave < RPW ? n_rays - r_wave : RPW;
+        const long long wave_span = RPW > 1 ? span_rays * S * 3 : 3ll * (S - k * 4 * G < 4 * G ? S - k * 4 * G : 4 * G);
+        const bool v = load_quad<G, RGB_LDS, true>(q, sg, d, c, S, k, gl, len, lds + (RGB_LDS ? wave * 768 : 0), lane, c_wave, wave_span);
+        const float e1 = q.sd[0], e2 = e1 + q.sd[1], e3 = e2 + q.sd[2], tot = e3 + q.sd[3];
+        const float base = carry + group_excl_scan_up<G>(tot, gl);
+        const float ex[4] = {base, base + e1, base + e2, base + e3};
+        f32x4 w4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float w = v ? expf(-ex[t]) * (1.f - expf(-q.sd[t])) : 0.f;
+            w4[t] = w;
+            a0 += w * q.col[t][0];
+            a1 += w * q.col[t][1];
+            a2 += w * q.col[t][2];
+            ad += w * q.dep[t];
+            ao += w;
+        }
+        if (v && live && prob) *reinterpret_cast<f32x4*>(prob + r * S + k * 4 * G + 4 * gl) = w4;
+        if (k + 1 < n_chunks) carry = __shfl(base + tot, G - 1, G);      // every lane is valid when another chunk follows
+    }
+    a0 = group_sum<G>(a0); a1 = group_sum<G>(a1); a2 = group_sum<G>(a2); ad = group_sum<G>(ad); ao = group_sum<G>(ao);
+    if (gl == 0 && live) {
+        if (has_bg) { const float t = bg * (1.f - ao); a0 += t; a1 += t; a2 += t; }
+        rgb[r * 3] = a0; rgb[r * 3 + 1] = a1; rgb[r * 3 + 2] = a2;
+        depth[r] = ad;
+        opacity[r] = ao;
+    }
+}
+
+template <int G, bool RGB_LDS>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                            const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                            long long n_rays, int S, int has_bg, float bg,
+                                                            const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                            const float* __restrict__ g_opacity, const float* __restrict__ g_prob,
+                                                            float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s,
+                                                            float* __restrict__ d_ray) {
+    __shared__ __attribute__((aligned(16))) float lds[RGB_LDS ? 4 * 768 : 4];
+    __shared__ float chunk_prefix[G == 64 ? 4 * kMaxChunks : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x % G;
+    constexpr int RPW = 64 / G;
+    const long long r_wave = ((long long)blockIdx.x * 4 + wave) * RPW;
+    if (r_wave >= n_rays) return;                               // wave-uniform: no ray left for this wave
+    const long long r_raw = r_wave + lane / G;
+    const bool live = r_raw < n_rays;
+    const long long r = live ? r_raw : n_rays - 1;
+    const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
+    const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float* d = depth_s + r * S;
+    const float* sg = sigma_s + r * S;
+    const float* c = rgb_s + r * S * 3;
+    const float gr0 = g_rgb ? g_rgb[r * 3] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[r] : 0.f;
+    float go = g_opacity ? g_opacity[r] : 0.f;
+    if (has_bg) go -= bg * (gr0 + gr1 + gr2);
+    const int n_chunks = (S + 4 * G - 1) / (4 * G);
+    float* lds_wave = lds + (RGB_LDS ? wave * 768 : 0);
+    // pass 1 (rays of more than one chunk, G = 64): sum of sigma*delta in front of every chunk
+    if (G == 64 && n_chunks > 1) {
+        float run = 0.f;
+        for (int k = 0; k < n_chunks; ++k) {
+            Quad q;
+            load_quad<G, false, false>(q, sg, d, c, S, k, gl, len, nullptr, lane, nullptr, 0);
+            if (gl == 0) chunk_prefix[wave * kMaxChunks + k] = run;
+            run += group_sum<G>((q.sd[0] + q.sd[1]) + (q.sd[2] + q.sd[3]));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // pass 2: chunks in reverse with a suffix carry of g_k w_k
+    float suffix = 0.f, dlen = 0.f;
+    for (int k = n_chunks - 1; k >= 0; --k) {
+        Quad q;
+        const float* c_wave = rgb_s + (r_wave * S + (long long)k * 4 * G) * 3;
+        const long long span_rays = n_rays - r_wave < RPW ? n_rays - r_wave : RPW;
+        const long long wave_span = RPW > 1 ? span_rays * S * 3 : 3ll * (S - k * 4 * G < 4 * G ? S - k * 4 * G : 4 * G);
+        const bool v = load_quad<G, RGB_LDS, true>(q, sg, d, c, S, k, gl, len, lds_wave, lane, c_wave, wave_span);
+        const int s0 = k * 4 * G + 4 * gl;
+        f32x4 gp = {0.f, 0.f, 0.f, 0.f};
+        if (v && g_prob) gp = *reinterpret_cast<const f32x4*>(g_prob + r * S + s0);
+        const float e1 = q.sd[0], e2 = e1 + q.sd[1], e3 = e2 + q.sd[2], tot = e3 + q.sd[3];
+        const float first = (G == 64 && n_chunks > 1) ? chunk_prefix[wave * kMaxChunks + k] : 0.f;
+        const float base = first + group_excl_scan_up<G>(tot, gl);
+        const float ex[4] = {base, base + e1, base + e2, base + e3};
+        float T[4], E[4], w[4], g[4], gw[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            T[t] = expf(-ex[t]);
+            E[t] = expf(-q.sd[t]);
+            w[t] = v ? T[t] * (1.f - E[t]) : 0.f;
+            g[t] = v ? gr0 * q.col[t][0] + gr1 * q.col[t][1] + gr2 * q.col[t][2] + gd * q.dep[t] + go + gp[t] : 0.f;
+            gw[t] = g[t] * w[t];
+        }
+        // sum_{j>i} g_j w_j = later samples of the lane + later lanes of the group + later chunks
+        const float b2 = gw[3], b1 = b2 + gw[2], b0 = b1 + gw[1], btot = b0 + gw[0];
+        const float after = suffix + group_excl_scan_down<G>(btot, gl);
+        const float aft[4] = {after + b0, after + b1, after + b2, after};
+        f32x4 ds4, dc4[3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float ds = g[t] * (T[t] * E[t]) - aft[t];           // dL/d(sigma*delta)
+            ds4[t] = ds * (q.itv[t] * len);
+            if (v) dlen += ds * (q.sig[t] * q.itv[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) dc4[t / 4][t % 4] = w[t / 3] * (t % 3 == 0 ? gr0 : t % 3 == 1 ? gr1 : gr2);
+        if (v && live) *reinterpret_cast<f32x4*>(d_sigma_s + r * S + s0) = ds4;
+        if (RGB_LDS) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(lds_wave + 12 * lane + 4 * j) = dc4[j];
+            __builtin_amdgcn_wave_barrier();
+            float* o_wave = d_rgb_s + (r_wave * S + (long long)k * 4 * G) * 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const long long e = 4ll * (lane + 64 * j);
+                if (e < wave_span) *reinterpret_cast<f32x4*>(o_wave + e) = *reinterpret_cast<const f32x4*>(lds_wave + e);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (v && live) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(d_rgb_s + (r * S + s0) * 3 + 4 * j) = dc4[j];
+        }
+        if (k > 0) suffix = __shfl(after + btot, 0, G);
+    }
+    dlen = group_sum<G>(dlen);
+    if (gl == 0 && live) {
+        const float inv = len > 0.f ? dlen / len : 0.f;
+        d_ray[r * 3] = inv * rx; d_ray[r * 3 + 1] = inv * ry; d_ray[r * 3 + 2] = inv * rz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// scalar fallback: one 64-lane wave per ray, one sample per lane, 64-sample chunks (any S >= 2, any alignment)
+// ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -27,17 +284,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-
-// sigma*delta of sample s (reference: dist = intv * ray_length; sigma_delta = density * dist)
 __device__ __forceinline__ float interval(const float* __restrict__ d, int s, int S) {
     return s == S - 1 ? 1e10f : d[s + 1] - d[s];
 }
 
-__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
-                                                            const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
-                                                            long long n_rays, int S, int has_bg, float bg,
-                                                            float* __restrict__ rgb, float* __restrict__ depth,
-                                                            float* __restrict__ opacity, float* __restrict__ prob) {
+__global__ __launch_bounds__(256) void composite_fwd_scalar_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                                   const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                                   long long n_rays, int S, int has_bg, float bg,
+                                                                   float* __restrict__ rgb, float* __restrict__ depth,
+                                                                   float* __restrict__ opacity, float* __restrict__ prob) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rays) return;
@@ -55,8 +310,6 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
             dv = d[s];
             sd = sg[s] * (interval(d, s, S) * len);
         }
-        // exclusive scan: shift by one lane first (an inclusive-minus-self form would cancel
-        // catastrophically against the 1e10 closing interval)
         float sh = __shfl_up(sd, 1);
         if (lane == 0) sh = 0.f;
         const float excl = carry + wave_incl_scan(sh, lane);
@@ -81,14 +334,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
-                                                            const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
-                                                            long long n_rays, int S, int has_bg, float bg,
-                                                            const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
-                                                            const float* __restrict__ g_opacity, const float* __restrict__ g_prob,
-                                                            float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s,
-                                                            float* __restrict__ d_ray) {
-    __shared__ float chunk_prefix[4][17];
+__global__ __launch_bounds__(256) void composite_bwd_scalar_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                                   const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                                   long long n_rays, int S, int has_bg, float bg,
+                                                                   const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                                   const float* __restrict__ g_opacity, const float* __restrict__ g_prob,
+                                                                   float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s,
+                                                                   float* __restrict__ d_ray) {
+    __shared__ float chunk_prefix[4][4 * kMaxChunks];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long r = (long long)blockIdx.x * 4 + wv;
     if (r >= n_rays) return;
@@ -101,7 +354,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     const float gd = g_depth ? g_depth[r] : 0.f;
     float go = g_opacity ? g_opacity[r] : 0.f;
     if (has_bg) go -= bg * (gr0 + gr1 + gr2);
-    // pass 1: prefix of sigma*delta at the start of every chunk
     const int n_chunks = (S + 63) / 64;
     float carry = 0.f;
     for (int k = 0; k < n_chunks; ++k) {
@@ -111,7 +363,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         carry += wave_sum(sd);
     }
     __builtin_amdgcn_wave_barrier();
-    // pass 2: chunks in reverse with a suffix carry of g_k w_k
     float suffix = 0.f, dlen = 0.f;
     for (int k = n_chunks - 1; k >= 0; --k) {
         const int s = k * 64 + lane;
@@ -130,11 +381,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         const float T = expf(-excl), e = expf(-sd);
         const float w = v ? T * (1.f - e) : 0.f;
         const float gw = g * w;
-        // sum_{k>i} g_k w_k = (inclusive suffix within chunk) - own + carry from later chunks
         float shd = __shfl_down(gw, 1);
         if (lane == 63) shd = 0.f;
         const float after = suffix + wave_suffix_incl_scan(shd, lane);
-        const float ds = g * (T * e) - after;           // dL/d(sigma*delta)
+        const float ds = g * (T * e) - after;
         if (v) {
             d_sigma_s[r * S + s] = ds * (itv * len);
             d_rgb_s[(r * S + s) * 3] = w * gr0;
@@ -151,6 +401,22 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     }
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int group_lanes(int S) {
+    const int need = (S + 3) / 4;
+    return need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+}
+// colours through LDS whenever a wave's colours of a chunk form one contiguous span: one ray per wave, or rays that
+// fill their groups exactly
+inline bool rgb_through_lds(int G, int S) {
+#ifdef NIW_COMPOSITE_NO_LDS      // diagnostic build (tools/composite_bench.py): colours by 48-byte-strided 16-byte accesses
+    (void)G; (void)S;
+    return false;
+#else
+    return G == 64 || S == 4 * G;
+#endif
+}
+
 }  // namespace
 
 extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s,
@@ -161,9 +427,22 @@ extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const flo
     // reference nerf.py:461-462 builds the closing 1e10 interval with empty_like(intervals[..., :1]): with a single sample
     // that slice is empty, the sample gets NO interval and every output is zero with an empty prob -- not reproduced
     NIW_REQUIRE(n_samples >= 2, "niw_composite_fwd: needs at least 2 samples per ray (the reference degenerates to all-zero outputs at S=1)");
-    const int blocks = (int)((n_rays + 3) / 4);
-    composite_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(ray, rgb_s, sigma_s, depth_s, n_rays, n_samples, has_bg, bg,
-                                                                 rgb, depth, opacity, prob);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = n_samples;
+    if (S % 4 == 0 && aligned16(rgb_s) && aligned16(sigma_s) && aligned16(depth_s) && (!prob || aligned16(prob))) {
+        const int G = group_lanes(S);
+        const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
+        const bool lds = rgb_through_lds(G, S);
+#define NIW_CFWD(GG, LL) composite_fwd_kernel<GG, LL><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob)
+        if (G == 8) { if (lds) NIW_CFWD(8, true); else NIW_CFWD(8, false); }
+        else if (G == 16) { if (lds) NIW_CFWD(16, true); else NIW_CFWD(16, false); }
+        else if (G == 32) { if (lds) NIW_CFWD(32, true); else NIW_CFWD(32, false); }
+        else { if (lds) NIW_CFWD(64, true); else NIW_CFWD(64, false); }
+#undef NIW_CFWD
+    } else {
+        const int blocks = (int)((n_rays + 3) / 4);
+        composite_fwd_scalar_kernel<<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob);
+    }
     NIW_LAUNCH_CHECK("niw_composite_fwd");
     return NIW_OK;
 }
@@ -173,10 +452,27 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
                                  const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_prob,
                                  float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream) {
     NIW_REQUIRE(ray && rgb_s && sigma_s && depth_s && d_rgb_s && d_sigma_s && d_ray, "niw_composite_bwd: null pointer");
-    NIW_REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= 1024, "niw_composite_bwd: need 2 <= S <= 1024 (S=%d)", n_samples);
-    const int blocks = (int)((n_rays + 3) / 4);
-    composite_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(ray, rgb_s, sigma_s, depth_s, n_rays, n_samples, has_bg, bg,
-                                                                 d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray);
+    NIW_REQUIRE(n_rays > 0 && n_samples >= 2, "niw_composite_bwd: need n_rays > 0 and S >= 2 (n_rays=%lld, S=%d)", (long long)n_rays, n_samples);
+    NIW_REQUIRE(n_samples <= 256 * kMaxChunks, "niw_composite_bwd: S=%d exceeds the %d samples per ray the chunk-prefix table holds",
+                n_samples, 256 * kMaxChunks);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = n_samples;
+    if (S % 4 == 0 && aligned16(rgb_s) && aligned16(sigma_s) && aligned16(depth_s) && aligned16(d_rgb_s) && aligned16(d_sigma_s) &&
+        (!d_prob || aligned16(d_prob))) {
+        const int G = group_lanes(S);
+        const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
+        const bool lds = rgb_through_lds(G, S);
+#define NIW_CBWD(GG, LL) composite_bwd_kernel<GG, LL><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray)
+        if (G == 8) { if (lds) NIW_CBWD(8, true); else NIW_CBWD(8, false); }
+        else if (G == 16) { if (lds) NIW_CBWD(16, true); else NIW_CBWD(16, false); }
+        else if (G == 32) { if (lds) NIW_CBWD(32, true); else NIW_CBWD(32, false); }
+        else { if (lds) NIW_CBWD(64, true); else NIW_CBWD(64, false); }
+#undef NIW_CBWD
+    } else {
+        const int blocks = (int)((n_rays + 3) / 4);
+        composite_bwd_scalar_kernel<<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity,
+                                                            d_prob, d_rgb_s, d_sigma_s, d_ray);
+    }
     NIW_LAUNCH_CHECK("niw_composite_bwd");
     return NIW_OK;
 }

@@ -212,11 +212,8 @@ int launch_gemm(NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int
     nsplit = (steps_total + per - 1) / per;
     const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
     auto kern = dw_gemm_kernel<WN, WK, NBW, KBW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_set{0ull};
+    if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM")) return rc;
     kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(A, B, spb, steps_total, per, partial, bias_side);
     NIW_LAUNCH_CHECK("NT GEMM");
     *nsplit_out = nsplit;
@@ -299,13 +296,11 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     return NIW_OK;
 }
 
-extern "C" int niw_mlp_bwd(const float* packed, const float* params, const float* center, const float* ray,
-                           const float* depth, int64_t n_rays, int n_samples,
-                           const float* band_w3d, const float* band_wview, int density_activ,
+extern "C" int niw_mlp_bwd(const float* packed, const float* center, const float* ray,
+                           const float* depth, int64_t n_rays, int n_samples, int density_activ,
                            const float* rgb, const float* d_rgb, const float* d_sigma,
                            const float* save, float* gradws, float* partial,
                            float* d_params, float* d_center, float* d_ray, niw_stream_t stream) {
-    (void)params; (void)band_w3d; (void)band_wview;
     int rc = niw_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
                             d_center, d_ray, stream);
     if (rc != NIW_OK) return rc;

@@ -213,6 +213,7 @@ struct MlpFwdArgs {
     int S, act;
     float w3d[NIW_L3D];
     float wview[NIW_LVIEW];
+    const float* band_dev;      // device copy of {w3d, wview} read at run time (HIP-graph replays), or NULL: the by-value copies above
 };
 
 __device__ __forceinline__ float density_act(float x, int kind) {
@@ -242,8 +243,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         u[0] = rx / nrm; u[1] = ry / nrm; u[2] = rz / nrm;
     }
     float enc[32], venc[16];
-    encode_slots<NIW_L3D, 8>(p, a.w3d, h, enc);
-    encode_slots<NIW_LVIEW, 4>(u, a.wview, h, venc);
+    {
+        float w3[NIW_L3D], wv[NIW_LVIEW];
+#pragma unroll
+        for (int i = 0; i < NIW_L3D; ++i) w3[i] = a.band_dev ? a.band_dev[i] : a.w3d[i];
+#pragma unroll
+        for (int i = 0; i < NIW_LVIEW; ++i) wv[i] = a.band_dev ? a.band_dev[NIW_L3D + i] : a.wview[i];
+        encode_slots<NIW_L3D, 8>(p, w3, h, enc);
+        encode_slots<NIW_LVIEW, 4>(u, wv, h, venc);
+    }
     // Workspace layout: plain feature-major [row][Mpad].  (A blocked [128-sample block][row][128]
     // image was measured 10-14 % slower for this kernel and the dX chain on MI355X.)
     // All hot-loop memory traffic uses buffer addressing (see niw_mlp_device.h): host guarantees 128*Mpad < 2^31.
@@ -374,11 +382,10 @@ extern "C" int niw_mlp_pack_weights_indexed(const float* params, const int32_t* 
     return NIW_OK;
 }
 
-extern "C" int niw_mlp_fwd(const float* packed, const float* params, const float* center, const float* ray,
+extern "C" int niw_mlp_fwd(const float* packed, const float* center, const float* ray,
                            const float* depth, const float* noise, int64_t n_rays, int n_samples,
-                           const float* band_w3d, const float* band_wview, int density_activ,
+                           const float* band_w3d, const float* band_wview, const float* band_dev, int density_activ,
                            float* rgb, float* sigma, float* save, niw_stream_t stream) {
-    (void)params;
     NIW_REQUIRE(packed && center && ray && depth && rgb && sigma, "niw_mlp_fwd: null pointer");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_fwd: n_rays=%lld n_samples=%d must be positive", (long long)n_rays, n_samples);
     NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 24), "niw_mlp_fwd: too many samples per call (%lld)", (long long)(n_rays * n_samples));
@@ -390,6 +397,7 @@ extern "C" int niw_mlp_fwd(const float* packed, const float* params, const float
     a.S = n_samples; a.act = density_activ;
     for (int i = 0; i < NIW_L3D; ++i) a.w3d[i] = band_w3d ? band_w3d[i] : 1.f;
     for (int i = 0; i < NIW_LVIEW; ++i) a.wview[i] = band_wview ? band_wview[i] : 1.f;
+    a.band_dev = band_dev;
     const int blocks = (int)(a.Mpad / 128);
     if (save)
         mlp_fwd_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(a);

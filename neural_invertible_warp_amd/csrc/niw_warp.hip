@@ -400,8 +400,8 @@ extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float
     if (rc != NIW_OK) return rc;
     NIW_REQUIRE(out, "niw_warp_fwd: null output");
     a.out = out; a.inverse = inverse;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
+    static std::atomic<unsigned long long> attr_set{0ull};
+    if (int rc2 = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(warp_fwd_kernel), kWarpLds, attr_set, "niw_warp_fwd")) return rc2;
     warp_fwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_fwd");
     return NIW_OK;
@@ -427,8 +427,8 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
     // padded columns of the factor rows must be zero
     if (ppad != (long long)n_views * n_pts)
         (void)hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWarpLds); attr = true; }
+    static std::atomic<unsigned long long> attr_set{0ull};
+    if (int rc2 = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(warp_bwd_kernel), kWarpLds, attr_set, "niw_warp_bwd")) return rc2;
     warp_bwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, st>>>(a);
     NIW_LAUNCH_CHECK("niw_warp_bwd");
     float* p1 = workspace + 3ll * kRowsPerBlock * ppad;

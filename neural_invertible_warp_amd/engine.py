@@ -1,45 +1,99 @@
-"""Thin training step around the Graph, honouring the reference engine's call sequence for one
-iteration (model/nerf_inn_llff.py:80-100 + model/barf_inn_llff.py:106-120 + model/base.py:130-142):
-zero_grad -> graph.forward(mode="train", iter=it) -> compute_loss -> summarize_loss (sum of
-10^w * loss) -> backward -> Adam(nerf) + Adam(warp_mlp, warp_latent) -> ExponentialLR ->
-progress = it / max_iter.  The Adam updates run as fused launches over flat buffers
-(niw_adam_step); under ray sharding the gradients of all groups are summed over ranks in one
-flat all-reduce first (..parallel.GradBucket).
+"""Training step around the Graph, with the call sequence of the reference engine for one iteration
+(model/nerf_inn_llff.py:80-100 + model/barf_inn_llff.py:106-120 / model/barf_inn_dtu.py:355-369 +
+model/base.py:130-142):
+
+    zero_grad -> graph.forward(mode="train", iter=it) -> compute_loss -> summarize_loss (sum of 10^w * loss)
+    -> backward -> Adam(nerf[, nerf_fine]) + Adam(warp network, latent table) -> ExponentialLR -> it += 1
+    -> progress = it / max_iter
+
+The Adam updates run as fused launches over flat buffers (niw_adam_step); under ray sharding the gradients of all
+groups are summed over ranks in ONE flat all-reduce first (..parallel.GradBucket).  Two model families share it:
+`barf_inn_llff` (warp modules on the graph) and `barf_inn_dtu` (warp inside INNPoseParams, metric depth from the data).
 """
+import math
+
 import torch
 
 from . import ops, parallel
-from .model import barf_inn_llff
+from ._lib import NiwError
 from .util import edict
 
 
+def _sched_gamma(lr0, lr_end, sched, max_iter, what):
+    """decay rate of the reference's scheduler block (nerf_inn_llff.py:40-47, barf_inn_llff.py:96-104)"""
+    if not sched:
+        return 1.0
+    kind = sched.get("type")
+    if kind != "ExponentialLR":
+        raise NiwError(f"{what}.type={kind!r}: the fused Adam step implements ExponentialLR (or no scheduler)")
+    if lr_end:
+        return (lr_end / lr0) ** (1.0 / max_iter)
+    return float(sched.get("gamma") or 1.0)
+
+
 class INNTrainer:
-    def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0):
-        self.opt, self.rank, self.world = opt, rank, world
+    def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None):
+        self.opt, self.rank, self.world, self.n_views = opt, rank, world, n_views
+        o = opt.optim
+        if o.get("algo", "Adam") != "Adam":
+            raise NiwError(f"optim.algo={o.algo!r}: only Adam is fused (niw_adam_step)")
         torch.manual_seed(seed)                       # identical initial weights on every rank
-        self.graph = barf_inn_llff.Graph(opt).attach_warp(opt, n_views)
+        self.family = "dtu" if opt.model == "barf_inn_dtu" else "llff"
+        if self.family == "dtu":
+            from .model import barf_inn_dtu
+            from .model.pose_models.inn import INNPoseParams
+            if initial_poses_w2c is None:
+                raise NiwError("barf_inn_dtu needs initial_poses_w2c (Model.set_initial_poses)")
+            self.pose_net = INNPoseParams(opt, num_poses=n_views, initial_poses_w2c=initial_poses_w2c, device=opt.device)
+            self.graph = barf_inn_dtu.Graph(opt, self.pose_net)
+            self.warp_mlp, self.warp_latent = self.pose_net.pose_embedding, self.pose_net.pose_latent
+            train_warp = train_latent = True          # barf_inn_dtu.py:341-345: both groups, unconditionally
+        else:
+            from .model import barf_inn_llff
+            self.graph = barf_inn_llff.Graph(opt).attach_warp(opt, n_views)
+            self.warp_mlp, self.warp_latent = self.graph.warp_mlp, self.graph.warp_latent
+            train_warp = bool(opt.inn.get("optimize", {}).get("enabled", True))
+            train_latent = bool(opt.warp_latent.get("optimize", {}).get("enabled", True))
         if warp_perturb:
             # the reference zero-initialises the last layer of every sub-network (identity warp);
             # a small perturbation makes the warp and its gradients non-trivial for benchmarking
             with torch.no_grad():
-                for name, p in self.graph.warp_mlp.named_parameters():
+                for name, p in self.warp_mlp.named_parameters():
                     if "_1." in name or "_c." in name:
                         p.normal_(0.0, warp_perturb)
         self.nets = [self.graph.nerf] + ([self.graph.nerf_fine] if opt.nerf.fine_sampling else [])
         # optimizer groups = the flat buffers the kernels read (NeRF nets, warp network) + the latent table
-        latent = self.graph.warp_latent.weight
+        latent = self.warp_latent.weight
         dev = latent.device
         self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets] +
-                                          [list(self.graph.warp_mlp.parameters()), [latent]], dev)
-        self.flats = [n.flat_params for n in self.nets] + [self.graph.warp_mlp.flat_params, latent.data.view(-1)]
-        self.m = [torch.zeros_like(f) for f in self.flats]
-        self.v = [torch.zeros_like(f) for f in self.flats]
-        o = opt.optim
-        self.lrs = [(o.lr, o.lr_end)] * len(self.nets) + [(o.lr_pose, o.lr_pose_end)] * 2
+                                          [list(self.warp_mlp.parameters()), [latent]], dev)
+        flats = self._flats()
+        self.m = [torch.zeros_like(f) for f in flats]
+        self.v = [torch.zeros_like(f) for f in flats]
+        g_main = _sched_gamma(o.lr, o.get("lr_end"), o.get("sched", {"type": "ExponentialLR"}), opt.max_iter, "optim.sched")
+        g_pose = _sched_gamma(o.lr_pose, o.get("lr_pose_end"), o.get("sched_pose", {"type": "ExponentialLR"}), opt.max_iter, "optim.sched_pose")
+        n = len(self.nets)
+        self.lrs = [(o.lr, o.get("lr_end"))] * n + [(o.lr_pose, o.get("lr_pose_end"))] * 2       # (checkpoint.py reads these)
+        self.gammas = [g_main] * n + [g_pose] * 2
+        self.trainable = [True] * n + [train_warp, train_latent]
+        self.warmup_pose = o.get("warmup_pose")
         self.it = 0
         if world > 1:
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)
+
+    def _flats(self):
+        """The flat parameter buffers the kernels read, looked up every step: re-flattening (after .to() or an external
+        re-assignment of parameter storage) replaces them, and Adam must update the buffer that is actually in use."""
+        return [n.flat_params for n in self.nets] + [self.warp_mlp.flat_params, self.warp_latent.weight.data.view(-1)]
+
+    def learning_rate(self, group, it):
+        """lr of optimizer group `group` in 0-based iteration `it` (scheduler stepped `it` times; the reference's linear
+        pose warm-up touches param_groups[0] of optim_pose only, i.e. the warp network: barf_inn_llff.py:108-111)"""
+        lr = self.lrs[group][0] * self.gammas[group] ** it
+        if self.warmup_pose and group == len(self.nets):
+            lr *= min(1.0, it / self.warmup_pose)
+        return lr
 
     def summarize_loss(self, loss):
         """reference model/base.py:130-142"""
@@ -53,21 +107,22 @@ class INNTrainer:
 
     def train_iteration(self, var):
         opt = self.opt
-        self.it += 1
+        it = self.it                                   # the reference's self.it during the step (0-based)
         for g in self.bucket.groups:
             for p in g:
                 p.grad = None
-        var = self.graph.forward(opt, var, mode="train", iter=self.it)
+        var = self.graph.forward(opt, var, mode="train", iter=it)
         loss = self.summarize_loss(self.graph.compute_loss(opt, var, mode="train"))
         loss.all.backward()
         self.bucket.gather()
         self.bucket.all_reduce()
-        for i, flat in enumerate(self.flats):
-            lr0, lr_end = self.lrs[i]
-            gamma = (lr_end / lr0) ** (1.0 / opt.max_iter) if lr_end else 1.0
-            ops.adam_step(flat, self.bucket.segment(i), self.m[i], self.v[i], lr0 * gamma ** (self.it - 1), self.it)
+        for i, flat in enumerate(self._flats()):
+            if self.trainable[i]:
+                ops.adam_step(flat, self.bucket.segment(i), self.m[i], self.v[i], self.learning_rate(i, it), it + 1)
+        self.it = it + 1
         for n in self.nets:
-            n.set_progress(self.it / opt.max_iter)
+            if hasattr(n, "set_progress"):
+                n.set_progress(self.it / opt.max_iter)
         return loss
 
 
@@ -79,3 +134,28 @@ def synthetic_scene(opt, n_views, seed=0):
     intr = torch.tensor([[0.8 * opt.W, 0, opt.W / 2], [0, 0.8 * opt.W, opt.H / 2], [0, 0, 1]], dtype=torch.float32).repeat(n_views, 1, 1)
     pose = torch.eye(3, 4).repeat(n_views, 1, 1)
     return edict(idx=torch.arange(n_views), image=image.to(opt.device), intr=intr.to(opt.device), pose=pose.to(opt.device))
+
+
+def synthetic_dtu_scene(opt, n_views, seed=0):
+    """DTU-shaped synthetic inputs (cfg 5): cameras on a ring of radius 3 looking at the origin, ground-truth world-to-camera
+    poses, metric depth range [1.2, 5.2] per view (data/dtu.py:110-111), and initial poses = se(3) noise (sigma = pose.noise)
+    composed with the ground truth (barf_inn_dtu.py:38-45).  -> (var, initial_poses_w2c)"""
+    from . import camera
+    var = synthetic_scene(opt, n_views, seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    poses = []
+    for i in range(n_views):
+        a = 2 * math.pi * i / max(n_views, 1) * 0.25            # a quarter arc, as neighbouring DTU views
+        eye = torch.tensor([3 * math.sin(a), 0.0, -3 * math.cos(a)])
+        z = -eye / eye.norm()
+        x = torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]), z)
+        x = x / x.norm()
+        y = torch.linalg.cross(z, x)
+        R = torch.stack([x, y, z])                              # rows: camera axes in world coordinates (world -> camera)
+        poses.append(torch.cat([R, (-R @ eye)[:, None]], dim=1))
+    gt = torch.stack(poses).to(opt.device)
+    noise = camera.lie.se3_to_SE3(torch.randn(n_views, 6, generator=gen).to(opt.device) * float(opt.pose.noise))
+    init = camera.pose.compose([noise, gt])[:, :3]
+    var.pose = gt
+    var.depth_range = torch.tensor([[1.2, 5.2]] * n_views, device=opt.device)
+    return var, init

@@ -46,11 +46,14 @@ class Graph(nerf_inn_llff.Graph):
 
     def _host_depth_range(self, depth_range):
         """var.depth_range[0] as two Python floats (the kernels take the range by value).  The device->host read is a
-        synchronisation point, so it is done once per tensor, not once per step (the range is a per-scene constant)."""
-        key = (depth_range.data_ptr(), depth_range._version)
-        if getattr(self, "_dr_key", None) != key:
-            self._dr_key, self._dr_val = key, [float(x) for x in depth_range[0]]
-        return self._dr_val
+        synchronisation point, so it is done once per tensor OBJECT and content version (the range is a per-scene constant);
+        the tensor is held by a weak reference, so an unrelated tensor that the allocator later places at the same address is
+        never mistaken for it."""
+        import weakref
+        cached = getattr(self, "_dr_cache", None)
+        if cached is None or cached[0]() is not depth_range or cached[1] != depth_range._version:
+            self._dr_cache = cached = (weakref.ref(depth_range), depth_range._version, [float(x) for x in depth_range[0]])
+        return cached[2]
 
     def compute_loss(self, opt, var, mode=None):
         """reference nerf_inn_dtu.py:398-415"""
@@ -59,7 +62,12 @@ class Graph(nerf_inn_llff.Graph):
             target = torch.cat([var.grid_local, var.center_local], dim=1)
             source = torch.cat([var.grid_init, var.center_init], dim=1)
             pose_global_w2c = self.pose_net.get_w2c_poses()
-            loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, pose_global_w2c))
+            if getattr(opt, "ray_shard", None) is None:
+                loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, pose_global_w2c))
+            else:
+                # ray sharding: this rank's share of the global mean (the gradient all-reduce sums the shares)
+                n_global = 3 * target.shape[0] * 2 * (opt.nerf.rand_rays // target.shape[0])
+                loss.global_alignment = ((target - camera.cam2world(source, pose_global_w2c)) ** 2).sum() / n_global
         return loss
 
     def render(self, opt, pose, intr=None, ray_idx=None, mode=None, depth_range=None):

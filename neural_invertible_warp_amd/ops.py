@@ -217,8 +217,8 @@ class _FieldMLP(torch.autograd.Function):
         if noise is not None:
             noise = _f32(noise, "noise")
         with timed("mlp_fwd_train" if need else "mlp_fwd", n_rays * S):
-            _lib.call("niw_mlp_fwd", _p(packed), _p(state.flat), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
-                      b3, bv, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
+            _lib.call("niw_mlp_fwd", _p(packed), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
+                      b3, bv, None, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
         ctx.save_ws, ctx.packed = save, packed
         ctx.set_materialize_grads(False)

@@ -76,7 +76,7 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
     # null pointers
     cases = {
         "niw_mlp_pack_weights": (None, None, None),
-        "niw_mlp_fwd": (None,) * 6 + (4, 8, None, None, 1, None, None, None, None),
+        "niw_mlp_fwd": (None,) * 5 + (4, 8, None, None, None, 1, None, None, None, None),
         "niw_mlp_bwd_dx": (None,) * 4 + (4, 8, 1) + (None,) * 8,
         "niw_mlp_bwd_dw": (None, None, 4, 8, None, None, None),
         "niw_composite_bwd": (None,) * 4 + (4, 8, 0, 0.0) + (None,) * 8,
@@ -94,9 +94,9 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
         rc = getattr(lib, name)(*args)
         assert rc == -1 and err(), (name, rc, err())
     # sizes / enums (pointers non-null)
-    assert lib.niw_mlp_fwd(p, p, p, p, p, None, 0, 8, None, None, 1, p, p, None, None) == -1 and "positive" in err()
-    assert lib.niw_mlp_fwd(p, p, p, p, p, None, 4, 8, None, None, 7, p, p, None, None) == -1 and "activation" in err()
-    assert lib.niw_mlp_fwd(p, p, p, p, p, None, 1 << 20, 64, None, None, 1, p, p, None, None) == -1 and "too many samples" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 0, 8, None, None, None, 1, p, p, None, None) == -1 and "positive" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 4, 8, None, None, None, 7, p, p, None, None) == -1 and "activation" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 1 << 20, 64, None, None, None, 1, p, p, None, None) == -1 and "too many samples" in err()
     assert lib.niw_warp_prep_fwd(p, p, 65, p, p, p, p, None) == -1 and "views" in err()
     assert lib.niw_warp_prep_fwd(p, p, 0, p, p, p, p, None) == -1
     # workspace queries are pure host arithmetic

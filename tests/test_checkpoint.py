@@ -114,9 +114,9 @@ def test_round_trip_through_the_wire_format(tmp_path):
     for i in range(len(tr.m)):
         assert torch.equal(tr.m[i], tr2.m[i]) and torch.equal(tr.v[i], tr2.v[i])
     # the kernels' flat buffers still alias the restored Parameters
-    assert tr2.graph.nerf.flat_params.data_ptr() == tr2.flats[0].data_ptr()
-    assert tr2.graph.warp_mlp.flat_params.data_ptr() == tr2.flats[2].data_ptr()
-    assert torch.equal(tr2.flats[2], tr.flats[2]) and torch.equal(tr2.flats[0], tr.flats[0])
+    assert tr2.graph.nerf.flat_params.data_ptr() == tr2._flats()[0].data_ptr() == tr2.graph.nerf.mlp_feat[0].weight.data_ptr()
+    assert tr2.graph.warp_mlp.flat_params.data_ptr() == tr2._flats()[2].data_ptr()
+    assert torch.equal(tr2._flats()[2], tr._flats()[2]) and torch.equal(tr2._flats()[0], tr._flats()[0])
     assert tr2.graph.nerf.progress_host == pytest.approx(7 / opt.max_iter)
     # weights-only load (opt.load) leaves the optimizer state alone
     opt3, tr3 = make_trainer()
