@@ -22,6 +22,11 @@ per-GPU ray count fixed (rank r renders pixels idx[r::N] of a global draw N time
 batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
 on one GPU: a proxy of what one rank of a K-GPU strong-scaled job executes (no collective).  Prints ONE JSON line on rank 0.
 
+The timed iterations replay ONE captured HIP graph each (engine.INNTrainer(hip_graph=True): forward, backward, gradient gather and
+the Adam updates; the step's scalars -- c2f bands, warp windows, Adam bias corrections, pixel-draw number -- travel in a 256-byte
+device buffer refreshed before every replay); under N > 1 the RCCL all-reduce is issued between two graphs.  --no-hip-graph launches
+the ~140 kernels one by one.
+
 Besides the contract fields the line carries `roofline` (dominant single MLP kernel: algorithmic FLOPs / mean launch time from
 device events on the launch stream vs the fp32-MFMA peak; `traffic` from the PMC passes in profiles/), `kernels` (per-kernel
 device-event averages of the timed steps), and at N = 1: `composite_scan` (the compositing kernels alone at full-image size: achieved
@@ -80,41 +85,53 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None):
                        f"best of 2 after 1 warm-up, torch CPU {threads} threads")
 
 
-def composite_scan(dev, iters=10):
+def composite_scan(dev, iters=20):
     """The compositing kernels alone at the size where they reach HBM (one 300x400 image: 120,000 rays x 192 samples, 0.55 GB forward):
-    achieved ALGORITHMIC bytes per second from device events.  tools/composite_bench.py is the stand-alone version the rocprofv3 PMC
-    passes of profiles/r2_composite_traffic.json run."""
+    achieved ALGORITHMIC bytes per second.  The launches go straight through the C ABI into pre-allocated buffers, `iters` of them
+    back to back between two device events on the launch stream, so the average is kernel time (plus the ~1.5 us kernel boundary), not
+    allocator or Python time.  tools/composite_bench.py is the stand-alone version the rocprofv3 PMC passes of
+    profiles/r2_composite_traffic.json run."""
     import torch
-    from neural_invertible_warp_amd import ops
+    from neural_invertible_warp_amd import _lib, ops
     N, S = 120000, 192
     gen = torch.Generator(device=dev).manual_seed(5)
     ray = torch.randn(N, 3, device=dev, generator=gen)
-    rgb_s = torch.rand(N, S, 3, device=dev, generator=gen).requires_grad_(True)
-    sig = (torch.rand(N, S, device=dev, generator=gen) * 2).requires_grad_(True)
+    rgb_s = torch.rand(N, S, 3, device=dev, generator=gen)
+    sig = torch.rand(N, S, device=dev, generator=gen) * 2
     dep = (torch.rand(N, S, device=dev, generator=gen) * 0.9 / S + torch.arange(S, device=dev) / S + 1.0).contiguous()
     g_rgb = torch.randn(N, 3, device=dev, generator=gen)
-    tf, tb = [], []
-    for i in range(iters + 2):
-        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        rgb_s.grad = sig.grad = None
+    rgb, depth, opa, prob = (torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, S, device=dev))
+    d_rgb_s, d_sig, d_ray = torch.empty_like(rgb_s), torch.empty_like(sig), torch.empty_like(ray)
+    P, st = ops._p, ops._stream()
+
+    def fwd():
+        _lib.call("niw_composite_fwd", P(ray), P(rgb_s), P(sig), P(dep), N, S, 0, 0.0, P(rgb), P(depth), P(opa), P(prob), st)
+
+    def bwd():
+        _lib.call("niw_composite_bwd", P(ray), P(rgb_s), P(sig), P(dep), N, S, 0, 0.0, P(g_rgb), None, None, None, P(d_rgb_s), P(d_sig), P(d_ray), st)
+
+    def timed(fn):
+        fn(); fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        rgb = ops.composite(ray, rgb_s, sig, dep)[0]
+        for _ in range(iters):
+            fn()
         b.record()
-        rgb.backward(g_rgb)
-        c.record()
         torch.cuda.synchronize()
-        if i >= 2:
-            tf.append(a.elapsed_time(b))
-            tb.append(b.elapsed_time(c))
-    med = lambda v: sorted(v)[len(v) // 2]
+        return a.elapsed_time(b) / iters                     # ms per launch
+
+    tf, tb = timed(fwd), timed(bwd)
     bf, bb = N * S * 24 + N * 32, N * S * 36 + N * 36
     return dict(workload=f"{N} rays x {S} samples (one 300x400 image, fine pass)", bound="hbm", unit="GB/s", peak=PEAK_HBM, achievable=6290.0,
-                fwd=dict(bytes=bf, us=round(med(tf) * 1e3, 1), achieved=round(bf / med(tf) / 1e6, 1), frac_of_peak=round(bf / med(tf) / 1e6 / PEAK_HBM, 4)),
-                bwd=dict(bytes=bb, us=round(med(tb) * 1e3, 1), achieved=round(bb / med(tb) / 1e6, 1), frac_of_peak=round(bb / med(tb) / 1e6 / PEAK_HBM, 4)),
-                bytes_per_sample=dict(fwd="12 rgb + 4 sigma + 4 depth in, 4 prob out", bwd="20 in, 12 d_rgb + 4 d_sigma out"))
+                fwd=dict(kernel=f"composite_fwd_kernel<64>", bytes=bf, us=round(tf * 1e3, 1), achieved=round(bf / tf / 1e6, 1), frac_of_peak=round(bf / tf / 1e6 / PEAK_HBM, 4),
+                         frac_of_achievable=round(bf / tf / 1e6 / 6290.0, 4)),
+                bwd=dict(kernel=f"composite_bwd_kernel<64>", bytes=bb, us=round(tb * 1e3, 1), achieved=round(bb / tb / 1e6, 1), frac_of_peak=round(bb / tb / 1e6 / PEAK_HBM, 4),
+                         frac_of_achievable=round(bb / tb / 1e6 / 6290.0, 4)),
+                bytes_per_sample=dict(fwd="12 rgb + 4 sigma + 4 depth in, 4 prob out", bwd="20 in, 12 d_rgb + 4 d_sigma out"),
+                traffic_source="profiles/r2_composite_traffic.json (rocprofv3 FETCH_SIZE x2 / WRITE_SIZE of the same launches)")
 
 
-def build_workloads(name, dev, rank, world, scaling, shard_of):
+def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True):
     """-> (list of (trainer, var0, B, R_local, S, Sf), description, rays of the global batch per scene)"""
     from neural_invertible_warp_amd import configs, engine
     eff_world, eff_rank = (shard_of, 0) if shard_of else (world, rank)
@@ -124,10 +141,10 @@ def build_workloads(name, dev, rank, world, scaling, shard_of):
         opt.nerf.rand_rays = rays * (eff_world if scaling == "weak" else 1)        # global draw; each rank keeps idx[rank::world]
         if dtu:
             var0, init = engine.synthetic_dtu_scene(opt, B)
-            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, initial_poses_w2c=init)
+            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, initial_poses_w2c=init, hip_graph=hip_graph)
         else:
             var0 = engine.synthetic_scene(opt, B)
-            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb)
+            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, hip_graph=hip_graph)
         R = (opt.nerf.rand_rays // B + eff_world - 1 - eff_rank) // eff_world       # rays per view on this rank
         S = opt.nerf.sample_intvs
         Sf = opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0
@@ -169,6 +186,8 @@ def main():
     ap.add_argument("--no-composite-scan", action="store_true")
     ap.add_argument("--no-psnr-parity", action="store_true")
     ap.add_argument("--lean", action="store_true", help="train step only: all four --no-* switches")
+    ap.add_argument("--no-hip-graph", action="store_true", help="launch every kernel of the iteration eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--kernel-steps", type=int, default=3, help="extra eager steps after the timed region for the per-kernel device-event table (0: skip)")
     args = ap.parse_args()
     if args.lean:
         args.no_cpu_baseline = args.no_forward_only = args.no_composite_scan = args.no_psnr_parity = True
@@ -188,13 +207,14 @@ def main():
     dev = f"cuda:{local}"
     scaling = "strong" if args.shard_of else args.scaling
 
-    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of)
+    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=not args.no_hip_graph)
     evals_local = sum(B * R * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
 
-    def step():
+    # the batch tensors stay resident at fixed addresses (the captured graph reads them in place)
+    def step(replay=True):
         loss = None
         for tr, var0, *_ in loads:
-            loss = tr.train_iteration(type(var0)(var0))
+            loss = tr.train_iteration(type(var0)(var0), replay=replay)
         return loss
 
     def fence():
@@ -202,16 +222,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3)):              # >= 3: two eager steps, then the capture
         step()
-    ops.TIMING.enabled = True
-    ops.TIMING.reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    loss_value = float(loss.all.detach())
+    graphed = all(tr._captured is not None for tr, *_ in loads)
+    # per-kernel device events: a few more iterations launched one by one (events cannot be recorded inside a replayed graph);
+    # outside the timed region, same kernels, same shapes
+    ops.TIMING.enabled = True
+    ops.TIMING.reset()
+    for _ in range(args.kernel_steps):
+        step(replay=False)
+    fence()
     ops.TIMING.enabled = False
     kern = ops.TIMING.summary()
 
@@ -273,7 +300,7 @@ def main():
                            samples_per_ray="+".join(str(x) for x in ((loads[0][4], loads[0][4] + loads[0][5]) if loads[0][5] else (loads[0][4],))),
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=par, precision="exact fp32 MFMA"),
                frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4),
-               loss=float(loss.all.detach()), roofline=roofline, kernels=kernels)
+               loss=loss_value, hip_graph=graphed, roofline=roofline, kernels=kernels)
     g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]
     S, Sf = loads[0][4], loads[0][5]
     if world == 1 and not args.no_composite_scan:

@@ -148,10 +148,20 @@ int niw_sample_pdf_merge(const float* pdf, const float* depth_coarse, const floa
  *         world by pose_init when given).
  * mode 1: camera.get_center_and_ray (camera.py:419-443): out_a = centre, out_b = ray
  *         (pose is world->camera and is inverted as camera.py:89-95 does).
- * intr [B,3,3]; pose [B,3,4] or NULL; ray_idx [R] int64 pixel ids (y*W+x) or NULL (= all H*W);
+ * intr [B,3,3]; pose [B,3,4] or NULL; ray_idx [R] int64 pixel ids (y*W+x), or NULL: the R consecutive pixels
+ * first_pixel .. first_pixel+R-1 (a slice of a full-image render, model/nerf.py:321-332; 0 and R = H*W: the whole image);
  * outputs [B,R,3]. */
-int niw_raygen(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, int64_t n_rays_per_view,
-               int H, int W, int mode, float* out_a, float* out_b, niw_stream_t stream);
+int niw_raygen(const float* intr, const float* pose, const int64_t* ray_idx, int64_t first_pixel, int n_views,
+               int64_t n_rays_per_view, int H, int W, int mode, float* out_a, float* out_b, niw_stream_t stream);
+
+/* The random pixel subset of a training step: `torch.randperm(H*W)[:n]` of the reference (model/nerf_inn_llff.py:510,
+ * model/nerf.py:256) as ONE launch without a sort: out[i] = P(first + i * stride), i < n, where P is a keyed pseudo-random
+ * PERMUTATION of [0, n_pixels) (4-round Feistel network on ceil(log2 n_pixels) bits, cycle-walked into range), so the
+ * indices are distinct and every pixel is equally likely, as with randperm.  The key is hash(seed, draw); `draw` comes by
+ * value or, when draw_dev != NULL, from that device word (a captured HIP graph then draws a fresh subset on every replay
+ * after the host bumped the word).  first / stride select a rank's share idx[rank::world] of the common permutation. */
+int niw_draw_ray_idx(int64_t n_pixels, int64_t n, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t first,
+                     int64_t stride, int64_t* out, niw_stream_t stream);
 
 /* camera.convert_NDC (camera.py:523-540); center, ray [B,R,3] in/out buffers distinct. */
 int niw_convert_ndc(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view,
@@ -168,7 +178,9 @@ int niw_convert_ndc(const float* center, const float* ray, const float* intr, in
  * pts [n_views, n_pts, 3]; chan_w[6] (host) per-band window or NULL; index_window[6] (host) or NULL: the
  * reference's dim-1 slicing of model/nvp/embedder.py:47 on 4-D input -- window value i scales ALL
  * channels of the points (2i+1)d .. (2i+3)d-1 (d = 2 for the 2-D embedding, 1 for the 1-D one), passed by value
- * with the launch; pt_scale_a / pt_scale_b [n_pts] (device) optional additional per-point scales.
+ * with the launch; window_dev: DEVICE array of 12 floats {chan_w[6], index_window[6]} or NULL -- when given it overrides the
+ * two host arrays and is read by the kernel at run time (HIP-graph replays), with use_index_window saying whether the index
+ * window applies; pt_scale_a / pt_scale_b [n_pts] (device) optional additional per-point scales.
  * inverse != 0 evaluates .inverse.  xin_save [n_views,n_pts,3,3] (block inputs) may be NULL. */
 #define NIW_WARP_WEMB_FLOATS (3 * (128 * 26 + 128 * 13))
 #define NIW_WARP_WHEAD_FLOATS (3 * (128 + 1 + 3 * 128 + 3))
@@ -188,17 +200,18 @@ int niw_warp_prep_fwd(const float* params, const float* code, int n_views, float
 int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
                       const float* d_w_head, float* workspace, float* d_params, float* d_code, niw_stream_t stream);
 int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                 int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* pt_scale_a,
-                 const float* pt_scale_b, int inverse, float* out, niw_stream_t stream);
+                 int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                 int use_index_window, const float* pt_scale_a, const float* pt_scale_b, int inverse, float* out,
+                 niw_stream_t stream);
 
 /* Backward of the forward warp.  d_out [n_views,n_pts,3] -> d_w_emb, d_view_b, d_w_head (same
  * shapes as the inputs, overwritten) and d_pts [n_views,n_pts,3] (may be NULL).
  * workspace: niw_warp_bwd_workspace_floats() floats of scratch.  n_views <= 64 per call. */
 int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts);
 int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                 int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* pt_scale_a,
-                 const float* pt_scale_b, const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
-                 niw_stream_t stream);
+                 int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                 int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* d_out, float* workspace,
+                 float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts, niw_stream_t stream);
 
 /* ------------------------------------------------------------------ global-alignment loss
  * Rotation of the rigid registration (Kabsch with reflection fix) behind `roma.rigid_points_registration`
@@ -208,19 +221,33 @@ int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, c
 int niw_kabsch_rotation_fwd(const float* M, int n, float* R, float* Us, float* V, float* S, niw_stream_t stream);
 int niw_kabsch_rotation_bwd(const float* Us, const float* V, const float* S, const float* dR, int n, float* dM, niw_stream_t stream);
 
+/* The whole alignment term fused (model/nerf_inn_llff.py:563-572, model/nerf_inn_dtu.py:410-414):
+ *   niw_align_moments: target (warped points x), source (un-warped points y) [n_views,n_points,3] -> moments [n_views,16] DOUBLE:
+ *                      n, sum x[3], sum y[3], sum y x^T[9].  Under ray sharding the ranks all-reduce this buffer.
+ *   niw_align_solve:   moments -> poses [n_views,3,4] = [R|t] minimising sum |R x + t - y|^2 (Kabsch with reflection fix).
+ *   niw_align_loss:    loss[0] = sum |x - R^T (y - t)|^2 / n_norm (overwritten; n_norm = 3 * n_views * n_points of the GLOBAL
+ *                      batch) and d_target [n_views,n_points,3] = 2 (x - R^T (y - t)) / n_norm (may be NULL).  The loss is
+ *                      stationary in (R, t), so this IS the total derivative (csrc/niw_align.hip). */
+int niw_align_moments(const float* target, const float* source, int n_views, int64_t n_points, double* moments, niw_stream_t stream);
+int niw_align_solve(const double* moments, int n_views, float* poses, niw_stream_t stream);
+int niw_align_loss(const float* target, const float* source, const float* poses, int n_views, int64_t n_points, double n_norm,
+                   float* loss, float* d_target, niw_stream_t stream);
+
 /* ------------------------------------------------------------------ loss and optimizer
  * Graph.compute_loss photometric part + MSE_loss (model/nerf_inn_llff.py:548-559,
  * model/base.py:209-211): gathers image[b,:,ray_idx] ([B,3,H*W] layout), writes
  * loss[0] = mean((rgb - image)^2) * 1 and d_rgb = scale * 2 (rgb - image) / (3*B*R_norm).
  * n_norm: element count used for the mean (= 3*B*R of the GLOBAL batch under ray sharding).
- * loss is ACCUMULATED (caller zeroes). */
+ * loss[0] is OVERWRITTEN (one workgroup, fixed-order reduction: bit-reproducible, no float atomics, no zero-fill). */
 int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx, int n_views,
                     int64_t n_rays_per_view, int64_t hw, double n_norm, float grad_scale,
                     float* loss, float* d_rgb, niw_stream_t stream);
 
-/* torch.optim.Adam step (model/nerf.py:34-38 uses it with default betas/eps) on a flat buffer. */
+/* torch.optim.Adam step (model/nerf.py:34-38 uses it with default betas/eps) on a flat buffer.
+ * hyper_dev: DEVICE array {lr / (1 - beta1^step), sqrt(1 - beta2^step)} or NULL; when given it replaces the two values
+ * formed from lr / step on the host and is read at run time (HIP-graph replays). */
 int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                  double lr, double beta1, double beta2, double eps, int step, niw_stream_t stream);
+                  double lr, double beta1, double beta2, double eps, int step, const float* hyper_dev, niw_stream_t stream);
 
 #ifdef __cplusplus
 }

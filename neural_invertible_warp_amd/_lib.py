@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NIW_LIB_PATH") or os.path.join(_HERE, "libniw_hip.so")   # override: diagnostic builds (tools/)
 
-_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+_vp, _i, _i64, _u64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/niw.h one to one
 SIGNATURES = {
@@ -30,19 +30,23 @@ SIGNATURES = {
     "niw_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_sample_stratified": (_i, [_vp, _i64, _i, _f, _f, _i, _vp, _vp]),
     "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
-    "niw_raygen": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "niw_raygen": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "niw_draw_ray_idx": (_i, [_i64, _i64, _u64, _u64, _vp, _i64, _i64, _vp, _vp]),
     "niw_convert_ndc": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
-    "niw_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "niw_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "niw_warp_bwd_workspace_floats": (_i64, [_i, _i64]),
-    "niw_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_warp_prep_fwd_workspace_floats": (_i64, [_i]),
     "niw_warp_prep_bwd_workspace_floats": (_i64, [_i]),
     "niw_warp_prep_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "niw_warp_prep_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_kabsch_rotation_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "niw_kabsch_rotation_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "niw_align_moments": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    "niw_align_solve": (_i, [_vp, _i, _vp, _vp]),
+    "niw_align_loss": (_i, [_vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp]),
     "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _d, _f, _vp, _vp, _vp]),
-    "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp]),
+    "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp, _vp]),
 }
 
 _lib = None

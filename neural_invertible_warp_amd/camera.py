@@ -172,17 +172,17 @@ def get_unwarped_center_and_ray(opt, intr=None, ray_idx=None, pose_init=None):
     return ops.raygen(intr, pose_init, ray_idx, opt.H, opt.W, 0)
 
 
-def get_center_and_ray(opt, pose, intr=None, ray_idx=None):
-    """reference camera.py:419-443 -> (center_3D, ray), each [B,R,3].  `ray_idx` (an extension
-    of the reference signature) restricts generation to the pixels the caller would index."""
+def get_center_and_ray(opt, pose, intr=None, ray_idx=None, pixel_range=None):
+    """reference camera.py:419-443 -> (center_3D, ray), each [B,R,3].  `ray_idx` / `pixel_range` = (first, count) (extensions
+    of the reference signature) restrict generation to the pixels the caller would index."""
     assert opt.camera.model == "perspective"
     if torch.is_grad_enabled() and pose.requires_grad:
         # pose optimisation (test-time photometric refinement, barf_inn_llff.py:218-234): camera-frame grid
         # from the kernel, then the reference's cam2world algebra so that autograd reaches the pose
-        center_cam, grid_cam = ops.raygen(intr, None, ray_idx, opt.H, opt.W, 0)
+        center_cam, grid_cam = ops.raygen(intr, None, ray_idx, opt.H, opt.W, 0, pixel_range=pixel_range)
         center, grid = cam2world(center_cam, pose), cam2world(grid_cam, pose)
         return center, grid - center
-    return ops.raygen(intr, pose, ray_idx, opt.H, opt.W, 1)
+    return ops.raygen(intr, pose, ray_idx, opt.H, opt.W, 1, pixel_range=pixel_range)
 
 
 def get_3D_points_from_depth(opt, center, ray, depth, multi_samples=False):
@@ -194,5 +194,18 @@ def get_3D_points_from_depth(opt, center, ray, depth, multi_samples=False):
 
 
 def convert_NDC(opt, center, ray, intr, near=1):
-    """reference camera.py:523-540"""
+    """reference camera.py:523-540: rays re-parametrised in normalised device coordinates (near plane at z = `near`, +z forward).
+    Gradient-free inputs go through niw_convert_ndc; when a gradient can flow into `center` / `ray` (warped rays in training, a
+    refined pose at test time) the same formulas run as torch algebra so that autograd reaches the warp / the pose -- the kernel
+    has no backward, and dropping that gradient silently would stop the poses from training."""
+    if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad):
+        sx = (intr[:, 0, 0] / intr[:, 0, 2])[:, None]                   # focal / principal point, per view
+        sy = (intr[:, 1, 1] / intr[:, 1, 2])[:, None]
+        cx, cy, cz = center.unbind(dim=-1)
+        rx, ry, rz = ray.unbind(dim=-1)
+        shift = (near - cz) / rz                                         # slide every origin onto the near plane
+        cx, cy, cz = cx + shift * rx, cy + shift * ry, cz + shift * rz
+        center_ndc = torch.stack([sx * (cx / cz), sy * (cy / cz), 1 - 2 * near / cz], dim=-1)
+        ray_ndc = torch.stack([sx * (rx / rz - cx / cz), sy * (ry / rz - cy / cz), 2 * near / cz], dim=-1)
+        return center_ndc, ray_ndc
     return ops.convert_ndc(center, ray, intr, near)

@@ -105,6 +105,8 @@ def load_optimizer_state_dicts(trainer, checkpoint):
 def save_checkpoint(opt, trainer, ep, it, latest=False, children=None):
     """reference util.py:147-163; `trainer` plays the reference's `model` (has .graph and optimizer state)"""
     os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
+    if hasattr(trainer, "sync_state"):
+        trainer.sync_state()
     sd = trainer.graph.state_dict()
     if children is not None:
         sd = {k: v for k, v in sd.items() if k.startswith(children)}

@@ -5,8 +5,9 @@
 // Vector kernels (S % 4 == 0, 16-byte aligned rows -- every shipped configuration): a ray is owned by a GROUP of
 // G = 8 / 16 / 32 / 64 lanes (G = S/4 rounded up to a power of two), so a wave carries 64/G rays at once (four rays of
 // 64 samples, two of 128, one of 192 ...).  Every lane owns FOUR consecutive samples: sigma, depth and prob move as one
-// 16-byte access per lane, rgb as three (either directly, lane stride 48 B, or -- RGB_LDS -- as three fully coalesced
-// wave accesses transposed through LDS: 3 KiB per wave, conflict-free ds_read_b128 at a 12-dword lane stride).
+// 16-byte access per lane, rgb as three at a lane stride of 48 B (every byte of a fetched line is used by the same wave within
+// three instructions; measured on MI355X against a variant that moved the colours as three fully coalesced wave accesses
+// transposed through LDS: equal forward, the LDS variant 5-10 % slower backward -- the direct form is kept).
 // The transmittance T_i = exp(-sum_{j<i} sigma_j delta_j) is a segmented wave scan: a serial exclusive prefix over the
 // lane's four samples plus a shuffle ladder of width G over the lane totals (shift-then-scan: an inclusive-minus-self
 // form would cancel catastrophically against the 1e10 closing interval); rays longer than 4G = 256 samples run in
@@ -54,10 +55,9 @@ struct Quad {
 
 // The lane's four samples of chunk `k` of its ray: sigma, depth, the interval to the next sample (1e10 after the
 // last one, nerf.py:461-462), sigma * (interval * |ray|) (nerf.py:463-464) and, when WITH_RGB, the colours.
-template <int G, bool RGB_LDS, bool WITH_RGB>
+template <int G, bool WITH_RGB>
 __device__ __forceinline__ bool load_quad(Quad& q, const float* __restrict__ sg, const float* __restrict__ d, const float* __restrict__ c,
-                                          int S, int k, int gl, float len, float* __restrict__ lds_wave, int lane,
-                                          const float* __restrict__ c_wave, long long wave_span) {
+                                          int S, int k, int gl, float len) {
     const int s0 = k * 4 * G + 4 * gl;
     const bool v = s0 < S;
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, d4 = s4;
@@ -67,24 +67,8 @@ __device__ __forceinline__ bool load_quad(Quad& q, const float* __restrict__ sg,
     }
     if (WITH_RGB) {
         f32x4 c4[3];
-        if (RGB_LDS) {
-            // the wave's colours of this chunk are ONE contiguous span (wave_span floats from c_wave): three coalesced
-            // 1 KiB accesses -> LDS -> every lane reads back its own 12 floats
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const long long e = 4ll * (lane + 64 * j);
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (e < wave_span) t = *reinterpret_cast<const f32x4*>(c_wave + e);
-                *reinterpret_cast<f32x4*>(lds_wave + e) = t;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 3; ++j) c4[j] = *reinterpret_cast<const f32x4*>(lds_wave + 12 * lane + 4 * j);
-            __builtin_amdgcn_wave_barrier();
-        } else {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) c4[j] = v ? *reinterpret_cast<const f32x4*>(c + 3 * s0 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < 3; ++j) c4[j] = v ? *reinterpret_cast<const f32x4*>(c + 3 * s0 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 12; ++t) q.col[t / 3][t % 3] = c4[t / 4][t % 4];
     }
@@ -105,13 +89,12 @@ __device__ __forceinline__ bool load_quad(Quad& q, const float* __restrict__ sg,
     return v;
 }
 
-template <int G, bool RGB_LDS>
+template <int G>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
                                                             const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
                                                             long long n_rays, int S, int has_bg, float bg,
                                                             float* __restrict__ rgb, float* __restrict__ depth,
                                                             float* __restrict__ opacity, float* __restrict__ prob) {
-    __shared__ __attribute__((aligned(16))) float lds[RGB_LDS ? 4 * 768 : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x % G;
     constexpr int RPW = 64 / G;                                  // rays per wave
     const long long r_wave = ((long long)blockIdx.x * 4 + wave) * RPW;
@@ -128,11 +111,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     float carry = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, ao = 0.f;
     for (int k = 0; k < n_chunks; ++k) {
         Quad q;
-        // RGB_LDS: the colours of the wave's rays of this chunk start at ray r_wave, sample k*4G and run on contiguously
-        const float* c_wave = rgb_s + (r_wave * S + (long long)k * 4 * G) * 3;
-        const long long span_rays = n_rays - r_wave < RPW ? n_rays - r_wave : RPW;
-        const long long wave_span = RPW > 1 ? span_rays * S * 3 : 3ll * (S - k * 4 * G < 4 * G ? S - k * 4 * G : 4 * G);
-        const bool v = load_quad<G, RGB_LDS, true>(q, sg, d, c, S, k, gl, len, lds + (RGB_LDS ? wave * 768 : 0), lane, c_wave, wave_span);
+        const bool v = load_quad<G, true>(q, sg, d, c, S, k, gl, len);
         const float e1 = q.sd[0], e2 = e1 + q.sd[1], e3 = e2 + q.sd[2], tot = e3 + q.sd[3];
         const float base = carry + group_excl_scan_up<G>(tot, gl);
         const float ex[4] = {base, base + e1, base + e2, base + e3};
@@ -159,7 +138,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     }
 }
 
-template <int G, bool RGB_LDS>
+template <int G>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
                                                             const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
                                                             long long n_rays, int S, int has_bg, float bg,
@@ -167,7 +146,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g_opacity, const float* __restrict__ g_prob,
                                                             float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s,
                                                             float* __restrict__ d_ray) {
-    __shared__ __attribute__((aligned(16))) float lds[RGB_LDS ? 4 * 768 : 4];
     __shared__ float chunk_prefix[G == 64 ? 4 * kMaxChunks : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x % G;
     constexpr int RPW = 64 / G;
@@ -186,13 +164,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     float go = g_opacity ? g_opacity[r] : 0.f;
     if (has_bg) go -= bg * (gr0 + gr1 + gr2);
     const int n_chunks = (S + 4 * G - 1) / (4 * G);
-    float* lds_wave = lds + (RGB_LDS ? wave * 768 : 0);
     // pass 1 (rays of more than one chunk, G = 64): sum of sigma*delta in front of every chunk
     if (G == 64 && n_chunks > 1) {
         float run = 0.f;
         for (int k = 0; k < n_chunks; ++k) {
             Quad q;
-            load_quad<G, false, false>(q, sg, d, c, S, k, gl, len, nullptr, lane, nullptr, 0);
+            load_quad<G, false>(q, sg, d, c, S, k, gl, len);
             if (gl == 0) chunk_prefix[wave * kMaxChunks + k] = run;
             run += group_sum<G>((q.sd[0] + q.sd[1]) + (q.sd[2] + q.sd[3]));
         }
@@ -202,10 +179,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     float suffix = 0.f, dlen = 0.f;
     for (int k = n_chunks - 1; k >= 0; --k) {
         Quad q;
-        const float* c_wave = rgb_s + (r_wave * S + (long long)k * 4 * G) * 3;
-        const long long span_rays = n_rays - r_wave < RPW ? n_rays - r_wave : RPW;
-        const long long wave_span = RPW > 1 ? span_rays * S * 3 : 3ll * (S - k * 4 * G < 4 * G ? S - k * 4 * G : 4 * G);
-        const bool v = load_quad<G, RGB_LDS, true>(q, sg, d, c, S, k, gl, len, lds_wave, lane, c_wave, wave_span);
+        const bool v = load_quad<G, true>(q, sg, d, c, S, k, gl, len);
         const int s0 = k * 4 * G + 4 * gl;
         f32x4 gp = {0.f, 0.f, 0.f, 0.f};
         if (v && g_prob) gp = *reinterpret_cast<const f32x4*>(g_prob + r * S + s0);
@@ -236,18 +210,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t < 12; ++t) dc4[t / 4][t % 4] = w[t / 3] * (t % 3 == 0 ? gr0 : t % 3 == 1 ? gr1 : gr2);
         if (v && live) *reinterpret_cast<f32x4*>(d_sigma_s + r * S + s0) = ds4;
-        if (RGB_LDS) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(lds_wave + 12 * lane + 4 * j) = dc4[j];
-            __builtin_amdgcn_wave_barrier();
-            float* o_wave = d_rgb_s + (r_wave * S + (long long)k * 4 * G) * 3;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const long long e = 4ll * (lane + 64 * j);
-                if (e < wave_span) *reinterpret_cast<f32x4*>(o_wave + e) = *reinterpret_cast<const f32x4*>(lds_wave + e);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else if (v && live) {
+        if (v && live) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(d_rgb_s + (r * S + s0) * 3 + 4 * j) = dc4[j];
         }
@@ -406,17 +369,6 @@ inline int group_lanes(int S) {
     const int need = (S + 3) / 4;
     return need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
 }
-// colours through LDS whenever a wave's colours of a chunk form one contiguous span: one ray per wave, or rays that
-// fill their groups exactly
-inline bool rgb_through_lds(int G, int S) {
-#ifdef NIW_COMPOSITE_NO_LDS      // diagnostic build (tools/composite_bench.py): colours by 48-byte-strided 16-byte accesses
-    (void)G; (void)S;
-    return false;
-#else
-    return G == 64 || S == 4 * G;
-#endif
-}
-
 }  // namespace
 
 extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s,
@@ -432,12 +384,11 @@ extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const flo
     if (S % 4 == 0 && aligned16(rgb_s) && aligned16(sigma_s) && aligned16(depth_s) && (!prob || aligned16(prob))) {
         const int G = group_lanes(S);
         const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
-        const bool lds = rgb_through_lds(G, S);
-#define NIW_CFWD(GG, LL) composite_fwd_kernel<GG, LL><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob)
-        if (G == 8) { if (lds) NIW_CFWD(8, true); else NIW_CFWD(8, false); }
-        else if (G == 16) { if (lds) NIW_CFWD(16, true); else NIW_CFWD(16, false); }
-        else if (G == 32) { if (lds) NIW_CFWD(32, true); else NIW_CFWD(32, false); }
-        else { if (lds) NIW_CFWD(64, true); else NIW_CFWD(64, false); }
+#define NIW_CFWD(GG) composite_fwd_kernel<GG><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob)
+        if (G == 8) NIW_CFWD(8);
+        else if (G == 16) NIW_CFWD(16);
+        else if (G == 32) NIW_CFWD(32);
+        else NIW_CFWD(64);
 #undef NIW_CFWD
     } else {
         const int blocks = (int)((n_rays + 3) / 4);
@@ -461,12 +412,11 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
         (!d_prob || aligned16(d_prob))) {
         const int G = group_lanes(S);
         const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
-        const bool lds = rgb_through_lds(G, S);
-#define NIW_CBWD(GG, LL) composite_bwd_kernel<GG, LL><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray)
-        if (G == 8) { if (lds) NIW_CBWD(8, true); else NIW_CBWD(8, false); }
-        else if (G == 16) { if (lds) NIW_CBWD(16, true); else NIW_CBWD(16, false); }
-        else if (G == 32) { if (lds) NIW_CBWD(32, true); else NIW_CBWD(32, false); }
-        else { if (lds) NIW_CBWD(64, true); else NIW_CBWD(64, false); }
+#define NIW_CBWD(GG) composite_bwd_kernel<GG><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray)
+        if (G == 8) NIW_CBWD(8);
+        else if (G == 16) NIW_CBWD(16);
+        else if (G == 32) NIW_CBWD(32);
+        else NIW_CBWD(64);
 #undef NIW_CBWD
     } else {
         const int blocks = (int)((n_rays + 3) / 4);

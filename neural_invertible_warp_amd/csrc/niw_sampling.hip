@@ -83,12 +83,13 @@ __device__ __forceinline__ void inv3x3(const float* __restrict__ K, float (&o)[9
 }
 
 __global__ void raygen_kernel(const float* __restrict__ intr, const float* __restrict__ pose, const int64_t* __restrict__ ray_idx,
-                              int B, long long R, int H, int W, int mode, float* __restrict__ out_a, float* __restrict__ out_b) {
+                              long long first_pixel, int B, long long R, int H, int W, int mode, float* __restrict__ out_a,
+                              float* __restrict__ out_b) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * R) return;
     const int b = (int)(i / R);
     const long long r = i % R;
-    const long long pix = ray_idx ? ray_idx[r] : r;
+    const long long pix = ray_idx ? ray_idx[r] : first_pixel + r;
     const float x = (float)(pix % W) + 0.5f, y = (float)(pix / W) + 0.5f;
     float Ki[9];
     inv3x3(intr + b * 9, Ki);
@@ -131,38 +132,79 @@ __global__ void ndc_kernel(const float* __restrict__ center, const float* __rest
 }
 
 // ---------------------------------------------------------------- L1: MSE (base.py:209-211) + gather (nerf.py:279-281)
-__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ image,
-                                                  const int64_t* __restrict__ ray_idx, int B, long long R, long long hw,
-                                                  double n_norm, float grad_scale, float* __restrict__ loss, float* __restrict__ d_rgb) {
-    __shared__ float red[4];
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    float sq = 0.f;
-    if (i < (long long)B * R * 3) {
+// one workgroup of 1024 threads over all B*R*3 elements: fixed-order reduction, loss[0] overwritten
+__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ image,
+                                                   const int64_t* __restrict__ ray_idx, int B, long long R, long long hw,
+                                                   double n_norm, float grad_scale, float* __restrict__ loss, float* __restrict__ d_rgb) {
+    __shared__ double red[16];
+    const long long total = (long long)B * R * 3;
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < total; i += 1024) {
         const int c = (int)(i % 3);
         const long long br = i / 3, b = br / R, r = br % R;
         const long long pix = ray_idx ? ray_idx[r] : r;
         const float diff = rgb[i] - image[(b * 3 + c) * hw + pix];
-        sq = diff * diff;
+        acc += diff * diff;
         if (d_rgb) d_rgb[i] = (float)((double)grad_scale * 2.0 * (double)diff / n_norm);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (float)((double)(red[0] + red[1] + red[2] + red[3]) / n_norm));
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = (float)(t / n_norm);
+    }
 }
 
 // ---------------------------------------------------------------- torch.optim.Adam (single tensor, no amsgrad / weight decay)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long n, float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt) {
+                            long long n, float w1, float b2, float w2, float eps, float step_size, float bc2_sqrt,
+                            const float* __restrict__ hyper_dev) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (hyper_dev) { step_size = hyper_dev[0]; bc2_sqrt = hyper_dev[1]; }
     const float gi = g[i];
     const float mi = m[i] + w1 * (gi - m[i]);                 // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = v[i] * b2 + (w2 * gi) * gi;              // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;           // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
     p[i] -= step_size * (mi / denom);                         // addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
+}
+
+// ---------------------------------------------------------------- G0: var.ray_idx = randperm(H*W)[:n] (nerf_inn_llff.py:510)
+__device__ __forceinline__ unsigned mix32(unsigned x) {          // murmur3 finaliser
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+// keyed permutation of [0, 2^(2*half)): 4-round balanced Feistel network
+__device__ __forceinline__ unsigned long long feistel(unsigned long long v, int half, const unsigned (&key)[4]) {
+    const unsigned mask = (1u << half) - 1u;
+    unsigned l = (unsigned)(v >> half) & mask, r = (unsigned)v & mask;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned f = mix32(r ^ key[k]) & mask;
+        const unsigned t = l ^ f;
+        l = r;
+        r = t;
+    }
+    return ((unsigned long long)l << half) | r;
+}
+__global__ void draw_ray_idx_kernel(long long n_pixels, long long n, unsigned long long seed, unsigned long long draw,
+                                    const unsigned long long* __restrict__ draw_dev, long long first, long long stride, int half,
+                                    int64_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (draw_dev) draw = draw_dev[0];
+    unsigned key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        key[k] = mix32((unsigned)(seed >> (16 * (k & 1))) + 0x9e3779b9u * (unsigned)(k + 1)) ^ mix32((unsigned)draw + 0x7f4a7c15u * (unsigned)(k + 1)) ^
+                 mix32((unsigned)(draw >> 32) ^ (unsigned)(seed >> 32));
+    unsigned long long v = (unsigned long long)(first + i * stride);
+    do { v = feistel(v, half, key); } while (v >= (unsigned long long)n_pixels);       // cycle walking keeps it a permutation of [0, n_pixels)
+    out[i] = (int64_t)v;
 }
 
 }  // namespace
@@ -190,14 +232,15 @@ extern "C" int niw_sample_pdf_merge(const float* pdf, const float* depth_coarse,
     return NIW_OK;
 }
 
-extern "C" int niw_raygen(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, int64_t n_rays_per_view,
-                          int H, int W, int mode, float* out_a, float* out_b, niw_stream_t stream) {
+extern "C" int niw_raygen(const float* intr, const float* pose, const int64_t* ray_idx, int64_t first_pixel, int n_views,
+                          int64_t n_rays_per_view, int H, int W, int mode, float* out_a, float* out_b, niw_stream_t stream) {
     NIW_REQUIRE(intr && out_a && out_b, "niw_raygen: null pointer");
     NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && H > 0 && W > 0, "niw_raygen: empty input");
     NIW_REQUIRE(mode == 0 || (mode == 1 && pose), "niw_raygen: mode %d needs a pose", mode);
-    NIW_REQUIRE(ray_idx || n_rays_per_view == (int64_t)H * W, "niw_raygen: without ray_idx the ray count must be H*W");
+    NIW_REQUIRE(ray_idx || (first_pixel >= 0 && first_pixel + n_rays_per_view <= (int64_t)H * W),
+                "niw_raygen: pixel range [%lld, %lld) leaves the %dx%d image", (long long)first_pixel, (long long)(first_pixel + n_rays_per_view), H, W);
     const long long n = (long long)n_views * n_rays_per_view;
-    raygen_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(intr, pose, ray_idx, n_views, n_rays_per_view, H, W, mode, out_a, out_b);
+    raygen_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(intr, pose, ray_idx, first_pixel, n_views, n_rays_per_view, H, W, mode, out_a, out_b);
     NIW_LAUNCH_CHECK("niw_raygen");
     return NIW_OK;
 }
@@ -217,20 +260,38 @@ extern "C" int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64
                                float* loss, float* d_rgb, niw_stream_t stream) {
     NIW_REQUIRE(rgb && image && loss, "niw_mse_fwd_bwd: null pointer");
     NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && hw > 0 && n_norm > 0, "niw_mse_fwd_bwd: empty input");
-    const long long n = (long long)n_views * n_rays_per_view * 3;
-    mse_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(rgb, image, ray_idx, n_views, n_rays_per_view, hw, n_norm, grad_scale, loss, d_rgb);
+    mse_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rgb, image, ray_idx, n_views, n_rays_per_view, hw, n_norm, grad_scale, loss, d_rgb);
     NIW_LAUNCH_CHECK("niw_mse_fwd_bwd");
     return NIW_OK;
 }
 
 extern "C" int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                             double lr, double beta1, double beta2, double eps, int step, niw_stream_t stream) {
+                             double lr, double beta1, double beta2, double eps, int step, const float* hyper_dev,
+                             niw_stream_t stream) {
     NIW_REQUIRE(param && grad && exp_avg && exp_avg_sq, "niw_adam_step: null pointer");
-    NIW_REQUIRE(n > 0 && step >= 1, "niw_adam_step: n=%lld step=%d", (long long)n, step);
+    NIW_REQUIRE(n > 0 && (step >= 1 || hyper_dev), "niw_adam_step: n=%lld step=%d", (long long)n, step);
+    if (step < 1) step = 1;
     // the scalars are formed in double like torch.optim.Adam forms them in Python floats, and rounded to fp32 once
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     adam_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
-                                                                        (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
+                                                                        (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2), hyper_dev);
     NIW_LAUNCH_CHECK("niw_adam_step");
+    return NIW_OK;
+}
+
+extern "C" int niw_draw_ray_idx(int64_t n_pixels, int64_t n, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t first,
+                                int64_t stride, int64_t* out, niw_stream_t stream) {
+    NIW_REQUIRE(out, "niw_draw_ray_idx: null output");
+    NIW_REQUIRE(n_pixels > 0 && n > 0 && first >= 0 && stride >= 1, "niw_draw_ray_idx: n_pixels=%lld n=%lld first=%lld stride=%lld",
+                (long long)n_pixels, (long long)n, (long long)first, (long long)stride);
+    NIW_REQUIRE(first + (n - 1) * stride < n_pixels, "niw_draw_ray_idx: %lld indices from %lld by %lld leave the %lld-pixel permutation",
+                (long long)n, (long long)first, (long long)stride, (long long)n_pixels);
+    NIW_REQUIRE(n_pixels <= (1ll << 40), "niw_draw_ray_idx: at most 2^40 pixels");
+    int bits = 1;
+    while ((1ll << bits) < n_pixels) ++bits;
+    const int half = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+    draw_ray_idx_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(n_pixels, n, seed, draw, (const unsigned long long*)draw_dev, first,
+                                                                                  stride, half, out);
+    NIW_LAUNCH_CHECK("niw_draw_ray_idx");
     return NIW_OK;
 }

@@ -127,12 +127,34 @@ struct WarpArgs {
     int n_views, inverse, use_iw;
     float cw[kNF];
     float iw[kNF];      // index window (reference_exact): scales whole points by their index
+    const float* win_dev;   // device copy of {cw, iw} read at run time (HIP-graph replays) or NULL: the by-value copies above
 };
 
+// the annealing windows of this launch: by value, or from the device buffer a captured graph re-reads on every replay
+struct Windows {
+    float cw[kNF], iw[kNF];
+    int use_iw;
+};
+__device__ __forceinline__ Windows load_windows(const WarpArgs& a) {
+    Windows w;
+#pragma unroll
+    for (int i = 0; i < kNF; ++i) {
+        w.cw[i] = a.win_dev ? a.win_dev[i] : a.cw[i];
+        w.iw[i] = a.win_dev ? a.win_dev[kNF + i] : a.iw[i];
+    }
+    w.use_iw = a.use_iw;
+    return w;
+}
+
 // embedder.py:47 on 4-D input: window value i multiplies points (2i+1)d .. (2i+3)d-1 along dim 1
-__device__ __forceinline__ float index_scale(const WarpArgs& a, long long p, int d) {
+__device__ __forceinline__ float index_scale(const Windows& w, long long p, int d) {
     const long long q = p / d;
-    return (a.use_iw && q >= 1 && q < 1 + 2 * kNF) ? a.iw[(q - 1) >> 1] : 1.f;
+    if (!(w.use_iw && q >= 1 && q < 1 + 2 * kNF)) return 1.f;
+    const int k = (int)((q - 1) >> 1);
+    float v = w.iw[0];
+#pragma unroll
+    for (int i = 1; i < kNF; ++i) v = k == i ? w.iw[i] : v;      // register select (a dynamic index would spill the array)
+    return v;
 }
 
 __device__ __forceinline__ void stage_weights(const WarpArgs& a, float* lw, float* lh, float* lv, int view) {
@@ -216,16 +238,17 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
     float* lv = lh + 3 * kHeadBlock;
     const int view = blockIdx.y;
     stage_weights(a, lw, lh, lv, view);
+    const Windows win = load_windows(a);
     const int sub = threadIdx.x & (kGroup - 1);
     const long long p = (long long)blockIdx.x * (blockDim.x / kGroup) + threadIdx.x / kGroup;
     if (p >= a.n_pts) return;                     // whole groups leave together
     const long long gi = (long long)view * a.n_pts + p;
     float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
-    const float psa = (a.ps_a ? a.ps_a[p] : 1.f) * index_scale(a, p, 2), psb = (a.ps_b ? a.ps_b[p] : 1.f) * index_scale(a, p, 1);
+    const float psa = (a.ps_a ? a.ps_a[p] : 1.f) * index_scale(win, p, 2), psb = (a.ps_b ? a.ps_b[p] : 1.f) * index_scale(win, p, 1);
     if (!a.inverse) {
-        for (int b = 0; b < 3; ++b) block_fwd(lw, lh, lv, a.cw, psa, psb, b, sub, x);
+        for (int b = 0; b < 3; ++b) block_fwd(lw, lh, lv, win.cw, psa, psb, b, sub, x);
     } else {
-        for (int b = 2; b >= 0; --b) block_inv(lw, lh, lv, a.cw, psa, psb, b, sub, x);
+        for (int b = 2; b >= 0; --b) block_inv(lw, lh, lv, win.cw, psa, psb, b, sub, x);
     }
     if (sub == 0) { a.out[gi * 3] = x[0]; a.out[gi * 3 + 1] = x[1]; a.out[gi * 3 + 2] = x[2]; }
 }
@@ -237,17 +260,18 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     float* lv = lh + 3 * kHeadBlock;
     const int view = blockIdx.y;
     stage_weights(a, lw, lh, lv, view);
+    const Windows win = load_windows(a);
     const int sub = threadIdx.x & (kGroup - 1);
     const long long p = (long long)blockIdx.x * (blockDim.x / kGroup) + threadIdx.x / kGroup;
     if (p >= a.n_pts) return;                     // whole groups leave together
     const long long gi = (long long)view * a.n_pts + p;
-    const float psa = (a.ps_a ? a.ps_a[p] : 1.f) * index_scale(a, p, 2), psb = (a.ps_b ? a.ps_b[p] : 1.f) * index_scale(a, p, 1);
+    const float psa = (a.ps_a ? a.ps_a[p] : 1.f) * index_scale(win, p, 2), psb = (a.ps_b ? a.ps_b[p] : 1.f) * index_scale(win, p, 1);
     float xin[3][3];
     {
         float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
         for (int b = 0; b < 3; ++b) {
             xin[b][0] = x[0]; xin[b][1] = x[1]; xin[b][2] = x[2];
-            block_fwd(lw, lh, lv, a.cw, psa, psb, b, sub, x);
+            block_fwd(lw, lh, lv, win.cw, psa, psb, b, sub, x);
         }
     }
     float gx[3] = {a.d_out[gi * 3], a.d_out[gi * 3 + 1], a.d_out[gi * 3 + 2]};
@@ -265,9 +289,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         // ---- recompute the block forward
         const float oth[2] = {xin[b][o0], xin[b][o1]};
         float ea[kEa], eb[kEb], o[3];
-        embed<2>(oth, a.cw, psa, sub, ea);
+        embed<2>(oth, win.cw, psa, sub, ea);
         const float foc[1] = {xin[b][f] - part_a(lw, lh, lv, b, sub, ea)};
-        embed<1>(foc, a.cw, psb, sub, eb);
+        embed<1>(foc, win.cw, psb, sub, eb);
         part_b(lw, lh, lv, b, sub, eb, o);
         float s, c;
         sincosf(o[0], &s, &c);
@@ -375,14 +399,16 @@ __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, co
 constexpr size_t kWarpLds = (3 * kWembBlock + 3 * kHeadBlock + 3 * 2 * kHid) * sizeof(float);
 
 int fill_args(WarpArgs& a, const float* w_emb, const float* view_b, const float* w_head, const float* pts, int n_views,
-              int64_t n_pts, const float* chan_w, const float* index_window, const float* ps_a, const float* ps_b) {
+              int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev, int use_index_window,
+              const float* ps_a, const float* ps_b) {
     NIW_REQUIRE(w_emb && view_b && w_head && pts, "niw_warp: null pointer");
     NIW_REQUIRE(n_views > 0 && n_pts > 0, "niw_warp: empty input (views=%d, points=%lld)", n_views, (long long)n_pts);
     a.w_emb = w_emb; a.view_b = view_b; a.w_head = w_head; a.pts = pts; a.ps_a = ps_a; a.ps_b = ps_b;
     a.n_pts = n_pts; a.n_views = n_views;
     for (int i = 0; i < kNF; ++i) a.cw[i] = chan_w ? chan_w[i] : 1.f;
-    a.use_iw = index_window != nullptr;
+    a.use_iw = window_dev ? (use_index_window != 0) : (index_window != nullptr);
     for (int i = 0; i < kNF; ++i) a.iw[i] = index_window ? index_window[i] : 1.f;
+    a.win_dev = window_dev;
     return NIW_OK;
 }
 
@@ -393,10 +419,11 @@ long long warp_ppad(int n_views, int64_t n_pts) { return ((long long)n_views * n
 static_assert(NIW_WARP_WEMB_FLOATS == 3 * kWembBlock && NIW_WARP_WHEAD_FLOATS == 3 * kHeadBlock, "header constants");
 
 extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                            int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* pt_scale_a,
-                            const float* pt_scale_b, int inverse, float* out, niw_stream_t stream) {
+                            int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                            int use_index_window, const float* pt_scale_a, const float* pt_scale_b, int inverse, float* out,
+                            niw_stream_t stream) {
     WarpArgs a{};
-    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, pt_scale_a, pt_scale_b);
+    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b);
     if (rc != NIW_OK) return rc;
     NIW_REQUIRE(out, "niw_warp_fwd: null output");
     a.out = out; a.inverse = inverse;
@@ -413,11 +440,11 @@ extern "C" int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts) {
 }
 
 extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                            int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* pt_scale_a,
-                            const float* pt_scale_b, const float* d_out, float* workspace, float* d_w_emb, float* d_view_b,
-                            float* d_w_head, float* d_pts, niw_stream_t stream) {
+                            int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                            int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* d_out,
+                            float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts, niw_stream_t stream) {
     WarpArgs a{};
-    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, pt_scale_a, pt_scale_b);
+    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b);
     if (rc != NIW_OK) return rc;
     NIW_REQUIRE(d_out && workspace && d_w_emb && d_view_b && d_w_head, "niw_warp_bwd: null pointer");
     NIW_REQUIRE(n_views <= 64, "niw_warp_bwd: at most 64 views per call (got %d)", n_views);

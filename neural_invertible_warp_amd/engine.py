@@ -19,6 +19,36 @@ from ._lib import NiwError
 from .util import edict
 
 
+class StepConstants:
+    """Every step-dependent SCALAR of a train iteration in one small device buffer, refreshed by one host-to-device copy per step:
+    c2f band weights (10 + 4), the warp's annealing windows (6 + 6), the two step-dependent Adam scalars of every optimizer group
+    and the number of the random pixel draw.  The kernels read them at run time (band_dev / window_dev / hyper_dev / draw_dev
+    arguments of the C ABI) instead of receiving them by value, which is what lets a captured HIP graph of the whole iteration
+    be replayed unchanged from step to step."""
+    BAND, WINDOW, HYPER, DRAW, BYTES = 0, 64, 128, 240, 256          # byte offsets (DRAW 8-byte aligned)
+
+    def __init__(self, device, n_groups):
+        assert self.HYPER + 8 * n_groups <= self.DRAW
+        self.host = torch.zeros(self.BYTES, dtype=torch.uint8)
+        if torch.device(device).type == "cuda":
+            self.host = self.host.pin_memory()
+        self.dev = torch.zeros(self.BYTES, dtype=torch.uint8, device=device)
+        f = lambda buf, off, n: buf[off:off + 4 * n].view(torch.float32)
+        self.band, self.window = f(self.dev, self.BAND, 14), f(self.dev, self.WINDOW, 12)
+        self.hyper = [f(self.dev, self.HYPER + 8 * g, 2) for g in range(n_groups)]
+        self.draw = self.dev[self.DRAW:self.DRAW + 8].view(torch.int64)
+        self._h = dict(band=f(self.host, self.BAND, 14), window=f(self.host, self.WINDOW, 12),
+                       hyper=f(self.host, self.HYPER, 2 * n_groups), draw=self.host[self.DRAW:self.DRAW + 8].view(torch.int64))
+
+    def upload(self, band, window, hyper, draw):
+        h = self._h
+        h["band"].copy_(torch.tensor(band, dtype=torch.float32))
+        h["window"].copy_(torch.tensor(window, dtype=torch.float32))
+        h["hyper"].copy_(torch.tensor(hyper, dtype=torch.float32).reshape(-1))
+        h["draw"].fill_(int(draw))
+        self.dev.copy_(self.host, non_blocking=True)            # stream-ordered in front of the kernels that read it
+
+
 def _sched_gamma(lr0, lr_end, sched, max_iter, what):
     """decay rate of the reference's scheduler block (nerf_inn_llff.py:40-47, barf_inn_llff.py:96-104)"""
     if not sched:
@@ -32,7 +62,11 @@ def _sched_gamma(lr0, lr_end, sched, max_iter, what):
 
 
 class INNTrainer:
-    def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None):
+    def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None, ray_sampler=None, hip_graph=False):
+        """ray_sampler: "feistel" (one sort-free launch, default on the GPU) or "randperm" (the reference's torch.randperm call).
+        hip_graph: capture the whole iteration (forward, backward, gradient gather, Adam) into a HIP graph after two eager
+        steps and replay it from then on -- one graph launch + one 256-byte constants upload per step instead of ~140 launches;
+        needs inputs that stay at the same device addresses from step to step (the engine's resident `var` tensors do)."""
         self.opt, self.rank, self.world, self.n_views = opt, rank, world, n_views
         o = opt.optim
         if o.get("algo", "Adam") != "Adam":
@@ -78,6 +112,18 @@ class INNTrainer:
         self.trainable = [True] * n + [train_warp, train_latent]
         self.warmup_pose = o.get("warmup_pose")
         self.it = 0
+        on_gpu = torch.device(opt.device).type == "cuda"
+        opt.nerf.ray_sampler = ray_sampler or opt.nerf.get("ray_sampler") or ("feistel" if on_gpu else "randperm")
+        self.hip_graph = bool(hip_graph) and on_gpu
+        self._captured = None
+        if self.hip_graph:
+            if opt.nerf.ray_sampler != "feistel":
+                raise NiwError("hip_graph=True needs ray_sampler='feistel' (torch.randperm cannot be replayed with a fresh draw)")
+            self.consts = StepConstants(dev, len(self.bucket.groups))
+            for n in self.nets:
+                n.band_dev = self.consts.band
+            self.warp_mlp.window_dev = self.consts.window
+            self.graph.draw_dev = self.consts.draw
         if world > 1:
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)
@@ -105,9 +151,9 @@ class INNTrainer:
         loss.update(all=total)
         return loss
 
-    def train_iteration(self, var):
+    # ------------------------------------------------------------------ one iteration
+    def _forward_backward(self, var, it):
         opt = self.opt
-        it = self.it                                   # the reference's self.it during the step (0-based)
         for g in self.bucket.groups:
             for p in g:
                 p.grad = None
@@ -115,15 +161,94 @@ class INNTrainer:
         loss = self.summarize_loss(self.graph.compute_loss(opt, var, mode="train"))
         loss.all.backward()
         self.bucket.gather()
-        self.bucket.all_reduce()
+        return loss
+
+    def _optimizer_step(self, it):
         for i, flat in enumerate(self._flats()):
             if self.trainable[i]:
-                ops.adam_step(flat, self.bucket.segment(i), self.m[i], self.v[i], self.learning_rate(i, it), it + 1)
+                ops.adam_step(flat, self.bucket.segment(i), self.m[i], self.v[i], self.learning_rate(i, it), it + 1,
+                              hyper_dev=self.consts.hyper[i] if self.hip_graph else None)
+
+    def _upload_constants(self, it):
+        """the scalars of 0-based iteration `it` (progress it / max_iter was set after the previous step, barf_inn_llff.py:117)"""
+        from .model.nvp import nvp_ndr
+        net = self.nets[0]
+        band = net.band_weights(self.opt, ops.L3D) + net.band_weights(self.opt, ops.LVIEW)
+        chan_w, index_window = self.warp_mlp._anneal(float(nvp_ndr.embedding_anneal_ratio(self.opt, it)))
+        hyper = [ops.adam_hyper(self.learning_rate(i, it), it + 1) for i in range(len(self.bucket.groups))]
+        self.consts.upload(band, list(chan_w) + list(index_window or [1.0] * 6), hyper, it + 1)
+
+    def train_iteration(self, var, replay=True):
+        """One iteration on the resident batch `var` (idx, image, intr[, pose, depth_range]) -> loss edict.  With hip_graph the
+        returned tensors are the graph's static outputs: read them before the next call.  replay=False runs the iteration
+        launch by launch even when a graph exists (per-kernel timing)."""
+        it = self.it                                   # the reference's self.it during the step (0-based)
+        if self.hip_graph:
+            loss = self._graph_iteration(var, it, replay)
+        else:
+            loss = self._forward_backward(var, it)
+            self.bucket.all_reduce()
+            self._optimizer_step(it)
         self.it = it + 1
         for n in self.nets:
             if hasattr(n, "set_progress"):
-                n.set_progress(self.it / opt.max_iter)
+                n.set_progress(self.it / self.opt.max_iter, device_copy=not self.hip_graph)
         return loss
+
+    def _graph_iteration(self, var, it, replay=True):
+        self._upload_constants(it)
+        if self._captured is None or not replay:
+            if not replay or it < 2 or not self._capture(var, it):
+                # warm-up (allocator, lazily built tables, kernel attributes) and fall-back: the same body, eagerly
+                loss = self._forward_backward(var, it)
+                self.bucket.all_reduce()
+                self._optimizer_step(it)
+                return loss
+        fb, adam, loss = self._captured
+        fb.replay()
+        if adam is not None:                           # ranks exchange gradients between the two graphs
+            self.bucket.all_reduce()
+            adam.replay()
+        return loss
+
+    def _capture(self, var, it):
+        """Capture iteration `it` (it also executes on replay, below).  One graph for a single rank; under ray sharding two graphs
+        (forward + backward + gather | Adam) with the RCCL all-reduce of the flat gradient bucket issued eagerly in between, so that
+        no collective is captured.  -> False when capture is not possible (the engine then stays eager)."""
+        import sys
+        self._static_inputs = {k: v for k, v in var.items() if isinstance(v, torch.Tensor)}      # must stay alive and in place
+        torch.cuda.synchronize()
+        try:
+            fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fb):
+                loss = self._forward_backward(var, it)
+                if self.world == 1:
+                    self._optimizer_step(it)
+            adam = None
+            if self.world > 1:
+                adam = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(adam, pool=fb.pool()):
+                    self._optimizer_step(it)
+        except Exception as e:  # noqa: BLE001 -- any capture failure: keep training eagerly, loudly
+            print(f"[niw] HIP-graph capture failed ({type(e).__name__}: {e}); continuing without graph replay", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            self.hip_graph_failed = True
+            self._captured = None
+            self.hip_graph = False
+            for n in self.nets:
+                n.band_dev = None
+            self.warp_mlp.window_dev = None
+            self.graph.draw_dev = None
+            return False
+        self._captured = (fb, adam, loss)
+        return True
+
+    def sync_state(self):
+        """bring device-side mirrors of host state up to date (the c2f `progress` Parameter is only written on demand under
+        graph replay): call before reading state_dict()"""
+        for n in self.nets:
+            if hasattr(n, "set_progress"):
+                n.set_progress(self.it / self.opt.max_iter if self.it else float(n.progress_host or 0.0))
 
 
 def synthetic_scene(opt, n_views, seed=0):

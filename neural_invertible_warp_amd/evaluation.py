@@ -15,25 +15,27 @@ The renders run on the HIP path (graph.forward(mode="eval")); the pose algebra i
 import numpy as np
 import torch
 
-from . import camera, metrics
+from . import camera, metrics, posealign
 from .align_trajectories import align_ate_c2b_use_a2b
 from .util import edict
 
 
 class _TestTimeRefinement:
     def evaluate_test_time_photometric_optim(self, opt, var):
-        """Absorb the remaining pose error of a test view in an se(3) correction optimised photometrically
-        (barf_inn_llff.py:218-234, barf_inn_dtu.py:467-483)"""
-        var.se3_refine_test = torch.nn.Parameter(torch.zeros(1, 6, device=opt.device))
-        optim_pose = getattr(torch.optim, opt.optim.algo)([dict(params=[var.se3_refine_test], lr=opt.optim.lr_pose)])
-        with torch.enable_grad():
-            for _ in range(opt.optim.test_iter):
-                optim_pose.zero_grad()
-                var.pose_refine_test = camera.lie.se3_to_SE3(var.se3_refine_test)
+        """Test-time pose refinement (reference barf_inn_llff.py:218-234, barf_inn_dtu.py:467-483): the aligned ground-truth pose
+        of a held-out view is still slightly off in the learnt frame; a 6-vector `var.se3_refine_test`, composed in front of it as
+        exp(se3) by `Graph.get_pose(mode="test-optim")`, is fitted to the view's own pixels for `optim.test_iter` Adam steps
+        (random rays, photometric loss only; the networks stay fixed)."""
+        correction = torch.zeros(1, 6, device=opt.device, requires_grad=True)
+        var.se3_refine_test = correction
+        adam = getattr(torch.optim, opt.optim.algo)([correction], lr=opt.optim.lr_pose)
+        for _ in range(opt.optim.test_iter):
+            with torch.enable_grad():
+                var.pose_refine_test = camera.lie.se3_to_SE3(correction)
                 var = self.graph.forward(opt, var, mode="test-optim")
-                loss = self.graph.compute_loss(opt, var, mode="test-optim")
-                loss.render.backward()
-                optim_pose.step()
+                photometric = self.graph.compute_loss(opt, var, mode="test-optim").render
+                (correction.grad,) = torch.autograd.grad(photometric, correction)
+            adam.step()
         return var
 
 
@@ -41,34 +43,28 @@ class _TestTimeRefinement:
 class LLFFEvaluator(_TestTimeRefinement):
     def __init__(self, opt, graph, pose_GT):
         """pose_GT: ground-truth w2c poses of the training views [N,3,4] (train_data.get_all_camera_poses)"""
-        self.opt, self.graph, self.pose_GT = opt, graph, pose_GT.to(opt.device)
+        self.opt, self.graph = opt, graph
+        self.pose_GT = torch.as_tensor(pose_GT).to(opt.device)
 
     @torch.no_grad()
     def get_all_training_poses(self, opt):
-        pose = self.graph.pose_eye
-        pose_refine = self.graph.global_rigid.weight.data.detach().clone().view(-1, 3, 4)
-        return camera.pose.compose([pose_refine, pose]), self.pose_GT
+        """-> (learnt w2c poses, ground truth): the per-view rigid motions registered by the alignment loss (`global_rigid`),
+        applied on top of the initial pose every view starts from (the identity: barf_inn_llff.py:156-169)"""
+        learnt = self.graph.global_rigid.weight.detach().reshape(-1, 3, 4).clone()
+        start = self.graph.pose_eye.expand_as(learnt)
+        return camera.pose.compose([learnt, start]), self.pose_GT
 
     @torch.no_grad()
     def prealign_cameras(self, opt, pose, pose_GT):
-        """Procrustes alignment of the predicted camera centres onto the ground truth -> (pose_aligned, sim3)"""
-        center = torch.zeros(1, 1, 3, device=opt.device)
-        center_pred = camera.cam2world(center, pose)[:, 0]
-        center_GT = camera.cam2world(center, pose_GT)[:, 0]
-        try:
-            sim3 = camera.procrustes_analysis(center_GT, center_pred)
-        except Exception:  # SVD did not converge
-            sim3 = edict(t0=0, t1=0, s0=1, s1=1, R=torch.eye(3, device=opt.device))
-        center_aligned = (center_pred - sim3.t1) / sim3.s1 @ sim3.R.t() * sim3.s0 + sim3.t0
-        R_aligned = pose[..., :3] @ sim3.R.t()
-        t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
-        return camera.pose(R=R_aligned, t=t_aligned), sim3
+        """-> (learnt poses expressed in the ground-truth frame, sim3) (barf_inn_llff.py:171-187)"""
+        pose, pose_GT = torch.as_tensor(pose).to(opt.device), torch.as_tensor(pose_GT).to(opt.device)
+        sim3 = posealign.fit_sim3(pose, pose_GT)
+        return posealign.transfer_poses(sim3, pose, to_gt=True), sim3
 
     @torch.no_grad()
     def evaluate_camera_alignment(self, opt, pose_aligned, pose_GT):
-        R_aligned, t_aligned = pose_aligned.split([3, 1], dim=-1)
-        R_GT, t_GT = pose_GT.split([3, 1], dim=-1)
-        return edict(R=camera.rotation_distance(R_aligned, R_GT), t=(t_aligned - t_GT)[..., 0].norm(dim=-1))
+        """-> edict(R [N] rad, t [N]) (barf_inn_llff.py:189-197)"""
+        return posealign.pose_errors(torch.as_tensor(pose_aligned), torch.as_tensor(pose_GT))
 
     def evaluate_full(self, opt, test_views, eps=1e-10):
         """test_views: iterable of var dicts (idx, image [1,3,H,W], intr, pose) -> edict(error=pose errors,

@@ -6,7 +6,7 @@ learnable poses through the NVP warp + BARF coarse-to-fine positional encoding.
 import numpy as np
 import torch
 
-from .. import camera
+from .. import camera, posealign
 from ..util import edict
 from . import nerf_inn_llff
 from .nvp import nvp_ndr
@@ -19,10 +19,13 @@ class NeRF(nerf_inn_llff.NeRF):
         # a Parameter so that the c2f state is checkpointed (reference barf_inn_llff.py:425)
         self.progress = torch.nn.Parameter(torch.tensor(0., device=opt.device))
 
-    def set_progress(self, value):
-        """Engine hook replacing `progress.data.fill_(it/max_iter)` (barf_inn_llff.py:117): also keeps
-        a host copy so that the band weights are formed without a device->host sync per step."""
-        self.progress.data.fill_(value)
+    def set_progress(self, value, device_copy=True):
+        """Engine hook replacing `progress.data.fill_(it/max_iter)` (barf_inn_llff.py:117): keeps a host copy so that the band
+        weights are formed without a device->host sync per step; device_copy=False defers the write of the Parameter itself
+        (a launch per network and step) until state is read (engine.INNTrainer.sync_state)."""
+        if device_copy:
+            self.progress.data.fill_(value)
+            self._progress_seen = self.progress._version
         self.progress_host = float(value)
 
     def band_weights(self, opt, L):
@@ -31,7 +34,11 @@ class NeRF(nerf_inn_llff.NeRF):
         if opt.barf_c2f is None:
             return [1.0] * L
         start, end = opt.barf_c2f
-        prog = self.progress_host if self.progress_host is not None else float(self.progress.data)
+        # one source of truth: the host copy, unless the Parameter was written behind its back (reference-style
+        # `nerf.progress.data.fill_()`, a checkpoint load) -- its version counter tells
+        if self.progress_host is None or getattr(self, "_progress_seen", None) != self.progress._version:
+            self.progress_host, self._progress_seen = float(self.progress.data), self.progress._version
+        prog = self.progress_host
         alpha = (np.float32(prog) - np.float32(start)) / np.float32(end - start) * np.float32(L)
         k = np.arange(L, dtype=np.float32)
         w = (1 - np.cos(np.clip(alpha - k, 0, 1).astype(np.float32) * np.float32(np.pi))) / 2
@@ -76,13 +83,9 @@ class Graph(nerf_inn_llff.Graph):
             ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.warp_mlp, self.warp_latent.weight, grid_cam, center_cam, alpha_ratio)
             return ray, center_3D, grid_3D, alpha_ratio
         if mode in ["val", "eval", "test-optim"]:
-            sim3 = self.sim3
-            center = torch.zeros(1, 1, 3, device=opt.device)
-            center = camera.cam2world(center, var.pose)[:, 0]
-            center_aligned = (center - sim3.t0) / sim3.s0 @ sim3.R * sim3.s1 + sim3.t1
-            R_aligned = var.pose[..., :3] @ sim3.R
-            t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
-            pose = camera.pose(R=R_aligned, t=t_aligned)
+            # a held-out view has no learnt pose: its ground-truth pose is brought into the learnt frame with the similarity the
+            # validation fitted to the training cameras (reference :385-396), plus, at test time, the photometric refinement
+            pose = posealign.transfer_poses(self.sim3, var.pose, to_gt=False)
             if opt.optim.test_photo and mode != "val":
                 pose = camera.pose.compose([var.pose_refine_test, pose])
             return pose

@@ -2,6 +2,8 @@
 (nerf.py:367-483) and `Graph` (nerf.py:243-365), same method names, argument meaning and
 state-dict keys; the arithmetic is delegated to libniw_hip.so through ..ops.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -20,8 +22,30 @@ def _slice_rays(opt):
     return max(1, min(int(n), ((1 << 24) - 128) // max(s, 1)))
 
 
-def _layer_dims(layers):
-    return list(zip(layers[:-1], layers[1:]))
+def _layer_table(arch):
+    """-> [(stack, fan_in, fan_out, head)] in state-dict order.  Feature stack: the encoded point (3 + 6 L_3D) enters layer 0 and
+    again every layer listed in `arch.skip`; the last feature layer emits one extra row, the raw density.  Colour stack: features
+    and the encoded view direction (3 + 6 L_view) in, rgb out.  `head` names the initialisation of the two output layers."""
+    d_point, d_view = 3 + 6 * arch.posenc.L_3D, 3 + 6 * arch.posenc.L_view
+    rows = []
+    widths = list(arch.layers_feat[1:])
+    for depth, width in enumerate(widths):
+        fan_in = (d_point if depth == 0 else widths[depth - 1]) + (d_point if depth in arch.skip else 0)
+        closing = depth == len(widths) - 1
+        rows.append(("mlp_feat", fan_in, width + (1 if closing else 0), "first" if closing else None))
+    widths_rgb = list(arch.layers_rgb[1:])
+    for depth, width in enumerate(widths_rgb):
+        fan_in = widths[-1] + d_view if depth == 0 else widths_rgb[depth - 1]
+        rows.append(("mlp_rgb", fan_in, width, "all" if depth == len(widths_rgb) - 1 else None))
+    return rows
+
+
+def _glorot_uniform_(weight, gain):
+    """U(-a, a) with a = gain * sqrt(3) * sqrt(2 / (fan_in + fan_out)), evaluated like torch.nn.init.xavier_uniform_ so that the same
+    generator state yields the same numbers"""
+    fan_out, fan_in = weight.shape
+    bound = 3.0 ** 0.5 * (gain * (2.0 / float(fan_in + fan_out)) ** 0.5)
+    return weight.uniform_(-bound, bound)
 
 
 class _BaseGraph(torch.nn.Module):
@@ -45,8 +69,9 @@ class NeRF(torch.nn.Module):
 
     # ------------------------------------------------------------------ parameters
     def define_network(self, opt):
-        """reference nerf.py:373-402.  The kernels are built for the one architecture every
-        reference config uses; anything else is refused loudly."""
+        """The two layer stacks of reference nerf.py:373-402 (`mlp_feat.N`, `mlp_rgb.N`: the state-dict keys), as views of ONE
+        flat parameter buffer laid out in state-dict order -- the buffer the kernels, the fused Adam and the gradient bucket
+        address.  The kernels are built for the one architecture every reference config uses; anything else is refused loudly."""
         arch = opt.arch
         if (list(arch.layers_feat) != _SUPPORTED_ARCH["layers_feat"] or list(arch.layers_rgb) != _SUPPORTED_ARCH["layers_rgb"]
                 or list(arch.skip) != _SUPPORTED_ARCH["skip"] or not arch.posenc or arch.posenc.L_3D != ops.L3D
@@ -55,62 +80,44 @@ class NeRF(torch.nn.Module):
                            "of the reference configs is built into libniw_hip.so")
         if arch.density_activ not in ops.ACT:
             raise NiwError(f"NeRF: density activation {arch.density_activ!r} not supported (relu, softplus)")
-        input_3D_dim = 3 + 6 * arch.posenc.L_3D
-        input_view_dim = 3 + 6 * arch.posenc.L_view
-        device = torch.device(opt.device)
-        flat = torch.zeros(ops.NERF_PARAM_FLOATS, device=device, dtype=torch.float32)
-        self.mlp_feat = torch.nn.ModuleList()
-        self.mlp_rgb = torch.nn.ModuleList()
-        self.total_param = 0
-        off = 0
-        L = _layer_dims(arch.layers_feat)
-        specs = []
-        for li, (k_in, k_out) in enumerate(L):
-            if li == 0: k_in = input_3D_dim
-            if li in arch.skip: k_in += input_3D_dim
-            if li == len(L) - 1: k_out += 1
-            specs.append((self.mlp_feat, k_in, k_out, "first" if li == len(L) - 1 else None))
-        Lr = _layer_dims(arch.layers_rgb)
-        for li, (k_in, k_out) in enumerate(Lr):
-            if li == 0: k_in = arch.layers_feat[-1] + input_view_dim
-            specs.append((self.mlp_rgb, k_in, k_out, "all" if li == len(Lr) - 1 else None))
-        for mlist, k_in, k_out, out in specs:
-            lin = torch.nn.Module()
-            lin.in_features, lin.out_features = k_in, k_out
-            lin.weight = torch.nn.Parameter(flat[off:off + k_in * k_out].view(k_out, k_in))
-            off += k_in * k_out
-            lin.bias = torch.nn.Parameter(flat[off:off + k_out])
-            off += k_out
+        flat = torch.zeros(ops.NERF_PARAM_FLOATS, device=torch.device(opt.device), dtype=torch.float32)
+        self.mlp_feat, self.mlp_rgb = torch.nn.ModuleList(), torch.nn.ModuleList()
+        stacks = dict(mlp_feat=self.mlp_feat, mlp_rgb=self.mlp_rgb)
+        cursor = 0
+        for stack, fan_in, fan_out, head in _layer_table(arch):
+            layer = torch.nn.Module()
+            layer.in_features, layer.out_features = fan_in, fan_out
+            layer.weight = torch.nn.Parameter(flat[cursor:cursor + fan_in * fan_out].view(fan_out, fan_in))
+            layer.bias = torch.nn.Parameter(flat[cursor + fan_in * fan_out:cursor + (fan_in + 1) * fan_out])
+            cursor += (fan_in + 1) * fan_out
             if arch.tf_init:
-                self.tensorflow_init_weights(opt, lin, out=out)
-            else:
-                torch.nn.init.kaiming_uniform_(lin.weight, a=5 ** 0.5)
-                torch.nn.init.uniform_(lin.bias, -1 / k_in ** 0.5, 1 / k_in ** 0.5)
-            mlist.append(lin)
-            self.total_param += lin.weight.numel()
-        assert off == ops.NERF_PARAM_FLOATS
+                self.tensorflow_init_weights(opt, layer, out=head)
+            else:                                                   # nn.Linear's own default
+                torch.nn.init.kaiming_uniform_(layer.weight, a=5 ** 0.5)
+                torch.nn.init.uniform_(layer.bias, -fan_in ** -0.5, fan_in ** -0.5)
+            stacks[stack].append(layer)
+        assert cursor == ops.NERF_PARAM_FLOATS
+        self.total_param = sum(l.weight.numel() for l in self.field_layers())
         self._state = ops.FieldState(flat)
         self.progress_host = None
+        self.band_dev = None            # device tensor [14] of c2f band weights read by the kernel at run time (engine.StepConstants)
 
     def tensorflow_init_weights(self, opt, linear, out=None):
-        """reference nerf.py:404-414"""
-        relu_gain = torch.nn.init.calculate_gain("relu")
+        """Glorot-uniform weights and zero biases as the TensorFlow NeRF code initialises them (reference nerf.py:404-414): hidden
+        layers with the ReLU gain; the colour output (`out="all"`) with gain 1; the layer that emits density and features
+        (`out="first"`) as two independent blocks -- the density row with gain 1, the feature rows with the ReLU gain."""
+        blocks = {"all": [(slice(None), 1.0)], "first": [(slice(0, 1), 1.0), (slice(1, None), 2.0 ** 0.5)]}.get(out, [(slice(None), 2.0 ** 0.5)])
         with torch.no_grad():
-            if out == "all":
-                torch.nn.init.xavier_uniform_(linear.weight)
-            elif out == "first":
-                torch.nn.init.xavier_uniform_(linear.weight[:1])
-                torch.nn.init.xavier_uniform_(linear.weight[1:], gain=relu_gain)
-            else:
-                torch.nn.init.xavier_uniform_(linear.weight, gain=relu_gain)
-            torch.nn.init.zeros_(linear.bias)
+            for rows, gain in blocks:
+                _glorot_uniform_(linear.weight[rows], gain)
+            linear.bias.zero_()
+
+    def field_layers(self):
+        return list(self.mlp_feat) + list(self.mlp_rgb)
 
     def field_parameters(self):
         """The 20 weight/bias Parameters in state-dict order (views of one flat buffer)."""
-        out = []
-        for lin in list(self.mlp_feat) + list(self.mlp_rgb):
-            out += [lin.weight, lin.bias]
-        return out
+        return [p for layer in self.field_layers() for p in (layer.weight, layer.bias)]
 
     @property
     def flat_params(self):
@@ -159,7 +166,8 @@ class NeRF(torch.nn.Module):
         if opt.nerf.density_noise_reg and mode == "train":
             noise = torch.randn(depth.shape, device=depth.device) * opt.nerf.density_noise_reg    # nerf.py:428-429
         return ops.field_mlp(self._state, self.field_parameters(), center, ray, depth,
-                             self.band_weights(opt, ops.L3D), self.band_weights(opt, ops.LVIEW), opt.arch.density_activ, noise)
+                             self.band_weights(opt, ops.L3D), self.band_weights(opt, ops.LVIEW), opt.arch.density_activ, noise,
+                             band_dev=self.band_dev)
 
     def forward(self, opt, points_3D, ray_unit=None, mode=None):
         """reference nerf.py:416-447: points [...,3], unit view directions [...,3] -> rgb [...,3],
@@ -244,12 +252,16 @@ class Graph(_BaseGraph):
         return ret
 
     def render(self, opt, pose, intr=None, ray_idx=None, mode=None):
-        """reference nerf.py:293-319 (the NaN retry loop of :296 guarded a CUDA bug and forced a
-        host sync per call; the HIP ray generator is deterministic, so it is not reproduced)."""
-        center, ray = camera.get_center_and_ray(opt, pose, intr=intr, ray_idx=ray_idx)
+        """reference nerf.py:293-319: rays of the poses (all pixels, or the pixels `ray_idx`) -> `_render_rays`.  The reference's
+        retry loop around NaN rays (:296) guarded a CUDA bug at the price of a host sync per call; the HIP ray generator is
+        deterministic, so it has no counterpart here."""
+        return self._render_pixels(opt, pose, intr, mode, ray_idx=ray_idx)
+
+    def _render_pixels(self, opt, pose, intr, mode, ray_idx=None, pixel_range=None, depth_range=None):
+        center, ray = camera.get_center_and_ray(opt, pose, intr=intr, ray_idx=ray_idx, pixel_range=pixel_range)
         if opt.camera.ndc:
             center, ray = camera.convert_NDC(opt, center, ray, intr=intr)
-        return self._render_rays(opt, center, ray, mode=mode)
+        return self._render_rays(opt, center, ray, mode=mode, depth_range=depth_range)
 
     def _hold_weights(self):
         """context: pack the networks' weights once for a loop of gradient-free renders (ops.FieldState.hold)"""
@@ -262,19 +274,25 @@ class Graph(_BaseGraph):
                     stack.enter_context(net._state.hold())
         return stack
 
-    def render_by_slices(self, opt, pose, intr=None, mode=None):
-        """reference nerf.py:321-332"""
-        ret_all = edict(rgb=[], depth=[], opacity=[])
-        if opt.nerf.fine_sampling:
-            ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
+    def _sweep_image(self, opt, piece):
+        """A full H x W render as a sequence of pixel RANGES (the reference bounds its memory the same way, by slices of
+        `nerf.rand_rays` pixels: nerf.py:321-332): `piece(first, count)` renders pixels first .. first+count-1 of every view and its
+        outputs land in pre-allocated [B, H*W, k] images.  No index tensors, no list-and-concatenate; weights are packed once."""
+        total, step = opt.H * opt.W, _slice_rays(opt)
+        image = None
         with self._hold_weights():
-            step = _slice_rays(opt)
-            for c in range(0, opt.H * opt.W, step):
-                ray_idx = torch.arange(c, min(c + step, opt.H * opt.W), device=opt.device)
-                ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode)
-                for k in ret: ret_all[k].append(ret[k])
-        for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)
-        return ret_all
+            for first in range(0, total, step):
+                count = min(step, total - first)
+                part = piece(first, count)
+                if image is None:
+                    image = edict({k: v.new_empty(v.shape[0], total, *v.shape[2:]) for k, v in part.items()})
+                for k, v in part.items():
+                    image[k][:, first:first + count] = v
+        return image
+
+    def render_by_slices(self, opt, pose, intr=None, mode=None):
+        """reference nerf.py:321-332 -> edict of [B, H*W, k] maps"""
+        return self._sweep_image(opt, lambda first, count: self._render_pixels(opt, pose, intr, mode, pixel_range=(first, count)))
 
     def sample_depth(self, opt, batch_size, num_rays=None, depth_range=None):
         """reference nerf.py:334-344 -> [B,R,S,1]; the stratified draw is torch.rand as in the

@@ -5,10 +5,8 @@ sample_depth; the alignment loss uses the detached Kabsch pose kept by the pose 
 (:410-414); the inverse-CDF bins still use the yaml range (:549), as in the reference."""
 import torch
 
-from .. import camera
-from ..util import edict
+from .. import ops
 from . import nerf, nerf_inn_llff
-from .nerf import _slice_rays
 
 
 class NeRF(nerf.NeRF):
@@ -56,40 +54,27 @@ class Graph(nerf_inn_llff.Graph):
         return cached[2]
 
     def compute_loss(self, opt, var, mode=None):
-        """reference nerf_inn_dtu.py:398-415"""
+        """reference nerf_inn_dtu.py:398-415: as the LLFF graph, except that the registered pose is the DETACHED one the pose network
+        keeps (refreshed by every get_warped_rays_in_world) and the un-warped points are the initial-pose world points."""
         loss = nerf.Graph.compute_loss(self, opt, var, mode=mode)
-        if mode == "train" and opt.loss_weight.global_alignment is not None:
-            target = torch.cat([var.grid_local, var.center_local], dim=1)
-            source = torch.cat([var.grid_init, var.center_init], dim=1)
-            pose_global_w2c = self.pose_net.get_w2c_poses()
-            if getattr(opt, "ray_shard", None) is None:
-                loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, pose_global_w2c))
-            else:
-                # ray sharding: this rank's share of the global mean (the gradient all-reduce sums the shares)
-                n_global = 3 * target.shape[0] * 2 * (opt.nerf.rand_rays // target.shape[0])
-                loss.global_alignment = ((target - camera.cam2world(source, pose_global_w2c)) ** 2).sum() / n_global
+        if mode != "train" or opt.loss_weight.global_alignment is None:
+            return loss
+        warped = torch.cat([var.grid_local, var.center_local], dim=1)
+        initial = torch.cat([var.grid_init, var.center_init], dim=1)
+        views = warped.shape[0]
+        sharded = getattr(opt, "ray_shard", None) is not None
+        elements = 3 * views * (2 * (opt.nerf.rand_rays // views) if sharded else warped.shape[1])
+        loss.global_alignment = (nerf_inn_llff.ALIGN_BACKEND or ops).alignment_residual(warped, initial, self.pose_net.get_w2c_poses(), n_norm=elements)
         return loss
 
     def render(self, opt, pose, intr=None, ray_idx=None, mode=None, depth_range=None):
         """reference nerf_inn_dtu.py:472-509"""
-        center, ray = camera.get_center_and_ray(opt, pose, intr=intr, ray_idx=ray_idx)
-        if opt.camera.ndc:
-            center, ray = camera.convert_NDC(opt, center, ray, intr=intr)
-        return self._render_rays(opt, center, ray, mode=mode, depth_range=depth_range)
+        return self._render_pixels(opt, pose, intr, mode, ray_idx=ray_idx, depth_range=depth_range)
 
     def render_by_slices(self, opt, pose, intr=None, mode=None, depth_range=None):
         """reference nerf_inn_dtu.py:511-522"""
-        ret_all = edict(rgb=[], depth=[], opacity=[])
-        if opt.nerf.fine_sampling:
-            ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
-        with self._hold_weights():
-            step = _slice_rays(opt)
-            for c in range(0, opt.H * opt.W, step):
-                ray_idx = torch.arange(c, min(c + step, opt.H * opt.W), device=opt.device)
-                ret = self.render(opt, pose, intr=intr, ray_idx=ray_idx, mode=mode, depth_range=depth_range)
-                for k in ret: ret_all[k].append(ret[k])
-        for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)
-        return ret_all
+        return self._sweep_image(opt, lambda first, count: self._render_pixels(opt, pose, intr, mode, pixel_range=(first, count),
+                                                                               depth_range=depth_range))
 
     def sample_depth(self, opt, batch_size, num_rays=None, depth_range=None):
         """reference nerf_inn_dtu.py:524-546 (explicit depth_range)"""

@@ -7,45 +7,24 @@ import torch
 from .. import camera, ops
 from ..util import edict
 from . import nerf
-from .nerf import _slice_rays
 
 
-def _all_reduce_sum(t):
-    """Differentiable SUM over ranks (identity without a process group)."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        import torch.distributed.nn.functional as dist_fn
-        return dist_fn.all_reduce(t.contiguous(), op=dist.ReduceOp.SUM)
-    return t
-
-
-# M [B,3,3] -> R [B,3,3].  None = the HIP solver; the CPU-only tests of the rank-sharded moments plug in a torch one.
-ROTATION_SOLVER = None
+# Test seam: the CPU-only multi-process tests of the sharded alignment term plug a torch restatement of the two fused
+# operations in here (an object with `rigid_registration` and `alignment_residual`).  None = libniw_hip.so (..ops).
+ALIGN_BACKEND = None
 
 
 def rigid_points_registration(x, y, sharded=False):
-    """R, t minimising sum ||R x + t - y||^2 over points [B,N,3] (Kabsch with reflection fix).
-    Stands in for roma.rigid_points_registration (roma==1.4.1, reference requirements.txt:1, call
-    site model/nerf_inn_llff.py:569); that package is not vendored in the reference, so this
-    restates the published algorithm -- parity unpinned.  Differentiable: the
-    reference does not detach the result (nerf_inn_llff.py:569-572).  Per-view 3x3 SVD on [B,3,3]
-    moments: host-side glue, not part of the per-sample path.
-    sharded=True (ray-shard data parallelism): every rank holds a slice of the points; the per-view
-    moments n, sum x, sum y, sum y x^T (16 floats per view) are summed over ranks before the SVD, so
-    all ranks obtain the registration of the GLOBAL point set."""
-    if sharded:
-        n = torch.full((x.shape[0], 1), float(x.shape[1]), device=x.device, dtype=x.dtype)
-        mom = torch.cat([n, x.sum(dim=1), y.sum(dim=1), (y.transpose(1, 2) @ x).reshape(x.shape[0], 9)], dim=1)
-        mom = _all_reduce_sum(mom)
-        n, sx, sy, syx = mom[:, :1], mom[:, 1:4], mom[:, 4:7], mom[:, 7:].reshape(-1, 3, 3)
-        xm, ym = (sx / n)[:, None], (sy / n)[:, None]
-        M = syx - n[:, :, None] * ym.transpose(1, 2) @ xm
-    else:
-        xm, ym = x.mean(dim=1, keepdim=True), y.mean(dim=1, keepdim=True)
-        M = (y - ym).transpose(1, 2) @ (x - xm)
-    R = (ROTATION_SOLVER or ops.kabsch_rotation)(M)       # niw_kabsch_rotation_fwd / _bwd (torch.linalg.svd blocks the host ~2 ms per call)
-    t = ym[:, 0] - (R @ xm.transpose(1, 2))[..., 0]
-    return R, t
+    """[R|t] minimising sum ||R x + t - y||^2 over points [B,N,3] (Kabsch with reflection fix) -> (R [B,3,3], t [B,3]).
+    Stands in for roma.rigid_points_registration (roma==1.4.1, reference requirements.txt:1, call sites
+    model/nerf_inn_llff.py:569, model/pose_models/inn.py:100); that package is not vendored in the reference, so this restates
+    the published algorithm -- parity unpinned.  Two launches (niw_align_moments: fp64 per-view moments; niw_align_solve:
+    Jacobi-SVD solve).  sharded=True (ray-shard data parallelism): every rank holds a slice of the points; the moments n, sum x,
+    sum y, sum y x^T (16 doubles per view) are summed over ranks before the solve, so all ranks obtain the registration of the
+    GLOBAL point set.  Gradient-free: see `Graph.compute_loss`."""
+    from .. import parallel
+    poses = (ALIGN_BACKEND or ops).rigid_registration(x, y, reduce_moments=parallel.all_reduce_sum_ if sharded else None)
+    return poses[..., :3], poses[..., 3]
 
 
 class NeRF(nerf.NeRF):
@@ -86,41 +65,53 @@ class Graph(nerf.Graph):
         return var
 
     def draw_ray_idx(self, opt, batch_size):
-        """reference :510 -- one pixel set shared by every view.  Under ray sharding (..parallel.shard_ray_idx) every
-        rank draws the same permutation and keeps its slice; the permutation then comes from a generator of its own,
-        seeded alike on all ranks, because the ranks' default generators drift apart as soon as their stratified
-        draws differ in size (rays per rank differ by one when the ray count is not a multiple of the world size)."""
+        """The pixel subset of a training step (reference :510): `nerf.rand_rays // batch_size` distinct pixels, the SAME set for
+        every view.  Two samplers, equal in distribution (a uniformly random subset in random order):
+          * "randperm" (default): `torch.randperm(H*W)[:n]`, the reference's own call (a device sort of H*W keys);
+          * "feistel" (`opt.nerf.ray_sampler`, what the engine selects): niw_draw_ray_idx, one sort-free launch keyed by
+            (opt.seed, number of the draw), also replayable from a captured HIP graph (`self.draw_dev`).
+        Under ray sharding (..parallel) every rank must see the same permutation and keep its share idx[rank::world]: "feistel"
+        has that by construction; "randperm" then draws from a generator of its own, seeded alike on all ranks, because the
+        ranks' default generators drift apart as soon as their stratified draws differ in size."""
         n = opt.nerf.rand_rays // batch_size
-        shard = getattr(opt, "ray_shard", None)
-        if shard is None:
+        rank, world = getattr(opt, "ray_shard", None) or (0, 1)
+        if opt.nerf.get("ray_sampler", "randperm") == "feistel":
+            self._ray_draws = getattr(self, "_ray_draws", 0) + 1
+            return ops.draw_ray_idx(opt.H * opt.W, len(range(rank, n, world)), int(getattr(opt, "seed", 0) or 0), self._ray_draws, opt.device,
+                                    first=rank, stride=world, draw_dev=getattr(self, "draw_dev", None))
+        if world == 1:
             return torch.randperm(opt.H * opt.W, device=opt.device)[:n]
         gen = getattr(self, "_ray_idx_gen", None)
         if gen is None:
             gen = self._ray_idx_gen = torch.Generator(device=opt.device)
             gen.manual_seed(1234567 + int(getattr(opt, "seed", 0) or 0))
-        rank, world = shard
         return torch.randperm(opt.H * opt.W, device=opt.device, generator=gen)[:n][rank::world]
 
     def get_pose_init(self, opt, var, mode=None, ind=None, iter=None):
         return None
 
     def compute_loss(self, opt, var, mode=None):
-        """reference nerf_inn_llff.py:548-573"""
+        """reference nerf_inn_llff.py:548-573: photometric term(s) + the global-alignment term, which ties the per-point warp to
+        ONE rigid motion per view: with [R|t] the rigid registration of the warped points (pixel grid ; camera centre) onto the
+        un-warped ones, the loss is the mean squared distance between the warped points and the registered rigid image of the
+        un-warped ones.  Fused (ops.rigid_registration + ops.alignment_residual: three launches).  The reference back-propagates
+        through roma's SVD as well; that part of the gradient is identically zero (the loss is stationary in [R|t], which
+        minimises it), so only the direct term is formed."""
         loss = super().compute_loss(opt, var, mode=mode)
-        if opt.loss_weight.global_alignment is not None and mode == "train":
-            source = torch.cat([var.grid_cam, var.center_cam], dim=1)
-            target = torch.cat([var.grid_3D, var.center], dim=1)
-            shard = getattr(opt, "ray_shard", None)
-            R_global, t_global = rigid_points_registration(target, source, sharded=shard is not None)
-            svd_poses = torch.cat((R_global, t_global[..., None]), -1)
-            if hasattr(self, "global_rigid"):
-                self.global_rigid.weight.data = svd_poses.detach().clone().view(-1, 12)
-            if shard is None:
-                loss.global_alignment = self.MSE_loss(target, camera.cam2world(source, svd_poses))
-            else:
-                # this rank's share of the global mean (the gradient all-reduce sums the shares)
-                n_global = 3 * target.shape[0] * 2 * (opt.nerf.rand_rays // target.shape[0])   # grid + centre points of the global draw
-                loss.global_alignment = ((target - camera.cam2world(source, svd_poses)) ** 2).sum() / n_global
+        if opt.loss_weight.global_alignment is None or mode != "train":
+            return loss
+        from .. import parallel
+        backend = ALIGN_BACKEND or ops
+        unwarped = torch.cat([var.grid_cam, var.center_cam], dim=1)
+        warped = torch.cat([var.grid_3D, var.center], dim=1)
+        sharded = getattr(opt, "ray_shard", None) is not None
+        poses = backend.rigid_registration(warped, unwarped, reduce_moments=parallel.all_reduce_sum_ if sharded else None)
+        if hasattr(self, "global_rigid"):
+            self.global_rigid.weight.data = poses.reshape(-1, 12).clone()          # what pose evaluation reads (:570)
+        views, local_points = warped.shape[0], warped.shape[1]
+        # mean over the GLOBAL batch: under sharding every rank contributes its share and the gradient all-reduce sums them
+        elements = 3 * views * (2 * (opt.nerf.rand_rays // views) if sharded else local_points)
+        loss.global_alignment = backend.alignment_residual(warped, unwarped, poses, n_norm=elements)
         return loss
 
     def get_pose(self, opt, var, mode=None):
@@ -136,15 +127,6 @@ class Graph(nerf.Graph):
         return self._render_rays(opt, center, ray, mode=mode, depth_range=depth_range)
 
     def render_by_slices_local(self, opt, ray, center, intr=None, mode=None):
-        """reference nerf_inn_llff.py:614-625"""
-        ret_all = edict(rgb=[], depth=[], opacity=[])
-        if opt.nerf.fine_sampling:
-            ret_all.update(rgb_fine=[], depth_fine=[], opacity_fine=[])
-        with self._hold_weights():
-            step = _slice_rays(opt)
-            for c in range(0, opt.H * opt.W, step):
-                ray_idx = torch.arange(c, min(c + step, opt.H * opt.W), device=opt.device)
-                ret = self.render_local(opt, ray, center, intr=intr, ray_idx=ray_idx, mode=mode)
-                for k in ret: ret_all[k].append(ret[k])
-        for k in ret_all: ret_all[k] = torch.cat(ret_all[k], dim=1)
-        return ret_all
+        """reference nerf_inn_llff.py:614-625: a full image from given rays, in pixel ranges (views of `ray` / `center`)"""
+        return self._sweep_image(opt, lambda first, count: self.render_local(opt, ray[:, first:first + count], center[:, first:first + count],
+                                                                             intr=intr, mode=mode))

@@ -70,6 +70,7 @@ class DeformNetwork(torch.nn.Module):
         for b in range(n_blocks):
             setattr(self, f"lin{b}_c", _zero_linear(d_feature, d_feature))
         self._ea, self._eb = ea, eb
+        self.window_dev = None      # device tensor [12] of annealing windows read by the kernels at run time (engine.StepConstants)
 
     # ------------------------------------------------------------------ operand preparation
     def _ensure_flat(self):
@@ -122,7 +123,8 @@ class DeformNetwork(torch.nn.Module):
             raise NiwError(f"DeformNetwork: deformation_code must be [{B},{_LAT}], got {tuple(deformation_code.shape)}")
         w_emb, view_b, w_head = self._operands(deformation_code)
         chan_w, index_window = self._anneal(float(alpha_ratio))
-        out = ops.warp_points(w_emb, view_b, w_head, input_pts.reshape(B, P, 3), chan_w, index_window, inverse=inverse)
+        out = ops.warp_points(w_emb, view_b, w_head, input_pts.reshape(B, P, 3), chan_w, index_window, inverse=inverse,
+                              window_dev=self.window_dev, use_index_window=self.reference_exact)
         return out.view(B, P, 1, 3)
 
     def forward(self, deformation_code, input_pts, alpha_ratio=0):

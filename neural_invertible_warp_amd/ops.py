@@ -83,19 +83,35 @@ def _farr(vals, n):
 # gradient-free stages
 # ------------------------------------------------------------------------------------------
 
-def raygen(intr, pose, ray_idx, H, W, mode):
+def raygen(intr, pose, ray_idx, H, W, mode, pixel_range=None):
     """mode 0: (center, grid) of camera.get_unwarped_center_and_ray; mode 1: (center, ray) of
-    camera.get_center_and_ray.  Returns two [B,R,3] tensors."""
+    camera.get_center_and_ray.  Returns two [B,R,3] tensors.  Rays: `ray_idx` (int64 pixel ids), or the consecutive pixels
+    `pixel_range` = (first, count) (a slice of a full-image render: no index tensor), or the whole image."""
     intr = _f32(intr, "intr")
     B = intr.shape[0]
     pose = None if pose is None else _f32(pose, "pose")
+    first = 0
     if ray_idx is not None:
         ray_idx = ray_idx.to(device=intr.device, dtype=torch.int64).contiguous()
-    R = H * W if ray_idx is None else ray_idx.numel()
+        R = ray_idx.numel()
+    elif pixel_range is not None:
+        first, R = int(pixel_range[0]), int(pixel_range[1])
+    else:
+        R = H * W
     a = torch.empty(B, R, 3, device=intr.device, dtype=torch.float32)
     b = torch.empty_like(a)
-    _lib.call("niw_raygen", _p(intr), _p(pose), _p(ray_idx), B, R, H, W, mode, _p(a), _p(b), _stream())
+    _lib.call("niw_raygen", _p(intr), _p(pose), _p(ray_idx), first, B, R, H, W, mode, _p(a), _p(b), _stream())
     return a, b
+
+
+def draw_ray_idx(n_pixels, n, seed, draw, device, first=0, stride=1, draw_dev=None):
+    """`torch.randperm(n_pixels)[:n]` of the reference (nerf_inn_llff.py:510) as one sort-free launch: element i is
+    P(first + i * stride) of a keyed pseudo-random permutation P of [0, n_pixels) (include/niw.h niw_draw_ray_idx).
+    `draw` numbers the draw (the training iteration); `draw_dev` (uint64 device word) overrides it at run time."""
+    out = torch.empty(n, device=device, dtype=torch.int64)
+    _lib.call("niw_draw_ray_idx", int(n_pixels), int(n), int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1), _p(draw_dev), int(first), int(stride),
+              _p(out), _stream())
+    return out
 
 
 def convert_ndc(center, ray, intr, near=1.0):
@@ -142,9 +158,15 @@ def sample_pdf_merge(pdf, depth_coarse, Sf, depth_range):
     return fine, merged
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
+    """(lr / bias_correction1, sqrt(bias_correction2)) as torch.optim.Adam forms them: the two step-dependent scalars of the update"""
+    return lr / (1.0 - beta1 ** step), math.sqrt(1.0 - beta2 ** step)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, hyper_dev=None):
+    """hyper_dev: device tensor [2] = adam_hyper(lr, step), read by the kernel at run time instead of lr / step (graph replays)"""
     _lib.call("niw_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(beta1),
-              float(beta2), float(eps), int(step), _stream())
+              float(beta2), float(eps), int(step), _p(hyper_dev), _stream())
 
 
 # ------------------------------------------------------------------------------------------
@@ -197,7 +219,7 @@ class FieldState:
 
 class _FieldMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, state, band3d, bandview, activ, noise, grad_mode, center, ray, depth, *params):
+    def forward(ctx, state, band3d, bandview, band_dev, activ, noise, grad_mode, center, ray, depth, *params):
         center, ray, depth = _f32(center, "center"), _f32(ray, "ray"), _f32(depth, "depth_samples")
         n_rays, S = depth.shape
         if center.shape != (n_rays, 3) or ray.shape != (n_rays, 3):
@@ -218,7 +240,7 @@ class _FieldMLP(torch.autograd.Function):
             noise = _f32(noise, "noise")
         with timed("mlp_fwd_train" if need else "mlp_fwd", n_rays * S):
             _lib.call("niw_mlp_fwd", _p(packed), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
-                      b3, bv, None, ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
+                      b3, bv, _p(band_dev), ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
         ctx.save_ws, ctx.packed = save, packed
         ctx.set_materialize_grads(False)
@@ -238,9 +260,9 @@ class _FieldMLP(torch.autograd.Function):
         gradws = torch.empty(GRAD_ROWS * ctx.mpad, device=dev, dtype=torch.float32)
         partial = torch.empty(lib.niw_mlp_bwd_workspace_floats(n_rays, S), device=dev, dtype=torch.float32)
         d_params = torch.empty(NERF_PARAM_FLOATS, device=dev, dtype=torch.float32)
-        ray_grad = ctx.needs_input_grad[6] or ctx.needs_input_grad[7]
-        d_center = torch.zeros_like(center) if ray_grad else None
-        d_ray = torch.zeros_like(ray) if ray_grad else None
+        ray_grad = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
+        d_both = torch.zeros(2, n_rays, 3, device=dev, dtype=torch.float32) if ray_grad else None     # accumulated by atomics: one fill for both
+        d_center, d_ray = (d_both[0], d_both[1]) if ray_grad else (None, None)
         with timed("mlp_bwd_dx", n_rays * S):
             _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], _p(rgb),
                       _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(d_center), _p(d_ray), _stream())
@@ -254,22 +276,23 @@ class _FieldMLP(torch.autograd.Function):
             n = math.prod(shp)
             grads.append(d_params[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, None, d_center, d_ray, None, *grads)
+        return (None, None, None, None, None, None, None, d_center, d_ray, None, *grads)
 
 
-def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None):
+def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None, band_dev=None):
     """NeRF.forward_samples on flattened rays: center, ray [N,3], depth [N,S] -> rgb [N,S,3], sigma [N,S].
+    band_dev: device tensor [14] = {band3d, bandview}; when given the kernel reads the c2f weights from it at run time.
     One launch takes fewer than 2^24 padded samples (32-bit byte offsets into the workspaces, niw_mlp_device.h); larger
     batches are split over the rays (autograd sums the parameter gradients of the pieces)."""
     n_rays, S = depth.shape
     max_rays = ((1 << 24) - 256) // S
     if n_rays <= max_rays:
-        return _FieldMLP.apply(state, band3d, bandview, activ, noise, torch.is_grad_enabled(), center, ray, depth, *params)
+        return _FieldMLP.apply(state, band3d, bandview, band_dev, activ, noise, torch.is_grad_enabled(), center, ray, depth, *params)
     rgb, sigma = [], []
     with (state.hold() if not params else contextlib.nullcontext()):
         for a in range(0, n_rays, max_rays):
             b = min(a + max_rays, n_rays)
-            r, s_ = _FieldMLP.apply(state, band3d, bandview, activ, None if noise is None else noise[a:b], torch.is_grad_enabled(), center[a:b], ray[a:b],
+            r, s_ = _FieldMLP.apply(state, band3d, bandview, band_dev, activ, None if noise is None else noise[a:b], torch.is_grad_enabled(), center[a:b], ray[a:b],
                                     depth[a:b], *params)
             rgb.append(r)
             sigma.append(s_)
@@ -322,16 +345,16 @@ def composite(ray, rgb_s, sigma_s, depth_s, bg=None):
 
 class _Warp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w_emb, view_b, w_head, pts, chan_w, index_window, ps_a, ps_b, inverse):
+    def forward(ctx, w_emb, view_b, w_head, pts, chan_w, index_window, ps_a, ps_b, inverse, window_dev=None, use_index_window=False):
         w_emb, view_b, w_head, pts = _f32(w_emb, "w_emb"), _f32(view_b, "view_b"), _f32(w_head, "w_head"), _f32(pts, "pts")
         B, P = pts.shape[0], pts.shape[1]
         out = torch.empty_like(pts)
         cw = _farr(chan_w, 6)
         iw = None if index_window is None else _farr(index_window, 6)       # by value with the launch: no H2D copy, no sync
-        _lib.call("niw_warp_fwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, cw, iw, _p(ps_a), _p(ps_b), 1 if inverse else 0,
-                  _p(out), _stream())
+        _lib.call("niw_warp_fwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, cw, iw, _p(window_dev), 1 if use_index_window else 0,
+                  _p(ps_a), _p(ps_b), 1 if inverse else 0, _p(out), _stream())
         ctx.save_for_backward(w_emb, view_b, w_head, pts, ps_a, ps_b)
-        ctx.cw, ctx.iw, ctx.inverse = cw, iw, inverse
+        ctx.cw, ctx.iw, ctx.inverse, ctx.window_dev, ctx.use_iw = cw, iw, inverse, window_dev, use_index_window
         return out
 
     @staticmethod
@@ -344,9 +367,9 @@ class _Warp(torch.autograd.Function):
         ws = torch.empty(lib.niw_warp_bwd_workspace_floats(B, P), device=pts.device, dtype=torch.float32)
         d_w_emb, d_view_b, d_w_head = torch.empty_like(w_emb), torch.empty_like(view_b), torch.empty_like(w_head)   # fully overwritten
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[3] else None
-        _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, ctx.iw, _p(ps_a), _p(ps_b),
-                  _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
-        return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None, None
+        _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, ctx.iw, _p(ctx.window_dev), 1 if ctx.use_iw else 0,
+                  _p(ps_a), _p(ps_b), _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
+        return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None, None, None, None
 
 
 WARP_PARAM_FLOATS = 165900
@@ -400,9 +423,11 @@ def warp_prepare(flat, params, code):
     return _WarpPrep.apply(flat, code, *params)
 
 
-def warp_points(w_emb, view_b, w_head, pts, chan_w, index_window=None, ps_a=None, ps_b=None, inverse=False):
-    """pts [B,P,3] -> warped [B,P,3]; see include/niw.h niw_warp_fwd for the operand layout."""
-    return _Warp.apply(w_emb, view_b, w_head, pts, chan_w, index_window, ps_a, ps_b, inverse)
+def warp_points(w_emb, view_b, w_head, pts, chan_w, index_window=None, ps_a=None, ps_b=None, inverse=False, window_dev=None,
+                use_index_window=False):
+    """pts [B,P,3] -> warped [B,P,3]; see include/niw.h niw_warp_fwd for the operand layout.  window_dev: device tensor [12] =
+    {chan_w, index_window} read by the kernels at run time (then use_index_window says whether the index window applies)."""
+    return _Warp.apply(w_emb, view_b, w_head, pts, chan_w, index_window, ps_a, ps_b, inverse, window_dev, use_index_window)
 
 
 # ------------------------------------------------------------------------------------------
@@ -433,6 +458,49 @@ def kabsch_rotation(M):
     return _KabschRotation.apply(M)
 
 
+def rigid_registration(target, source, reduce_moments=None):
+    """[R|t] [B,3,4] minimising sum_i |R x_i + t - y_i|^2 per view, x = target, y = source [B,N,3] (Kabsch with reflection fix:
+    what `roma.rigid_points_registration(target, source)` returns at reference nerf_inn_llff.py:569, pose_models/inn.py:100).
+    Two launches (fp64 moments, per-view solve); gradient-free: wherever the reference differentiates through it the derivative
+    vanishes (see alignment_residual).  reduce_moments: callable summing the [B,16] float64 moment buffer over ranks in place
+    (ray sharding: every rank registers the GLOBAL point set)."""
+    target, source = _f32(target.detach(), "target"), _f32(source.detach(), "source")
+    B, N = target.shape[0], target.shape[1]
+    mom = torch.empty(B, 16, device=target.device, dtype=torch.float64)
+    _lib.call("niw_align_moments", _p(target), _p(source), B, N, _p(mom), _stream())
+    if reduce_moments is not None:
+        reduce_moments(mom)
+    poses = torch.empty(B, 3, 4, device=target.device)
+    _lib.call("niw_align_solve", _p(mom), B, _p(poses), _stream())
+    return poses
+
+
+class _AlignResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, source, poses, n_norm):
+        target, source, poses = _f32(target, "target"), _f32(source, "source"), _f32(poses, "poses")
+        B, N = target.shape[0], target.shape[1]
+        loss = torch.empty(1, device=target.device)
+        d_target = torch.empty_like(target) if ctx.needs_input_grad[0] else None
+        _lib.call("niw_align_loss", _p(target), _p(source), _p(poses), B, N, float(n_norm if n_norm is not None else 3 * B * N),
+                  _p(loss), _p(d_target), _stream())
+        ctx.save_for_backward(d_target)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_target,) = ctx.saved_tensors
+        return (None if d_target is None else d_target * g), None, None, None
+
+
+def alignment_residual(target, source, poses, n_norm=None):
+    """mean |target - cam2world(source, poses)|^2 (nerf_inn_llff.py:571-572, nerf_inn_dtu.py:413-414) and its gradient w.r.t.
+    `target` in one launch.  `poses` is treated as a constant: when it is the rigid registration of target onto source the loss
+    is stationary in it, so the direct term is the total derivative (csrc/niw_align.hip; the DTU model detaches it anyway).
+    n_norm: element count of the mean (3 * B * N of the GLOBAL batch under ray sharding)."""
+    return _AlignResidual.apply(target, source, poses, n_norm)
+
+
 # ------------------------------------------------------------------------------------------
 # photometric loss
 # ------------------------------------------------------------------------------------------
@@ -445,7 +513,7 @@ class _MSE(torch.autograd.Function):
         hw = image.shape[-1] * image.shape[-2] if image.dim() == 4 else image.shape[-1]
         if ray_idx is not None:
             ray_idx = ray_idx.to(device=rgb.device, dtype=torch.int64).contiguous()
-        loss = torch.zeros(1, device=rgb.device)
+        loss = torch.empty(1, device=rgb.device)
         d_rgb = torch.empty_like(rgb)
         n = float(n_norm if n_norm is not None else rgb.numel())
         _lib.call("niw_mse_fwd_bwd", _p(rgb), _p(image), _p(ray_idx), B, R, hw, n, 1.0, _p(loss), _p(d_rgb), _stream())

@@ -39,6 +39,13 @@ def shard_ray_idx(ray_idx, rank, world):
     return ray_idx[rank::world]
 
 
+def all_reduce_sum_(t):
+    """In-place SUM over ranks (identity without a process group): the [B,16] Kabsch moments of the alignment loss."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def global_loss_elements(n_views, n_rays_global):
     """Element count of the global-batch MSE mean (3 colour channels)."""
     return 3 * n_views * n_rays_global

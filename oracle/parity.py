@@ -22,7 +22,7 @@ def psnr_trajectories(dev, steps=25, B=3, H=12, W=16, R=16, S=32, seed=7):
     opt = configs.cfg3_barf_inn_llff(device=dev, global_alignment=None)
     opt.H, opt.W = H, W
     opt.nerf.sample_intvs, opt.nerf.rand_rays = S, R * B
-    tr = engine.INNTrainer(opt, B, warp_perturb=0.0)
+    tr = engine.INNTrainer(opt, B, warp_perturb=0.0, ray_sampler="randperm")     # the harness injects the pixel draw through torch.randperm
     pc, wp, lat = O.make_nerf_params(71), O.make_warp_params(72, 0.02), O.make_latent(73, B)
     with torch.no_grad():
         for mod, prm in ((tr.graph.nerf, pc), (tr.graph.warp_mlp, wp)):

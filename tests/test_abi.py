@@ -81,13 +81,17 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
         "niw_mlp_bwd_dw": (None, None, 4, 8, None, None, None),
         "niw_composite_bwd": (None,) * 4 + (4, 8, 0, 0.0) + (None,) * 8,
         "niw_sample_stratified": (None, 4, 8, 0.0, 1.0, 0, None, None),
-        "niw_raygen": (None, None, None, 2, 4, 8, 8, 0, None, None, None),
+        "niw_raygen": (None, None, None, 0, 2, 4, 8, 8, 0, None, None, None),
+        "niw_draw_ray_idx": (64, 8, 1, 1, None, 0, 1, None, None),
         "niw_convert_ndc": (None, None, None, 2, 4, 1.0, None, None, None),
-        "niw_warp_fwd": (None,) * 4 + (2, 4, None, None, None, None, 0, None, None),
+        "niw_warp_fwd": (None,) * 4 + (2, 4, None, None, None, 0, None, None, 0, None, None),
         "niw_warp_prep_fwd": (None, None, 2, None, None, None, None, None),
         "niw_warp_prep_bwd": (None, None, 2) + (None,) * 7,
         "niw_mse_fwd_bwd": (None, None, None, 2, 4, 64, 1.0, 1.0, None, None, None),
-        "niw_adam_step": (None,) * 4 + (8, 1e-3, 0.9, 0.999, 1e-8, 1, None),
+        "niw_adam_step": (None,) * 4 + (8, 1e-3, 0.9, 0.999, 1e-8, 1, None, None),
+        "niw_align_moments": (None, None, 2, 8, None, None),
+        "niw_align_solve": (None, 2, None, None),
+        "niw_align_loss": (None, None, None, 2, 8, 48.0, None, None, None),
     }
     for name, args in cases.items():
         assert len(args) == len(_lib.SIGNATURES[name][1]), name

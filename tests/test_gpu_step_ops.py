@@ -1,0 +1,195 @@
+"""The operations around the MLP that a training step is made of besides the render kernels: fused alignment loss, sort-free
+pixel draw, pixel-range ray generation, single-launch losses, device-resident step constants and the HIP-graph replay of a whole
+iteration.  Each against the CPU oracle / a torch restatement on the same inputs.  Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import niw_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _points(B, N, seed, reflect=False):
+    gen = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, N, 3, generator=gen)
+    A = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen))[0]
+    if reflect:
+        A[:, :, 0] *= torch.sign(torch.det(A))[:, None] * -1            # improper: forces the det(UV^T) = -1 branch
+    tgt = src @ A.transpose(1, 2) + torch.randn(B, 1, 3, generator=gen) + 0.1 * torch.randn(B, N, 3, generator=gen)
+    return src, tgt
+
+
+@pytest.mark.parametrize("B,N,reflect", [(18, 226, False), (56, 72, False), (3, 1364, False), (5, 40, True)])
+def test_fused_alignment_loss_vs_oracle_autograd_through_svd(B, N, reflect):
+    from neural_invertible_warp_amd import ops
+    src, tgt = _points(B, N, seed=B + N, reflect=reflect)
+    t64 = tgt.double().requires_grad_(True)
+    Rg, tg = O.rigid_registration(t64, src.double())
+    ref_pose = torch.cat([Rg, tg[..., None]], -1)
+    ref = ((t64 - O.cam2world(src.double(), ref_pose)) ** 2).mean()
+    ref.backward()                                                        # the reference's route: autograd THROUGH the SVD
+    tg_dev = tgt.to(DEV).requires_grad_(True)
+    poses = ops.rigid_registration(tg_dev, src.to(DEV))
+    loss = ops.alignment_residual(tg_dev, src.to(DEV), poses)
+    (3.0 * loss).backward()
+    assert torch.allclose(poses.cpu().double(), ref_pose.detach(), atol=2e-6)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, float(ref.detach()))
+    g = tg_dev.grad.cpu().double() / 3.0
+    assert (g - t64.grad).abs().max() <= 2e-6 * t64.grad.abs().max() + 1e-12
+    # rotations: orthonormal with determinant +1, also when the unconstrained optimum is a reflection
+    R = poses[:, :, :3].double().cpu()
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(B, 3, 3), atol=1e-6)
+    assert (torch.det(R) - 1).abs().max() < 1e-6
+
+
+def test_pixel_draw_is_a_partitioned_duplicate_free_uniform_subset():
+    from neural_invertible_warp_amd import ops
+    HW = 300 * 400
+    a = ops.draw_ray_idx(HW, 2048, seed=0, draw=1, device=DEV).cpu().numpy()
+    assert a.min() >= 0 and a.max() < HW and len(set(a.tolist())) == 2048
+    # ranks keep idx[rank::world] of the SAME permutation: disjoint, together the unsharded draw
+    parts = [ops.draw_ray_idx(HW, len(range(r, 2048, 8)), seed=0, draw=1, device=DEV, first=r, stride=8).cpu().numpy() for r in range(8)]
+    for r in range(8):
+        assert np.array_equal(parts[r], a[r::8])
+    # a fresh subset per draw and per seed; draw_dev overrides the by-value draw number
+    b = ops.draw_ray_idx(HW, 2048, seed=0, draw=2, device=DEV).cpu().numpy()
+    c = ops.draw_ray_idx(HW, 2048, seed=1, draw=1, device=DEV).cpu().numpy()
+    assert len(set(a.tolist()) & set(b.tolist())) < 100 and len(set(a.tolist()) & set(c.tolist())) < 100
+    word = torch.tensor([2], dtype=torch.int64, device=DEV)
+    assert np.array_equal(ops.draw_ray_idx(HW, 2048, seed=0, draw=999, device=DEV, draw_dev=word).cpu().numpy(), b)
+    # the whole permutation: every pixel exactly once (also for sizes that are not powers of two / four)
+    for n in (HW, 12 * 16, 1000, 4097):
+        full = ops.draw_ray_idx(n, n, seed=3, draw=7, device=DEV).cpu().numpy()
+        assert np.array_equal(np.sort(full), np.arange(n))
+    # uniformity of the first 2048 of 120,000 over many draws: mean pixel id and a chi-square over 16 bins
+    draws = np.concatenate([ops.draw_ray_idx(HW, 2048, seed=5, draw=d, device=DEV).cpu().numpy() for d in range(200)])
+    assert abs(draws.mean() / HW - 0.5) < 0.005
+    hist = np.histogram(draws, bins=16, range=(0, HW))[0]
+    expected = len(draws) / 16
+    assert ((hist - expected) ** 2 / expected).sum() < 50           # 15 dof: 50 is far in the tail
+
+
+def test_raygen_pixel_range_equals_index_tensor():
+    from neural_invertible_warp_amd import ops
+    H, W, B = 30, 40, 3
+    intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], device=DEV).repeat(B, 1, 1)
+    pose = torch.eye(3, 4, device=DEV).repeat(B, 1, 1)
+    pose[:, :, 3] = torch.randn(B, 3, device=DEV)
+    for mode in (0, 1):
+        a = ops.raygen(intr, pose, torch.arange(100, 777, device=DEV), H, W, mode)
+        b = ops.raygen(intr, pose, None, H, W, mode, pixel_range=(100, 677))
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    full = ops.raygen(intr, pose, None, H, W, 1)
+    assert torch.equal(full[1][:, 100:777], b[1])
+    from neural_invertible_warp_amd._lib import NiwError
+    with pytest.raises(NiwError, match="leaves the"):
+        ops.raygen(intr, pose, None, H, W, 1, pixel_range=(1000, 400))
+
+
+def test_image_sweep_is_slice_independent():
+    """render_by_slices in pixel ranges of any size gives bit-identical images (reference nerf.py:321-332 semantics)"""
+    from neural_invertible_warp_amd import configs
+    from neural_invertible_warp_amd.model import nerf
+    opt = configs.cfg1_nerf_llff_repr(device=DEV)
+    opt.H, opt.W = 24, 32
+    opt.nerf.sample_stratified = False
+    opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine = 16, 16
+    g = nerf.Graph(opt)
+    intr = torch.tensor([[0.8 * 32, 0, 16], [0, 0.8 * 32, 12], [0, 0, 1]], device=DEV)[None]
+    pose = torch.eye(3, 4, device=DEV)[None]
+    with torch.no_grad():
+        outs = []
+        for rays in (768, 100, 257):
+            opt.nerf.rand_rays = rays
+            outs.append(g.render_by_slices(opt, pose, intr=intr, mode="eval"))
+    for k in outs[0]:
+        assert outs[0][k].shape[1] == 24 * 32
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k
+
+
+def test_mse_single_launch_matches_torch_at_full_image():
+    from neural_invertible_warp_amd import ops
+    B, H, W = 2, 300, 400
+    rgb = torch.rand(B, H * W, 3, device=DEV).requires_grad_(True)
+    image = torch.rand(B, 3, H, W, device=DEV)
+    loss = ops.mse_gather(rgb, image)
+    loss.backward()
+    r2 = rgb.detach().clone().requires_grad_(True)
+    ref = ((r2 - image.view(B, 3, H * W).permute(0, 2, 1)) ** 2).mean()
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6
+    assert (rgb.grad - r2.grad).abs().max() < 1e-9
+    assert torch.equal(ops.mse_gather(rgb.detach(), image), ops.mse_gather(rgb.detach(), image))     # no float atomics
+
+
+def test_ndc_reparametrisation_keeps_the_gradient_to_the_warp():
+    """with camera.ndc the rays of a training step still depend on the warp; the photometric gradient must reach
+    warp_mlp / warp_latent (the NDC kernel has no backward, so that case runs as torch algebra) and match the kernel's values."""
+    from neural_invertible_warp_amd import camera, configs, ops
+    from neural_invertible_warp_amd.model import barf_inn_llff
+    from neural_invertible_warp_amd.util import edict
+    opt = configs.cfg3_barf_inn_llff(device=DEV, global_alignment=None)
+    opt.H, opt.W, opt.camera.ndc = 24, 32, True
+    opt.nerf.sample_intvs, opt.nerf.rand_rays = 16, 3 * 20
+    opt.nerf.depth.range = [0, 1]
+    opt.nerf.depth.param = "metric"
+    graph = barf_inn_llff.Graph(opt).attach_warp(opt, 3)
+    with torch.no_grad():
+        for name, p in graph.warp_mlp.named_parameters():
+            if "_1." in name or "_c." in name:
+                p.normal_(0.0, 0.02)
+    var = edict(idx=torch.arange(3), image=torch.rand(3, 3, 24, 32, device=DEV),
+                intr=torch.tensor([[0.8 * 32, 0, 16], [0, 0.8 * 32, 12], [0, 0, 1]], device=DEV).repeat(3, 1, 1))
+    var = graph.forward(opt, var, mode="train", iter=50000)
+    graph.compute_loss(opt, var, mode="train").render.backward()
+    assert graph.warp_latent.weight.grad is not None and graph.warp_latent.weight.grad.abs().max() > 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in graph.warp_mlp.parameters())
+    # torch route == kernel route on the same rays
+    c = torch.randn(3, 50, 3, device=DEV) * 0.1
+    r = torch.randn(3, 50, 3, device=DEV) * 0.2 + torch.tensor([0.0, 0.0, 1.0], device=DEV)
+    a = camera.convert_NDC(opt, c, r, var.intr)
+    b = camera.convert_NDC(opt, c.clone().requires_grad_(True), r, var.intr)
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x, y.detach(), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("family", ["llff", "dtu"])
+def test_hip_graph_replay_equals_eager_training(family):
+    """The captured iteration (engine.INNTrainer(hip_graph=True): constants uploaded per step, one graph replay) must train exactly
+    like the eager engine: same pixel draws (Feistel, keyed by the iteration), deterministic mid-point samples, 8 steps; parameters
+    agree to the noise of the float atomics of the ray-gradient accumulation."""
+    from neural_invertible_warp_amd import configs, engine
+
+    def run(hip_graph):
+        if family == "llff":
+            opt = configs.cfg3_barf_inn_llff(device=DEV)
+            B = 5
+            var0, init = engine.synthetic_scene(opt, B), None
+        else:
+            opt = configs.cfg5_barf_inn_dtu(device=DEV)
+            B = 3
+            var0, init = engine.synthetic_dtu_scene(opt, B)
+        opt.nerf.sample_stratified = False
+        opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = B * 40, 32, 40      # short schedules: c2f bands, windows and lr all move
+        opt.inn.real_nvp.max_pe_iter = 20
+        tr = engine.INNTrainer(opt, B, warp_perturb=0.02, seed=11, initial_poses_w2c=init, hip_graph=hip_graph)
+        losses = []
+        for _ in range(8):
+            loss = tr.train_iteration(type(var0)(var0))
+            losses.append({k: float(v.detach()) for k, v in loss.items()})
+        return tr, losses
+
+    eager, l_e = run(False)
+    graph, l_g = run(True)
+    assert graph._captured is not None and not getattr(graph, "hip_graph_failed", False), "the iteration was not captured"
+    for a, b in zip(l_e, l_g):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-4 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
+    for fa, fb in zip(eager._flats(), graph._flats()):
+        assert (fa - fb).abs().max() <= 5e-4 * fa.abs().max()
+    assert l_g[-1]["render"] < l_g[0]["render"]
+    # the c2f progress Parameter is written on demand under replay
+    graph.sync_state()
+    assert abs(float(graph.graph.nerf.progress.data) - 8 / 40) < 1e-7

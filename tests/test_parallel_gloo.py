@@ -112,17 +112,11 @@ def _ga_points(seed=3):
     return src, tgt
 
 
-def _torch_rotation(M):
-    """U diag(1,1,det(UV^T)) V^T by torch.linalg.svd: stands in for the HIP solver in this CPU-only test of the moments' all-reduce"""
-    U, _, Vt = torch.linalg.svd(M)
-    det = torch.det(U @ Vt)
-    return U @ torch.diag_embed(torch.stack([torch.ones_like(det), torch.ones_like(det), det], dim=-1)) @ Vt
-
-
 def _ga_worker(rank, world, port, q):
     from neural_invertible_warp_amd import parallel
     from neural_invertible_warp_amd.model import nerf_inn_llff
-    nerf_inn_llff.ROTATION_SOLVER = _torch_rotation
+    from tests.util import TorchAlign
+    nerf_inn_llff.ALIGN_BACKEND = TorchAlign          # torch restatement of the fused kernels: this test is about the sharding
     from neural_invertible_warp_amd.util import edict
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
@@ -148,10 +142,7 @@ def _ga_worker(rank, world, port, q):
 
 
 def test_sharded_kabsch_alignment_loss_matches_single_process():
-    from neural_invertible_warp_amd import camera
-    from neural_invertible_warp_amd.model import nerf_inn_llff
-    from neural_invertible_warp_amd.model.nerf_inn_llff import rigid_points_registration
-    nerf_inn_llff.ROTATION_SOLVER = _torch_rotation
+    from oracle import niw_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -163,8 +154,9 @@ def test_sharded_kabsch_alignment_loss_matches_single_process():
         p.join(timeout=300)
         assert p.exitcode == 0
     src, tgt = _ga_points()
-    Rg, tg = rigid_points_registration(tgt, src)
-    loss = ((tgt - camera.cam2world(src, torch.cat([Rg, tg[..., None]], -1))) ** 2).mean()
+    # single process, the reference's formulation: autograd THROUGH the SVD of the registration (oracle)
+    Rg, tg = O.rigid_registration(tgt, src)
+    loss = ((tgt - O.cam2world(src, torch.cat([Rg, tg[..., None]], -1))) ** 2).mean()
     loss.backward()
     assert abs(float(lsum) - float(loss)) < 1e-6 * max(1.0, float(loss))
     assert (tgt.grad - torch.from_numpy(grad2)).abs().max() <= 1e-4 * tgt.grad.abs().max()

@@ -31,28 +31,33 @@ def main():
     dev = "cuda:0"
     sizes = FULL if args.sizes == "full" else TRAIN if args.sizes == "train" else FULL + TRAIN
     lines = []
+    from neural_invertible_warp_amd import _lib
+    P = ops._p
     for N, S in sizes:
         gen = torch.Generator(device=dev).manual_seed(N + S)
         ray = torch.randn(N, 3, device=dev, generator=gen)
-        rgb_s = torch.rand(N, S, 3, device=dev, generator=gen).requires_grad_(True)
-        sig = (torch.rand(N, S, device=dev, generator=gen) * 2).requires_grad_(True)
+        rgb_s = torch.rand(N, S, 3, device=dev, generator=gen)
+        sig = torch.rand(N, S, device=dev, generator=gen) * 2
         dep = (torch.rand(N, S, device=dev, generator=gen) * 0.9 / S + torch.arange(S, device=dev) / S + 1.0).contiguous()
         g_rgb = torch.randn(N, 3, device=dev, generator=gen)
-        ev = lambda: torch.cuda.Event(enable_timing=True)
-        t_f, t_b = [], []
-        for i in range(args.iters + 2):
-            a, b, c = ev(), ev(), ev()
-            rgb_s.grad = sig.grad = None
+        rgb, depth, opa, prob = torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, S, device=dev)
+        d_rgb_s, d_sig, d_ray = torch.empty_like(rgb_s), torch.empty_like(sig), torch.empty_like(ray)
+        st = ops._stream()
+        fwd = lambda: _lib.call("niw_composite_fwd", P(ray), P(rgb_s), P(sig), P(dep), N, S, 0, 0.0, P(rgb), P(depth), P(opa), P(prob), st)
+        bwd = lambda: _lib.call("niw_composite_bwd", P(ray), P(rgb_s), P(sig), P(dep), N, S, 0, 0.0, P(g_rgb), None, None, None, P(d_rgb_s), P(d_sig), P(d_ray), st)
+
+        def timed(fn):
+            # `iters` launches back to back between two device events: kernel time + the ~1.5 us kernel boundary
+            fn(); fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            rgb, d, opa, prob = ops.composite(ray, rgb_s, sig, dep)
+            for _ in range(args.iters):
+                fn()
             b.record()
-            rgb.backward(g_rgb)
-            c.record()
             torch.cuda.synchronize()
-            if i >= 2:
-                t_f.append(a.elapsed_time(b))
-                # backward event time includes the autograd engine's launch of ONE kernel; at full-image size it is all kernel
-                t_b.append(b.elapsed_time(c))
+            return [a.elapsed_time(b) / args.iters]
+
+        t_f, t_b = timed(fwd), timed(bwd)
         bytes_f = N * S * 24 + N * 32            # rgb 12 + sigma 4 + depth 4 in, prob 4 out per sample; ray 12 in + 20 out per ray
         bytes_b = N * S * 36 + N * 36            # 20 in + 16 out per sample (no d_prob); ray 12 + d_rgb 12 in, d_ray 12 out per ray
         med = lambda v: sorted(v)[len(v) // 2]
