@@ -29,13 +29,22 @@ namespace {
 
 constexpr int kLdsStride = 36;   // 32 samples + 4 pad floats per row
 
+// Up to kMaxBatch independent products per launch (blockIdx.y): the seven 256 x 256 weight gradients of a network, or its four
+// skinny pieces -- each with its own operand pair and bias side.
+constexpr int kMaxBatch = 8;
+struct GemmBatch {
+    NiwGemmOperand A[kMaxBatch], B[kMaxBatch];
+    int bias_side[kMaxBatch];
+};
+
 // WN x WK waves; each wave owns NBW x KBW blocks of 32x32 outputs.
 template <int WN, int WK, int NBW, int KBW>
-__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(NiwGemmOperand opA, NiwGemmOperand opB, int spb,
-                                                               int steps_total, int steps_per_wg,
-                                                               float* __restrict__ partial, int bias_side) {
-    const float* __restrict__ A = opA.p + (long long)blockIdx.y * opA.batch_stride;
-    const float* __restrict__ B = opB.p + (long long)blockIdx.y * opB.batch_stride;
+__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int spb, int steps_total, int steps_per_wg,
+                                                               float* __restrict__ partial) {
+    const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
+    const int bias_side = batch.bias_side[blockIdx.y];
+    const float* __restrict__ A = opA.p;
+    const float* __restrict__ B = opB.p;
     const int rowsA = opA.rows, rowsB = opB.rows;
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
     constexpr int ROWS = TN + TK;
@@ -146,16 +155,20 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(NiwGemmOperand op
     if (tid < 256) out[TN * TK + tid] = bsum;
 }
 
-// Deterministic reduction of the partial tiles + scatter into the flat parameter gradient.
+// Deterministic reduction of the partial tiles + scatter into the flat parameter gradient: ONE launch for all pieces of a
+// network (blockIdx.y = piece).
 struct ReduceArgs {
-    const float* partial;
-    float* d_params;
+    long long partial_off;   // floats from the start of the partial workspace to this piece's [nsplit][TN*TK + 256] tiles
     int nsplit, TN, TK;
     int layer;        // 0..9
     int n_off;        // kernel-row offset of tile row 0 (dY side)
     int k_off;        // slot offset of tile column 0 (X side)
     int transposed;   // tile is [slot][row] instead of [row][slot]
     int bias;         // 0: none, 1: bias sums indexed by the dY row
+};
+constexpr int kMaxPieces = 16;
+struct ReduceBatch {
+    ReduceArgs r[kMaxPieces];
 };
 
 // fixed-order sum over the split-M partial tiles with 8 independent accumulators (8 loads in flight
@@ -171,23 +184,23 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ p, long 
     return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-__global__ void dw_reduce_kernel(ReduceArgs a) {
+__global__ void dw_reduce_kernel(ReduceBatch batch, const float* __restrict__ partial_base, float* __restrict__ d_params) {
+    const ReduceArgs a = batch.r[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int tile = a.TN * a.TK;
     const int stride = tile + 256;
-    const int layer = a.layer + blockIdx.y;                  // batched launch: blockIdx.y-th of consecutive layers
-    const float* partial = a.partial + (long long)blockIdx.y * a.nsplit * stride;
+    const float* partial = partial_base + a.partial_off;
     if (idx < tile) {
         const int tr = idx / a.TK, tc = idx % a.TK;
         const int n = a.n_off + (a.transposed ? tc : tr), s = a.k_off + (a.transposed ? tr : tc);
-        const int row = out_row(layer, n), col = fwd_slot_col(layer, s);
+        const int row = out_row(a.layer, n), col = fwd_slot_col(a.layer, s);
         if (row < 0 || col < 0) return;
-        a.d_params[weight_off(layer) + row * layer_k(layer) + col] = sum_partials(partial + idx, stride, a.nsplit);
+        d_params[weight_off(a.layer) + row * layer_k(a.layer) + col] = sum_partials(partial + idx, stride, a.nsplit);
     } else if (a.bias && idx < tile + 256) {
         const int b = idx - tile;
-        const int row = out_row(layer, a.n_off + b);
+        const int row = out_row(a.layer, a.n_off + b);
         if (row < 0 || b >= (a.transposed ? a.TK : a.TN)) return;
-        a.d_params[bias_off(layer) + row] = sum_partials(partial + idx, stride, a.nsplit);
+        d_params[bias_off(a.layer) + row] = sum_partials(partial + idx, stride, a.nsplit);
     }
 }
 
@@ -199,8 +212,7 @@ struct Piece {
 };
 
 template <int WN, int WK, int NBW, int KBW>
-int launch_gemm(NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial, int bias_side,
-                int* nsplit_out, hipStream_t st) {
+int launch_gemm(const GemmBatch& batch, int spb, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
     // at least 8 slices per workgroup; one workgroup per CU, or -- for a batch of equal pieces -- just under two
@@ -214,41 +226,42 @@ int launch_gemm(NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int
     auto kern = dw_gemm_kernel<WN, WK, NBW, KBW>;
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM")) return rc;
-    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(A, B, spb, steps_total, per, partial, bias_side);
+    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(batch, spb, steps_total, per, partial);
     NIW_LAUNCH_CHECK("NT GEMM");
     *nsplit_out = nsplit;
     return NIW_OK;
 }
 
-int launch_piece(const Piece& p, NiwGemmOperand A, NiwGemmOperand B, long long mpad, int batches, float* partial, float* d_params,
-                 hipStream_t st) {
-    const int bias_side = p.bias ? (p.transposed ? 2 : 1) : 0;
-    int nsplit = 0;
-    int rc = niw_launch_nt_gemm(p.wide, A, B, (int)(mpad / 32), mpad, batches, partial, bias_side, &nsplit, st);
-    if (rc != NIW_OK) return rc;
-    ReduceArgs r;
-    r.partial = partial; r.d_params = d_params; r.nsplit = nsplit; r.layer = p.layer;
-    r.TN = p.wide == 2 ? 128 : 256;
-    r.TK = p.wide == 2 ? 288 : (p.wide == 1 ? 256 : 64);
-    r.n_off = p.n_off; r.k_off = p.k_off; r.transposed = p.transposed; r.bias = p.bias;
-    dw_reduce_kernel<<<dim3((r.TN * r.TK + 256 + 255) / 256, batches), 256, 0, st>>>(r);
-    NIW_LAUNCH_CHECK("niw_mlp_bwd (dW reduce)");
-    return NIW_OK;
+int launch_shape(int wide, const GemmBatch& batch, int spb, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
+    // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
+    if (wide == 2) return launch_gemm<4, 1, 1, 9>(batch, spb, mpad, batches, partial, nsplit_out, st);
+    return wide ? launch_gemm<4, 2, 2, 4>(batch, spb, mpad, batches, partial, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2>(batch, spb, mpad, batches, partial, nsplit_out, st);
 }
 
 }  // namespace
 
 int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
                        int bias_side, int* nsplit_out, hipStream_t st) {
-    // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
-    if (wide == 2) return launch_gemm<4, 1, 1, 9>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st);
-    return wide ? launch_gemm<4, 2, 2, 4>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st)
-                : launch_gemm<8, 1, 1, 2>(A, B, spb, mpad, batches, partial, bias_side, nsplit_out, st);
+    // `batches` products whose operands are batch_stride floats apart
+    if (batches < 1 || batches > kMaxBatch) {
+        niw_set_error("NT GEMM: %d batches (1..%d)", batches, kMaxBatch);
+        return NIW_ERR_INVALID_ARG;
+    }
+    GemmBatch gb{};
+    for (int b = 0; b < batches; ++b) {
+        gb.A[b] = A; gb.A[b].p = A.p + (long long)b * A.batch_stride;
+        gb.B[b] = B; gb.B[b].p = B.p + (long long)b * B.batch_stride;
+        gb.bias_side[b] = bias_side;
+    }
+    return launch_shape(wide, gb, spb, mpad, batches, partial, nsplit_out, st);
 }
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
     (void)n_rays; (void)n_samples;
-    return 512ll * (256 * 256 + 256);          // up to 511 partial tiles (7 batched pieces x 73 splits)
+    // every group's partial tiles live side by side until the single reduction: <= 511 tiles of 256 x 256 (7 x 73 splits),
+    // <= 508 of 256 x 64 (4 x 127), <= 256 of 128 x 288
+    return 511ll * (256 * 256 + 256) + 508ll * (256 * 64 + 256) + 256ll * (128 * 288 + 256);
 }
 
 extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
@@ -272,27 +285,48 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     hipStream_t st = (hipStream_t)stream;
     // dW pieces.  Non-transposed: tile rows = dY rows (gradws), tile columns = X slots (save).
     // Transposed (skinny dY: the density row, the 3 colour rows): tile rows = X slots, columns = dY rows.
-    const Piece pieces[] = {
+    // Four launches per network: [layers 1..7: seven 256 x 256 products] [four 256 x 64 pieces] [the colour layer, 128 x 288]
+    // [one reduction of all twelve partial-tile sets].
+    static_assert(kGradY7 == 7 * 256, "dY blocks of layers 0..7 are uniformly strided");
+    const Piece wide[7] = {
         // layer, a_row, a_rows, b_row, b_rows, n_off, k_off, transposed, bias, wide
-        {0, 0 * 256, 256, kSaveEnc, 64, 0, 0, 0, 1, 0},
-        // layers 1..7, 256 x 256 each: dY rows l*256 (kGradY7 = 7*256), X rows save_h(l) = 64 + (l-1)*256 -> ONE batched
-        // launch of 7 pieces (batch stride 256 rows on both sides)
-        {1, 1 * 256, 256, save_h(1), 256, 0, 0, 0, 1, 1},
-        {4, 4 * 256, 256, kSaveEnc, 64, 0, 256, 0, 0, 0},
+        {1, 1 * 256, 256, save_h(1), 256, 0, 0, 0, 1, 1}, {2, 2 * 256, 256, save_h(2), 256, 0, 0, 0, 1, 1},
+        {3, 3 * 256, 256, save_h(3), 256, 0, 0, 0, 1, 1}, {4, 4 * 256, 256, save_h(4), 256, 0, 0, 0, 1, 1},
+        {5, 5 * 256, 256, save_h(5), 256, 0, 0, 0, 1, 1}, {6, 6 * 256, 256, save_h(6), 256, 0, 0, 0, 1, 1},
+        {7, 7 * 256, 256, save_h(7), 256, 0, 0, 0, 1, 1}};
+    const Piece skinny[4] = {
+        {0, 0 * 256, 256, kSaveEnc, 64, 0, 0, 0, 1, 0},                  // first layer: 256 x 64 encoding slots
+        {4, 4 * 256, 256, kSaveEnc, 64, 0, 256, 0, 0, 0},                // skip connection: encoding columns of layer 4
         {7, save_h(7), 256, kGradY7 + 256, 1, 256, 0, 1, 1, 0},          // density row (transposed)
-        {8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2},              // feat rows and the 32 view-slot rows are contiguous
-        {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0},                  // colour rows (transposed)
-    };
-    static_assert(kGradY7 == 7 * 256, "the batched wide launch assumes uniformly strided dY blocks");
-    for (const Piece& p : pieces) {
-        // workspaces are plain feature-major [row][Mpad]: row pitch Mpad, a single sample block
-        const int batches = p.wide == 1 ? 7 : 1;
-        const long long bstride = batches > 1 ? 256 * mpad : 0;
-        const NiwGemmOperand A{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, bstride, mpad, 0};
-        const NiwGemmOperand B{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, bstride, mpad, 0};
-        int rc = launch_piece(p, A, B, mpad, batches, partial, d_params, st);
+        {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0}};                 // colour rows (transposed)
+    const Piece colour[1] = {{8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2}};   // feat rows and the 32 view-slot rows are contiguous
+    struct Group { const Piece* p; int n, wide, TN, TK; };
+    const Group groups[3] = {{wide, 7, 1, 256, 256}, {skinny, 4, 0, 256, 64}, {colour, 1, 2, 128, 288}};
+    ReduceBatch rb{};
+    int n_pieces = 0, max_tile = 0;
+    long long off = 0;
+    for (const Group& g : groups) {
+        GemmBatch gb{};
+        for (int b = 0; b < g.n; ++b) {
+            const Piece& p = g.p[b];
+            // workspaces are plain feature-major [row][Mpad]: row pitch Mpad, a single sample block
+            gb.A[b] = NiwGemmOperand{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad, 0};
+            gb.B[b] = NiwGemmOperand{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad, 0};
+            gb.bias_side[b] = p.bias ? (p.transposed ? 2 : 1) : 0;
+        }
+        int nsplit = 0;
+        int rc = launch_shape(g.wide, gb, (int)(mpad / 32), mpad, g.n, partial + off, &nsplit, st);
         if (rc != NIW_OK) return rc;
+        const long long tile = (long long)g.TN * g.TK + 256;
+        for (int b = 0; b < g.n; ++b) {
+            const Piece& p = g.p[b];
+            rb.r[n_pieces++] = ReduceArgs{off + (long long)b * nsplit * tile, nsplit, g.TN, g.TK, p.layer, p.n_off, p.k_off, p.transposed, p.bias};
+        }
+        off += (long long)g.n * nsplit * tile;
+        max_tile = (int)tile > max_tile ? (int)tile : max_tile;
     }
+    dw_reduce_kernel<<<dim3((max_tile + 255) / 256, n_pieces), 256, 0, st>>>(rb, partial, d_params);
+    NIW_LAUNCH_CHECK("niw_mlp_bwd (dW reduce)");
     return NIW_OK;
 }
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
                                                    double n_norm, float grad_scale, float* __restrict__ loss, float* __restrict__ d_rgb) {
     __shared__ double red[16];
     const long long total = (long long)B * R * 3;
+    const double slope = (double)grad_scale * 2.0 / n_norm;        // d mean / d rgb = 2 diff / n (one fp64 divide per launch, not per element)
     double acc = 0.0;
     for (long long i = threadIdx.x; i < total; i += 1024) {
         const int c = (int)(i % 3);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
         const long long pix = ray_idx ? ray_idx[r] : r;
         const float diff = rgb[i] - image[(b * 3 + c) * hw + pix];
         acc += diff * diff;
-        if (d_rgb) d_rgb[i] = (float)((double)grad_scale * 2.0 * (double)diff / n_norm);
+        if (d_rgb) d_rgb[i] = (float)(slope * (double)diff);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

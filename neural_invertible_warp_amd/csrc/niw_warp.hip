@@ -53,7 +53,7 @@ __device__ __forceinline__ float dsoftplus100(float x) {
 #define NIW_WARP_GROUP 16
 #endif
 constexpr int kGroup = NIW_WARP_GROUP, kPtsPerWg = 256 / kGroup;
-static_assert(kGroup == 4 || kGroup == 8 || kGroup == 16, "lanes per point");
+static_assert(kGroup == 4 || kGroup == 8 || kGroup == 16 || kGroup == 32 || kGroup == 64, "lanes per point");
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int o = 1; o < kGroup; o <<= 1) v += __shfl_xor(v, o);
@@ -74,7 +74,8 @@ __device__ __forceinline__ void embed(const float (&x)[D], const float* __restri
 #pragma unroll
         for (int dd = 1; dd < D; ++dd) xv = d == dd ? x[dd] : xv;
         sl[t] = cl[t] = 0.f;
-        if (n < N) sincosf(niw::mul_rn(xv, kPi32 * (float)(1 << i)), &sl[t], &cl[t]);
+        // fl32(x * 2^i pi32) = 2^i fl32(x pi32) exactly: one fp64 range reduction, then a short polynomial (niw_common.h sincos_band)
+        if (n < N) niw::sincos_band((double)niw::mul_rn(xv, kPi32) * 0.15915494309189533577, i < kNF ? i : 0, sl[t], cl[t]);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) e[d] = ps * x[d];
@@ -158,6 +159,11 @@ __device__ __forceinline__ float index_scale(const Windows& w, long long p, int 
 }
 
 __device__ __forceinline__ void stage_weights(const WarpArgs& a, float* lw, float* lh, float* lv, int view) {
+#ifdef NIW_WARP_EXP_NOSTAGE
+    if (threadIdx.x < 64) { lw[threadIdx.x] = a.w_emb[threadIdx.x]; lh[threadIdx.x] = a.w_head[threadIdx.x]; lv[threadIdx.x] = a.view_b[threadIdx.x]; }
+    __syncthreads();
+    return;
+#endif
     for (int i = threadIdx.x; i < 3 * kWembBlock; i += blockDim.x) lw[i] = a.w_emb[i];
     for (int i = threadIdx.x; i < 3 * kHeadBlock; i += blockDim.x) lh[i] = a.w_head[i];
     for (int i = threadIdx.x; i < 3 * 2 * kHid; i += blockDim.x) lv[i] = a.view_b[(long long)view * 3 * 2 * kHid + i];
@@ -253,6 +259,12 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
     if (sub == 0) { a.out[gi * 3] = x[0]; a.out[gi * 3 + 1] = x[1]; a.out[gi * 3 + 2] = x[2]; }
 }
 
+// one per-point factor of the parameter gradients -> row `row` of the block's feature-major workspace
+#ifdef NIW_WARP_EXP_NOSTORE
+#define NIW_WS(row, v) do { if (a.n_pts < 0) ws[(long long)(row) * P] = (v); } while (0)
+#else
+#define NIW_WS(row, v) ws[(long long)(row) * P] = (v)
+#endif
 __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lw = lds;
@@ -309,8 +321,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
             const float pre = vb[u] + dot_row<kEb>(Wb + u * kEb, eb);
             const float gh = hdb[u] * go[0] + hdb[kHid + u] * go[1] + hdb[2 * kHid + u] * go[2];
             const float gp = gh * dsoftplus100(pre);
-            ws[(long long)(kRowGb + u) * P] = gp;
-            ws[(long long)(kRowHb + u) * P] = softplus100(pre);
+            NIW_WS(kRowGb + u, gp);
+            NIW_WS(kRowHb + u, softplus100(pre));
 #pragma unroll
             for (int k = 0; k < kEb; ++k) geb[k] += Wb[u * kEb + k] * gp;
         }
@@ -327,8 +339,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         for (int u = sub; u < kHid; u += kGroup) {
             const float pre = va[u] + dot_row<kEa>(Wa + u * kEa, ea);
             const float gp = g_delta * hda[u] * dsoftplus100(pre);
-            ws[(long long)(kRowGa + u) * P] = gp;
-            ws[(long long)(kRowHa + u) * P] = softplus100(pre);
+            NIW_WS(kRowGa + u, gp);
+            NIW_WS(kRowHa + u, softplus100(pre));
 #pragma unroll
             for (int k = 0; k < kEa; ++k) gea[k] += Wa[u * kEa + k] * gp;
         }
@@ -340,16 +352,16 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         // (the factor rows that do not depend on the hidden unit are split over the group)
 #pragma unroll
         for (int k = 0; k < 32; ++k)
-            if (k % kGroup == sub) ws[(long long)(kRowEa + k) * P] = k < kEa ? ea[k] : 0.f;
+            if (k % kGroup == sub) NIW_WS(kRowEa + k, k < kEa ? ea[k] : 0.f);
 #pragma unroll
         for (int k = 0; k < 32; ++k)
-            if (k % kGroup == sub) ws[(long long)(kRowEb + k) * P] = k < kEb ? eb[k] : 0.f;
-        for (int v = sub; v < 64; v += kGroup) ws[(long long)(kRowInd + v) * P] = v == view ? 1.f : 0.f;
+            if (k % kGroup == sub) NIW_WS(kRowEb + k, k < kEb ? eb[k] : 0.f);
+        for (int v = sub; v < 64; v += kGroup) NIW_WS(kRowInd + v, v == view ? 1.f : 0.f);
         if (sub == 0) {
-            ws[(long long)(kRowGo + 0) * P] = g_delta;
-            ws[(long long)(kRowGo + 1) * P] = go[0];
-            ws[(long long)(kRowGo + 2) * P] = go[1];
-            ws[(long long)(kRowGo + 3) * P] = go[2];
+            NIW_WS(kRowGo + 0, g_delta);
+            NIW_WS(kRowGo + 1, go[0]);
+            NIW_WS(kRowGo + 2, go[1]);
+            NIW_WS(kRowGo + 3, go[2]);
         }
         gx[f] = g_foc;
         gx[o0] = g_d0 + goth[0];

@@ -199,10 +199,15 @@ class INNTrainer:
         self._upload_constants(it)
         if self._captured is None or not replay:
             if not replay or it < 2 or not self._capture(var, it):
-                # warm-up (allocator, lazily built tables, kernel attributes) and fall-back: the same body, eagerly
-                loss = self._forward_backward(var, it)
-                self.bucket.all_reduce()
-                self._optimizer_step(it)
+                # warm-up (allocator, lazily built tables, kernel attributes) and fall-back: the same body, launch by launch, on the
+                # side stream the capture will use (autograd's gradient accumulators stay tied to the stream they first ran on)
+                side = self._side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    loss = self._forward_backward(var, it)
+                    self.bucket.all_reduce()
+                    self._optimizer_step(it)
+                torch.cuda.current_stream().wait_stream(side)
                 return loss
         fb, adam, loss = self._captured
         fb.replay()
@@ -210,6 +215,11 @@ class INNTrainer:
             self.bucket.all_reduce()
             adam.replay()
         return loss
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def _capture(self, var, it):
         """Capture iteration `it` (it also executes on replay, below).  One graph for a single rank; under ray sharding two graphs
@@ -220,14 +230,14 @@ class INNTrainer:
         torch.cuda.synchronize()
         try:
             fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fb):
+            with torch.cuda.graph(fb, stream=self._side_stream()):
                 loss = self._forward_backward(var, it)
                 if self.world == 1:
                     self._optimizer_step(it)
             adam = None
             if self.world > 1:
                 adam = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(adam, pool=fb.pool()):
+                with torch.cuda.graph(adam, pool=fb.pool(), stream=self._side_stream()):
                     self._optimizer_step(it)
         except Exception as e:  # noqa: BLE001 -- any capture failure: keep training eagerly, loudly
             print(f"[niw] HIP-graph capture failed ({type(e).__name__}: {e}); continuing without graph replay", file=sys.stderr, flush=True)

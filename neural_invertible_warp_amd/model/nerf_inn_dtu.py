@@ -26,7 +26,7 @@ class Graph(nerf_inn_llff.Graph):
         batch_size = len(var.idx)
         depth_range = opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else self._host_depth_range(var.depth_range)
         if opt.nerf.rand_rays and mode == "train":
-            var.ray_idx = self.draw_ray_idx(opt, batch_size)
+            var.ray_idx = self.draw_ray_idx(opt, batch_size, draw=iter)
             ray, center, grid_3d = self.get_pose(opt, var, mode=mode, iter=iter)
             ret = self.render_local(opt, ray, center, intr=var.intr, mode=mode, depth_range=depth_range)
             ret.update(grid_local=grid_3d, center_local=center, grid_init=self.pose_net.grid_init, center_init=self.pose_net.center_init)

@@ -44,7 +44,7 @@ class Graph(nerf.Graph):
         render_train branch :531-538 are outside the supported configs)."""
         batch_size = len(var.idx)
         if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
-            var.ray_idx = self.draw_ray_idx(opt, batch_size)
+            var.ray_idx = self.draw_ray_idx(opt, batch_size, draw=iter)
             if mode == "train":
                 pose_init = self.get_pose_init(opt, var, mode=mode, iter=iter)
                 # camera-frame grid / centre kept for the alignment loss (:519); get_pose reuses them
@@ -64,12 +64,13 @@ class Graph(nerf.Graph):
         var.update(ret)
         return var
 
-    def draw_ray_idx(self, opt, batch_size):
+    def draw_ray_idx(self, opt, batch_size, draw=None):
         """The pixel subset of a training step (reference :510): `nerf.rand_rays // batch_size` distinct pixels, the SAME set for
         every view.  Two samplers, equal in distribution (a uniformly random subset in random order):
           * "randperm" (default): `torch.randperm(H*W)[:n]`, the reference's own call (a device sort of H*W keys);
           * "feistel" (`opt.nerf.ray_sampler`, what the engine selects): niw_draw_ray_idx, one sort-free launch keyed by
-            (opt.seed, number of the draw), also replayable from a captured HIP graph (`self.draw_dev`).
+            (opt.seed, `draw` = the training iteration -- a resumed run continues the same sequence; a running count of the
+            calls when no iteration is given), also replayable from a captured HIP graph (`self.draw_dev`).
         Under ray sharding (..parallel) every rank must see the same permutation and keep its share idx[rank::world]: "feistel"
         has that by construction; "randperm" then draws from a generator of its own, seeded alike on all ranks, because the
         ranks' default generators drift apart as soon as their stratified draws differ in size."""
@@ -77,7 +78,8 @@ class Graph(nerf.Graph):
         rank, world = getattr(opt, "ray_shard", None) or (0, 1)
         if opt.nerf.get("ray_sampler", "randperm") == "feistel":
             self._ray_draws = getattr(self, "_ray_draws", 0) + 1
-            return ops.draw_ray_idx(opt.H * opt.W, len(range(rank, n, world)), int(getattr(opt, "seed", 0) or 0), self._ray_draws, opt.device,
+            number = self._ray_draws if draw is None else int(draw) + 1
+            return ops.draw_ray_idx(opt.H * opt.W, len(range(rank, n, world)), int(getattr(opt, "seed", 0) or 0), number, opt.device,
                                     first=rank, stride=world, draw_dev=getattr(self, "draw_dev", None))
         if world == 1:
             return torch.randperm(opt.H * opt.W, device=opt.device)[:n]

@@ -137,9 +137,10 @@ def test_ndc_reparametrisation_keeps_the_gradient_to_the_warp():
     opt.nerf.depth.param = "metric"
     graph = barf_inn_llff.Graph(opt).attach_warp(opt, 3)
     with torch.no_grad():
-        for name, p in graph.warp_mlp.named_parameters():
-            if "_1." in name or "_c." in name:
-                p.normal_(0.0, 0.02)
+        # the reference initialisation zeroes the heads AND the latent columns of the first layers, which makes the latent's
+        # gradient vanish identically at step 0: perturb every warp parameter so that each route carries signal
+        for p in graph.warp_mlp.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
     var = edict(idx=torch.arange(3), image=torch.rand(3, 3, 24, 32, device=DEV),
                 intr=torch.tensor([[0.8 * 32, 0, 16], [0, 0.8 * 32, 12], [0, 0, 1]], device=DEV).repeat(3, 1, 1))
     var = graph.forward(opt, var, mode="train", iter=50000)
