@@ -218,7 +218,11 @@ int launch_gemm(const GemmBatch& batch, int spb, long long mpad, int batches, fl
     // at least 8 slices per workgroup; one workgroup per CU, or -- for a batch of equal pieces -- just under two
     // full rounds of the 256 CUs in total (fewer, longer workgroups: less partial-tile traffic for the reducer)
     const int cap = batches >= 4 ? (2 * 256 - 1) / batches : 256;
-    int nsplit = (steps_total + 7) / 8;
+    // short reductions (the warp's few thousand points, a 1/8 ray shard): fewer slices per workgroup, down to 2, until the
+    // launch has a workgroup for every CU -- the partial tile each workgroup writes (<= 256 KB) is the price of a split
+    int min_slices = 8;
+    while (min_slices > 2 && (long long)((steps_total + min_slices - 1) / min_slices) * batches < 256) min_slices >>= 1;
+    int nsplit = (steps_total + min_slices - 1) / min_slices;
     nsplit = nsplit < 1 ? 1 : (nsplit > cap ? cap : nsplit);
     const int per = (steps_total + nsplit - 1) / nsplit;
     nsplit = (steps_total + per - 1) / per;

@@ -37,13 +37,44 @@ constexpr int kRowGo = 640;                              // B2: head gradients (
 constexpr int kRowsPerBlock = 644;
 
 
-__device__ __forceinline__ float softplus100(float x) {
+// Softplus(beta = 100, threshold = 20) of the reference's coupling MLPs (nvp_ndr.py actfn, torch.nn.Softplus) and its derivative:
+//     z = 100 x;   softplus = z > 20 ? x : log1p(e^z) / 100;   d softplus / dx = z > 20 ? 1 : e^z / (1 + e^z)
+// (torch's softplus backward uses exactly e^z / (e^z + 1)).  libm's expf + log1pf cost ~250 instructions per value and were
+// 45 % of the forward kernel (measured with the activation stubbed out); this form is ~25:
+//   e^z   = 2^t (1 + r ln 2) with t = fl(z log2 e) on the hardware exp2 and r the exact rounding residue of that product plus the
+//           low word of log2 e -- without the correction the argument's rounding alone costs 7 ulp at |z| = 20;
+//   log1p = e (1 - e/2 + e^2/3 - e^3/4) for e < 2^-6 (truncation < 2e-10 relative), else ln(u) + (e - (u - 1)) / u with
+//           u = fl(1 + e) on the hardware log2 (the second term restores what rounding 1 + e lost).
+// Accuracy: a few ulp of the result, i.e. absolute errors < 1e-9 on activations of O(0.01 .. 0.2) -- below the rounding noise
+// of the 26-term dot products that feed them.
+struct Softplus100 {
+    float value, slope;
+};
+__device__ __forceinline__ Softplus100 softplus100_pair(float x) {
     const float z = 100.f * x;
-    return z > 20.f ? x : log1pf(expf(z)) / 100.f;
+    const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
+    const float zc = fminf(z, 20.f);
+    const float t = zc * kL2eHi;
+    const float r = fmaf(zc, kL2eLo, fmaf(zc, kL2eHi, -t));
+    float e = __builtin_amdgcn_exp2f(t);
+    e = fmaf(e, r * kLn2, e);
+    const float u = 1.f + e;
+    const float inv_u = 1.f / u;
+    const float series = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.333333343267440796f), -0.5f), 1.f);
+    const float general = fmaf(__builtin_amdgcn_logf(u), kLn2, (e - (u - 1.f)) * inv_u);
+    const float l1p = e < 0.015625f ? series : general;
+    Softplus100 o;
+    o.value = z > 20.f ? x : l1p / 100.f;
+    o.slope = z > 20.f ? 1.f : e * inv_u;
+    return o;
 }
-__device__ __forceinline__ float dsoftplus100(float x) {
-    const float z = 100.f * x;
-    return z > 20.f ? 1.f : 1.f / (1.f + expf(-z));
+__device__ __forceinline__ float softplus100(float x) { return softplus100_pair(x).value; }
+__device__ __forceinline__ float dsoftplus100(float x) { return softplus100_pair(x).slope; }
+
+// sin / cos of the coupling rotation angle (any magnitude): revolutions in fp64, then the short polynomial of sincos_band --
+// libm's full-range sincosf keeps a Payne-Hanek work array in scratch memory (56 bytes per lane) and costs ~150 instructions
+__device__ __forceinline__ void rotation_sincos(float theta, float& s, float& c) {
+    niw::sincos_band((double)theta * 0.15915494309189533577, 0, s, c);
 }
 
 // A point is served by a GROUP of kGroup adjacent lanes; lane `sub` owns hidden units sub, sub+kGroup, ...
@@ -159,11 +190,6 @@ __device__ __forceinline__ float index_scale(const Windows& w, long long p, int 
 }
 
 __device__ __forceinline__ void stage_weights(const WarpArgs& a, float* lw, float* lh, float* lv, int view) {
-#ifdef NIW_WARP_EXP_NOSTAGE
-    if (threadIdx.x < 64) { lw[threadIdx.x] = a.w_emb[threadIdx.x]; lh[threadIdx.x] = a.w_head[threadIdx.x]; lv[threadIdx.x] = a.view_b[threadIdx.x]; }
-    __syncthreads();
-    return;
-#endif
     for (int i = threadIdx.x; i < 3 * kWembBlock; i += blockDim.x) lw[i] = a.w_emb[i];
     for (int i = threadIdx.x; i < 3 * kHeadBlock; i += blockDim.x) lh[i] = a.w_head[i];
     for (int i = threadIdx.x; i < 3 * 2 * kHid; i += blockDim.x) lv[i] = a.view_b[(long long)view * 3 * 2 * kHid + i];
@@ -212,7 +238,7 @@ __device__ __forceinline__ void block_fwd(const float* lw, const float* lh, cons
     embed<1>(foc, cw, psb, sub, eb);
     part_b(lw, lh, lv, b, sub, eb, o);
     float s, c;
-    sincosf(o[0], &s, &c);
+    rotation_sincos(o[0], s, c);
     const float d0 = oth[0] - o[1], d1 = oth[1] - o[2];
     x[f] = foc[0];
     x[o0] = c * d0 + s * d1;
@@ -228,7 +254,7 @@ __device__ __forceinline__ void block_inv(const float* lw, const float* lh, cons
     embed<1>(single, cw, psb, sub, eb);
     part_b(lw, lh, lv, b, sub, eb, o);
     float s, c;
-    sincosf(o[0], &s, &c);                            // euler2rot_2d: [[cos, -sin], [sin, cos]]
+    rotation_sincos(o[0], s, c);                            // euler2rot_2d: [[cos, -sin], [sin, cos]]
     const float pr[2] = {c * x[o0] - s * x[o1] + o[1], s * x[o0] + c * x[o1] + o[2]};
     float ea[kEa];
     embed<2>(pr, cw, psa, sub, ea);
@@ -260,11 +286,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
 }
 
 // one per-point factor of the parameter gradients -> row `row` of the block's feature-major workspace
-#ifdef NIW_WARP_EXP_NOSTORE
-#define NIW_WS(row, v) do { if (a.n_pts < 0) ws[(long long)(row) * P] = (v); } while (0)
-#else
 #define NIW_WS(row, v) ws[(long long)(row) * P] = (v)
-#endif
 __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lw = lds;
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         embed<1>(foc, win.cw, psb, sub, eb);
         part_b(lw, lh, lv, b, sub, eb, o);
         float s, c;
-        sincosf(o[0], &s, &c);
+        rotation_sincos(o[0], s, c);
         const float d0 = oth[0] - o[1], d1 = oth[1] - o[2];
         const float n0 = c * d0 + s * d1, n1 = -s * d0 + c * d1;
         // ---- rotation / translation
@@ -320,9 +342,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         for (int u = sub; u < kHid; u += kGroup) {
             const float pre = vb[u] + dot_row<kEb>(Wb + u * kEb, eb);
             const float gh = hdb[u] * go[0] + hdb[kHid + u] * go[1] + hdb[2 * kHid + u] * go[2];
-            const float gp = gh * dsoftplus100(pre);
+            const Softplus100 act = softplus100_pair(pre);
+            const float gp = gh * act.slope;
             NIW_WS(kRowGb + u, gp);
-            NIW_WS(kRowHb + u, softplus100(pre));
+            NIW_WS(kRowHb + u, act.value);
 #pragma unroll
             for (int k = 0; k < kEb; ++k) geb[k] += Wb[u * kEb + k] * gp;
         }
@@ -338,9 +361,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         for (int k = 0; k < kEa; ++k) gea[k] = 0.f;
         for (int u = sub; u < kHid; u += kGroup) {
             const float pre = va[u] + dot_row<kEa>(Wa + u * kEa, ea);
-            const float gp = g_delta * hda[u] * dsoftplus100(pre);
+            const Softplus100 act = softplus100_pair(pre);
+            const float gp = g_delta * hda[u] * act.slope;
             NIW_WS(kRowGa + u, gp);
-            NIW_WS(kRowHa + u, softplus100(pre));
+            NIW_WS(kRowHa + u, act.value);
 #pragma unroll
             for (int k = 0; k < kEa; ++k) gea[k] += Wa[u * kEa + k] * gp;
         }
