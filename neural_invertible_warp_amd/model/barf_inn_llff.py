@@ -107,21 +107,9 @@ class Model:
 
     # ---- reference model/base.py:24-33 / nerf_inn_llff.py:22-32
     def load_dataset(self, opt, eval_split="val"):
-        import importlib
-        import os
-        name = opt.data.dataset
-        root = opt.data.get("root") or "data/{}".format(name)
-        if name != "synthetic" and not os.path.isdir("{}/{}".format(root, opt.data.scene)):
-            print("[niw] dataset {}/{} not found: using the procedural scene".format(root, opt.data.scene))
-            name = "synthetic"
-        data = importlib.import_module("neural_invertible_warp_amd.data.{}".format(name))
-        if opt.data.get("val_on_test"):
-            eval_split = "test"
-        self.train_data = data.Dataset(opt, split="train", subset=opt.data.get("train_sub"))
-        self.test_data = data.Dataset(opt, split=eval_split, subset=opt.data.get("val_sub"))
-        for d in (self.train_data, self.test_data):
-            d.prefetch_all_data(opt)
-            d.all = edict({k: v.to(opt.device) for k, v in d.all.items()})
+        """reference model/base.py:24-33 + nerf_inn_llff.py:22-32: both splits pre-loaded, tensors resident on the device"""
+        from .. import data
+        self.train_data, self.test_data = data.open_splits(opt, eval_split=eval_split)
 
     # ---- barf_inn_llff.py:41-75 (+ setup_optimizer :84-104: the trainer owns the flat Adam state and the schedules)
     def build_networks(self, opt):

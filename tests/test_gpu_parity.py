@@ -299,6 +299,45 @@ def test_inn_train_step_dtu_golden():
     check_grad_summary(pose_net.pose_latent.weight.grad, gd, "grad.pose_latent.weight", rtol=0.15)
 
 
+def test_inn_train_step_dtu_c2f_golden():
+    """cfg 5 with the shipped --barf_c2f=[0.1,0.5] (tests/golden/make_golden_dtu.py): forward values at the LLFF tolerances and ALL
+    gradients to 1e-2 of scale (the CPU oracle itself sits 4.5e-3 from the reference on mlp_feat.0.weight: metric depths, points
+    3-8 units from the origin) -- the unmasked fixture above can only bound them to 15 %."""
+    from neural_invertible_warp_amd.model import barf_inn_dtu
+    from neural_invertible_warp_amd.model.pose_models.inn import INNPoseParams
+    from neural_invertible_warp_amd.util import edict
+    gd = golden("inn_step_cfg5_c2f")
+    H, W, S, R = (int(gd[k]) for k in ("H", "W", "S", "R"))
+    opt = mk_opt("cfg5_barf_inn_dtu", H=H, W=W, **{"nerf.sample_intvs": S, "nerf.rand_rays": R * 3, "barf_c2f": [0.1, 0.5]})
+    pose_net = INNPoseParams(opt, num_poses=3, initial_poses_w2c=g(t(gd["pose_init"])), device=DEV)
+    load_nerf(pose_net.pose_embedding, O.make_warp_params(int(gd["seed_warp"]), float(gd["warp_perturb"])))
+    with torch.no_grad():
+        pose_net.pose_latent.weight.copy_(O.make_latent(int(gd["seed_latent"]), 3))
+    graph = barf_inn_dtu.Graph(opt, pose_net)
+    load_nerf(graph.nerf, O.make_nerf_params(int(gd["seed_coarse"])))
+    graph.nerf.set_progress(float(gd["progress"]))
+    var = edict(idx=torch.arange(3), image=g(t(gd["image"])), intr=g(t(gd["intr"])), pose=g(t(gd["pose_init"])),
+                depth_range=g(t(gd["depth_range"])))
+    with _capture_rng(g(t(gd["u"])), g(torch.from_numpy(gd["ray_idx"]))):
+        var = graph.forward(opt, var, mode="train", iter=int(gd["it"]))
+    close(var.center_init, gd["center_init"], atol=2e-6); close(var.grid_init, gd["grid_init"], atol=2e-6)
+    close(var.center_local, gd["center"], atol=2e-5); close(var.grid_local, gd["grid_3D"], atol=2e-5)
+    close(var.rgb, gd["rgb"], atol=3e-5, rtol=2e-4); close(var.opacity, gd["opacity"], atol=3e-5, rtol=2e-4)
+    relclose(var.depth, gd["depth"], 2e-4)
+    loss = graph.compute_loss(opt, var, mode="train")
+    close(loss.render, gd["loss_render"], atol=1e-6)
+    loss.render.backward()
+    for k, prm in graph.nerf.named_parameters():
+        if f"grad.{k}.norm" in gd:
+            check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=1e-2)
+    # warp gradients: world-scale inputs amplify fp32 roundoff to percent level in ANY fp32 evaluation (see test_oracle_golden)
+    for k, prm in pose_net.pose_embedding.named_parameters():
+        check_grad_summary(prm.grad, gd, f"grad.pose_embedding.{k}", rtol=0.15 if prm.numel() > 16 else 0.6)
+        if prm.numel() > 16:
+            assert abs(float(prm.grad.norm()) - float(gd[f"grad.pose_embedding.{k}.norm"])) <= 2e-2 * float(gd[f"grad.pose_embedding.{k}.norm"]), k
+    check_grad_summary(pose_net.pose_latent.weight.grad, gd, "grad.pose_latent.weight", rtol=0.05)
+
+
 @pytest.mark.parametrize("tag", ["cfg3", "cfg2"])
 def test_inn_train_step_golden(tag):
     from neural_invertible_warp_amd.model import barf_inn_llff

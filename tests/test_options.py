@@ -34,3 +34,34 @@ def test_yaml_directory_with_parent_inheritance(tmp_path):
     opt = options.set(options.parse_arguments(["--model=m", "--yaml=leaf", f"--options_dir={d}", "--nerf.rand_rays=32"]))
     assert opt.optim.lr == 5e-4 and opt.optim.algo == "Adam" and opt.data.scene == "b" and opt.data.image_size == [10, 12]
     assert opt.nerf.rand_rays == 32 and opt.model == "m" and (opt.H, opt.W) == (10, 12)
+
+
+REFERENCE_OPTIONS = "/root/reference/options"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE_OPTIONS), reason="reference checkout not present (build container only)")
+@pytest.mark.parametrize("name", ["nerf_llff_repr", "nerf_inn_llff", "barf_inn_llff", "barf_inn_dtu"])
+def test_builtin_trees_restate_the_reference_yaml_files(name):
+    """`--yaml=<name>` without --options_dir must train the problem the reference command line trains: every key of the built-in
+    tree that the reference's resolved yaml also holds carries the same value, and every reference key of the sections the render
+    path and the engine read is present."""
+    from neural_invertible_warp_amd import configs
+    ref = options.load_options(f"{REFERENCE_OPTIONS}/{name}.yaml")
+    mine = configs.BY_YAML[name]()
+    ours_only = {"model", "yaml", "device", "H", "W"}            # set by options.process_options / the command line in the reference
+
+    def walk(a, b, path):
+        for k, v in a.items():
+            if path == "" and k in ours_only:
+                continue
+            assert k in b, f"{name}: built-in key {path}{k} is not a reference key"
+            if isinstance(v, dict) and isinstance(b[k], dict):
+                walk(v, b[k], f"{path}{k}.")
+            else:
+                assert v == b[k] or (v in (None, {}) and b[k] in (None, {})), f"{name}: {path}{k} = {v!r}, reference {b[k]!r}"
+
+    walk(mine, ref, "")
+    for section in ("arch", "nerf", "camera", "loss_weight", "optim"):
+        missing = [k for k in ref.get(section, {}) if k not in mine[section]]
+        assert not missing, f"{name}: reference keys {section}.{missing} missing from the built-in tree"
+    assert mine.data.image_size == ref.data.image_size and mine.max_iter == ref.max_iter
