@@ -219,7 +219,7 @@ def test_train_entry_point_dtu_with_learnable_poses(tmp_path, capsys):
     """--model=barf_inn_dtu --yaml=barf_inn_dtu (BASELINE cfg 5 family): noisy initial poses, INNPoseParams, two optimizers,
     validation through the pairwise pose alignment + back-aligned test poses, resume."""
     from neural_invertible_warp_amd import train
-    args = ["--model=barf_inn_dtu", "--yaml=barf_inn_dtu", "--data.dataset=dtu", "--data.synthetic_fallback", "--data.image_size=[24,32]", "--nerf.rand_rays=192",
+    args = ["--model=barf_inn_dtu", "--yaml=barf_inn_dtu", "--barf_c2f=[0.1,0.5]", "--loss_weight.global_alignment=3", "--data.dataset=dtu", "--data.synthetic_fallback", "--data.image_size=[24,32]", "--nerf.rand_rays=192",
             "--nerf.sample_intvs=32", "--data.train_sub=3", "--freq.val=3", "--freq.ckpt=3", "--freq.scalar=1", "--optim.test_iter=3",
             f"--output_root={tmp_path}", "--name=d"]
     m = train.main(args + ["--max_iter=3"])
@@ -293,11 +293,11 @@ def test_train_entry_point_on_dataset_files(tmp_path, capsys):
     _scene_writer("make_golden_data.py", "N, FH, FW, H, W = 7, 40, 56, 30, 40", "def write_scene")["write_scene"](llff_root)
     _scene_writer("make_golden_dtu_data.py", "N_VIEWS, H, W = 49, 12, 16", "def rotation")["write_scene"](dtu_root)
     common = ["--nerf.sample_intvs=16", "--freq.val=2", "--freq.ckpt=2", "--freq.scalar=1", "--optim.test_iter=2", f"--output_root={tmp_path}", "--max_iter=2"]
-    m = train.main(["--model=barf_inn_llff", "--yaml=barf_inn_llff", f"--data.root={llff_root}", "--data.image_size=[30,40]", "--data.val_ratio=0.3",
+    m = train.main(["--model=barf_inn_llff", "--yaml=barf_inn_llff", "--barf_c2f=[0.1,0.5]", "--loss_weight.global_alignment=4", f"--data.root={llff_root}", "--data.image_size=[30,40]", "--data.val_ratio=0.3",
                     "--nerf.rand_rays=60", "--name=l"] + common)
     assert len(m.train_data) == 5 and len(m.test_data) == 2 and m.train_data.all.image.shape == (5, 3, 30, 40)
     assert "[val it 2]" in capsys.readouterr().out
-    m = train.main(["--model=barf_inn_dtu", "--yaml=barf_inn_dtu", f"--data.root={dtu_root}", "--data.image_size=[12,16]", "--data.dtu.split_type=pixelnerf",
+    m = train.main(["--model=barf_inn_dtu", "--yaml=barf_inn_dtu", "--barf_c2f=[0.1,0.5]", "--loss_weight.global_alignment=3", f"--data.root={dtu_root}", "--data.scene=scan65", "--data.image_size=[12,16]", "--data.dtu.split_type=pixelnerf",
                     "--data.dtu.train_sub=3", "--data.dtu.val_sub=2", "--nerf.rand_rays=48", "--name=d"] + common)
     assert len(m.train_data) == 3 and m.train_data.all.depth_range.shape == (3, 2) and list(m.train_data.render_img_id) == [25, 22, 28]
     assert "[val it 2]" in capsys.readouterr().out
