@@ -140,6 +140,8 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
     const long long total = (long long)B * R * 3;
     const double slope = (double)grad_scale * 2.0 / n_norm;        // d mean / d rgb = 2 diff / n (one fp64 divide per launch, not per element)
     double acc = 0.0;
+    // four elements per thread in flight: the pixel index and the image value are two dependent loads (L2 / HBM latency each)
+#pragma unroll 4
     for (long long i = threadIdx.x; i < total; i += 1024) {
         const int c = (int)(i % 3);
         const long long br = i / 3, b = br / R, r = br % R;
