@@ -22,10 +22,10 @@ per-GPU ray count fixed (rank r renders pixels idx[r::N] of a global draw N time
 batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
 on one GPU: a proxy of what one rank of a K-GPU strong-scaled job executes (no collective).  Prints ONE JSON line on rank 0.
 
-The timed iterations replay ONE captured HIP graph each (engine.INNTrainer(hip_graph=True): forward, backward, gradient gather and
-the Adam updates; the step's scalars -- c2f bands, warp windows, Adam bias corrections, pixel-draw number -- travel in a 256-byte
-device buffer refreshed before every replay); under N > 1 the RCCL all-reduce is issued between two graphs.  --no-hip-graph launches
-the ~140 kernels one by one.
+At N = 1 the timed iterations replay ONE captured HIP graph each (engine.INNTrainer(hip_graph=True): forward, backward, gradient
+gather and the Adam updates; the step's scalars -- c2f bands, warp windows, Adam bias corrections, pixel-draw number -- travel in a
+256-byte device buffer refreshed before every replay).  Under N > 1 the default is launch-by-launch (--hip-graph on: two graphs with
+the RCCL all-reduce issued eagerly between them); the step is GPU-bound at every BASELINE size, replay and eager launch time alike.
 
 Besides the contract fields the line carries `roofline` (dominant single MLP kernel: algorithmic FLOPs / mean launch time from
 device events on the launch stream vs the fp32-MFMA peak; `traffic` from the PMC passes in profiles/), `kernels` (per-kernel
@@ -186,7 +186,11 @@ def main():
     ap.add_argument("--no-composite-scan", action="store_true")
     ap.add_argument("--no-psnr-parity", action="store_true")
     ap.add_argument("--lean", action="store_true", help="train step only: all four --no-* switches")
-    ap.add_argument("--no-hip-graph", action="store_true", help="launch every kernel of the iteration eagerly instead of replaying the captured HIP graph")
+    ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the captured HIP graph of the iteration (on) or launch its kernels one by one (off); auto = on for one GPU, off under "
+                         "torch.distributed (measured: no throughput difference at any BASELINE size -- the step is GPU-bound -- so the multi-rank "
+                         "default avoids capturing next to a live RCCL communicator)")
+    ap.add_argument("--no-hip-graph", action="store_true", help="same as --hip-graph off")
     ap.add_argument("--kernel-steps", type=int, default=3, help="extra eager steps after the timed region for the per-kernel device-event table (0: skip)")
     args = ap.parse_args()
     if args.lean:
@@ -207,7 +211,8 @@ def main():
     dev = f"cuda:{local}"
     scaling = "strong" if args.shard_of else args.scaling
 
-    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=not args.no_hip_graph)
+    use_graph = False if args.no_hip_graph else (world == 1 if args.hip_graph == "auto" else args.hip_graph == "on")
+    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph)
     evals_local = sum(B * R * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
 
     # the batch tensors stay resident at fixed addresses (the captured graph reads them in place)

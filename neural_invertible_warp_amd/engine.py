@@ -229,15 +229,18 @@ class INNTrainer:
         self._static_inputs = {k: v for k, v in var.items() if isinstance(v, torch.Tensor)}      # must stay alive and in place
         torch.cuda.synchronize()
         try:
+            # ranks with a live RCCL communicator: its watchdog thread polls events while we capture, which "global" error mode
+            # would treat as a capture violation
+            mode = dict(capture_error_mode="thread_local") if self.world > 1 else {}
             fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fb, stream=self._side_stream()):
+            with torch.cuda.graph(fb, stream=self._side_stream(), **mode):
                 loss = self._forward_backward(var, it)
                 if self.world == 1:
                     self._optimizer_step(it)
             adam = None
             if self.world > 1:
                 adam = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(adam, pool=fb.pool(), stream=self._side_stream()):
+                with torch.cuda.graph(adam, pool=fb.pool(), stream=self._side_stream(), **mode):
                     self._optimizer_step(it)
         except Exception as e:  # noqa: BLE001 -- any capture failure: keep training eagerly, loudly
             print(f"[niw] HIP-graph capture failed ({type(e).__name__}: {e}); continuing without graph replay", file=sys.stderr, flush=True)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 PMC passes of tools/mlp_bench.py (csv output) into profiles/r2_traffic.json and profiles/r2_mfma_util.json.
+
+    cd /tmp && export TMPDIR=/tmp
+    for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d OUT/<fetch|write|mfma> -o pm -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192
+    done
+    python3 tools/mlp_traffic.py OUT profiles/r2
+
+Units and gfx950 corrections (MI355X_MICROARCH.md, HBM / rocprofv3 sections): FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled (128-byte
+requests tallied at 64 bytes); effective clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES
+(64 per v_mfma_f32_32x32x2_f32) / (4 SIMDs x 256 CUs x cycles)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+SAMPLES = 4086 * 192
+NAMES = {"mlp_fwd_kernel<true>": "mlp_fwd_train", "mlp_fwd_kernel<false>": "mlp_fwd", "mlp_bwd_dx_kernel": "mlp_bwd_dx",
+         "dw_gemm_kernel<4, 2, 2, 4>": "mlp_bwd_dw_wide_batch", "dw_gemm_kernel<8, 1, 1, 2>": "mlp_bwd_dw_skinny_batch",
+         "dw_gemm_kernel<4, 1, 1, 9>": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce"}
+ALGO = {  # algorithmic bytes per sample: reads / writes of the workspaces, fp32
+    "mlp_fwd_train": dict(read=16.0, write=9384.0), "mlp_fwd": dict(read=16.0, write=16.0),
+    "mlp_bwd_dx": dict(read=672.0, write=9344.0), "mlp_bwd_dw_wide_batch": dict(read=7 * 2 * 256 * 4.0, write=0.0),
+    "mlp_bwd_dw_skinny_batch": dict(read=(320 + 320 + 257 + 131) * 4.0, write=0.0), "mlp_bwd_dw_colour": dict(read=(128 + 288) * 4.0, write=0.0)}
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(mlp_fwd_kernel<\w+>|mlp_bwd_dx_kernel|dw_gemm_kernel<[\d, ]+>|dw_reduce_kernel)", r["Kernel_Name"])
+        if m:
+            agg[NAMES[m.group(1)]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[NAMES[m.group(1)]]["dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
+def main(out, prefix):
+    f, w, m = (per_kernel(f"{out}/{d}/pm_counter_collection.csv") for d in ("fetch", "write", "mfma"))
+    traffic = {}
+    for k in f:
+        if k not in ALGO:
+            continue
+        fr, wr = f[k]["FETCH_SIZE"] * 1024 / SAMPLES, w[k]["WRITE_SIZE"] * 1024 / SAMPLES
+        traffic[k] = dict(fetch_raw=round(fr, 1), fetch_corrected=round(2 * fr, 1), write=round(wr, 1), algorithmic_read=ALGO[k]["read"],
+                          algorithmic_write=ALGO[k]["write"], traffic_over_algorithmic=round((2 * fr + wr) / (ALGO[k]["read"] + ALGO[k]["write"]), 3))
+    doc = dict(source="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192; "
+                      "MI355X; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream), WRITE_SIZE as reported; KiB = 1024 B",
+               samples_per_launch=SAMPLES, bytes_per_sample=traffic)
+    json.dump(doc, open(prefix + "_traffic.json", "w"), indent=1)
+    rows = []
+    for k, d in m.items():
+        sec, cyc = d["dur_ns"] * 1e-9, d["GRBM_GUI_ACTIVE"] / 8
+        rows.append(dict(kernel=k, avg_ms=round(sec * 1e3, 3), clock_ghz=round(cyc / sec / 1e9, 3),
+                         mfma_util=round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc), 4),
+                         frac_of_2p4ghz_peak=round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * sec * 2.4e9), 4)))
+    json.dump(dict(source="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192 "
+                          "(profiled passes run a few per cent slower than un-profiled ones)", kernels=rows), open(prefix + "_mfma_util.json", "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+    print(json.dumps(rows, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
