@@ -224,14 +224,20 @@ class INNTrainer:
     def _capture(self, var, it):
         """Capture iteration `it` (it also executes on replay, below).  One graph for a single rank; under ray sharding two graphs
         (forward + backward + gather | Adam) with the RCCL all-reduce of the flat gradient bucket issued eagerly in between, so that
-        no collective is captured.  -> False when capture is not possible (the engine then stays eager)."""
+        no collective is captured -- which also rules capture out while the alignment term all-reduces its Kabsch moments in the
+        middle of the forward: that case is recognised up front and stays eager (-> False).  A capture that fails while recording
+        is an error (NiwError)."""
         import sys
+        import torch.distributed as dist
+        live_group = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if live_group and self.opt.loss_weight.get("global_alignment") is not None:
+            return self._give_up_capture("the sharded alignment loss all-reduces its moments inside the forward")
         self._static_inputs = {k: v for k, v in var.items() if isinstance(v, torch.Tensor)}      # must stay alive and in place
         torch.cuda.synchronize()
         try:
             # ranks with a live RCCL communicator: its watchdog thread polls events while we capture, which "global" error mode
             # would treat as a capture violation
-            mode = dict(capture_error_mode="thread_local") if self.world > 1 else {}
+            mode = dict(capture_error_mode="thread_local") if live_group else {}
             fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(fb, stream=self._side_stream(), **mode):
                 loss = self._forward_backward(var, it)
@@ -242,19 +248,26 @@ class INNTrainer:
                 adam = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(adam, pool=fb.pool(), stream=self._side_stream(), **mode):
                     self._optimizer_step(it)
-        except Exception as e:  # noqa: BLE001 -- any capture failure: keep training eagerly, loudly
-            print(f"[niw] HIP-graph capture failed ({type(e).__name__}: {e}); continuing without graph replay", file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            self.hip_graph_failed = True
-            self._captured = None
-            self.hip_graph = False
-            for n in self.nets:
-                n.band_dev = None
-            self.warp_mlp.window_dev = None
-            self.graph.draw_dev = None
-            return False
+        except Exception as e:  # noqa: BLE001
+            # a capture that was invalidated half-way leaves HIP's capture error sticky on this process (measured: neither a new
+            # stream nor CUDAGraph.reset() nor reseeding the generator brings launches back), so there is no eager fall-back to
+            # offer: fail loudly and name the switch
+            raise NiwError(f"HIP-graph capture of the train iteration failed ({type(e).__name__}: {e}); "
+                           "run with hip_graph=False (bench.py --hip-graph off)") from e
         self._captured = (fb, adam, loss)
         return True
+
+    def _give_up_capture(self, why):
+        import sys
+        print(f"[niw] HIP-graph capture not used ({why}); the iteration is launched kernel by kernel", file=sys.stderr, flush=True)
+        self.hip_graph_failed = True
+        self._captured = None
+        self.hip_graph = False
+        for n in self.nets:
+            n.band_dev = None
+        self.warp_mlp.window_dev = None
+        self.graph.draw_dev = None
+        return False
 
     def sync_state(self):
         """bring device-side mirrors of host state up to date (the c2f `progress` Parameter is only written on demand under
