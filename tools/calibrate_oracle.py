@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""BASELINE.md section 4 calibration (build container only: it imports the real reference): the CPU oracle that bench.py times as
+`cpu_baseline` must be a fair proxy of the reference's own PyTorch path, i.e. time within +-10 % of it on the same step.
+
+    python tools/calibrate_oracle.py            # writes profiles/r2_oracle_calibration.json
+
+Step timed on both sides, same shapes, same seeded weights / images / pixel draws / stratified draws, torch CPU with all cores:
+cfg-3-like `barf_inn_llff` train iteration (Graph.forward(mode="train") + compute_loss + backward) at 18 views x R rays x 128
+samples on 300x400 images, alignment weight 4.  R = 16 keeps a step around a second in this 8-vCPU sandbox."""
+import json
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import numpy as np
+import torch
+
+import make_golden as G
+from oracle import niw_oracle as O
+
+
+def main():
+    G.install_stubs()
+    sys.path.insert(0, G.REF)
+    import roma
+    roma.rigid_points_registration = lambda x, y, *a, **k: O.rigid_registration(x, y)
+    import model.barf_inn_llff as ref_barf
+    from easydict import EasyDict as edict
+    B, H, W, R, S, it, prog, steps = 18, 300, 400, 16, 128, 30000, 0.3, 4
+    torch.set_num_threads(os.cpu_count() or 1)
+    opt = G.load_opt("barf_inn_llff", "barf_inn_llff", **{"data.image_size": [H, W], "barf_c2f": [0.1, 0.5]})
+    opt.nerf.sample_intvs, opt.nerf.rand_rays = S, R * B
+    opt.loss_weight.global_alignment = 4
+    g = ref_barf.Graph(opt)
+    # the modules the reference's Model.build_networks attaches (barf_inn_llff.py:41-75)
+    import model.nvp.nvp_ndr as nvp
+    g.warp_latent = torch.nn.Embedding(B, 128)
+    g.warp_mlp = nvp.DeformNetwork(d_feature=128, d_in=3, d_out_1=1, d_out_2=3, n_blocks=3, d_hidden=128, n_layers=1, skip_in=[], multires=6,
+                                   weight_norm=True, actfn="softplus")
+    g.global_rigid = torch.nn.Embedding(B, 12)
+    g.pose_eye = torch.eye(3, 4)
+    pc, wp, lat = O.make_nerf_params(1), O.make_warp_params(3, 0.02), O.make_latent(4, B)
+    G.set_params(g.nerf, pc)
+    G.set_params(g.warp_mlp, wp)
+    with torch.no_grad():
+        g.warp_latent.weight.copy_(lat)
+    g.nerf.progress.data.fill_(prog)
+    rng = np.random.default_rng(0)
+    image = torch.from_numpy(rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32))
+    intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(B, 1, 1)
+    draws = [(torch.from_numpy(rng.permutation(H * W)[:R].astype(np.int64)), torch.from_numpy(rng.uniform(0, 1, (B, R, S, 1)).astype(np.float32)))
+             for _ in range(steps)]
+
+    def ref_step(ray_idx, u):
+        rand, perm = torch.rand, torch.randperm
+        torch.rand, torch.randperm = (lambda *a, **k: u.clone()), (lambda *a, **k: ray_idx.clone())
+        try:
+            g.zero_grad()
+            var = edict(idx=torch.arange(B), image=image, intr=intr)
+            var = g.forward(opt, var, mode="train", iter=it)
+            loss = g.compute_loss(opt, var, mode="train")
+            (loss.render + 10 ** 4 * loss.global_alignment).backward()
+        finally:
+            torch.rand, torch.randperm = rand, perm
+        return float(loss.render)
+
+    req = lambda d: {k: v.clone().requires_grad_(True) for k, v in d.items()}
+    pc2, wp2, lat2 = req(pc), req(wp), lat.clone().requires_grad_(True)
+    w3, wv = O.c2f_weights(prog, (0.1, 0.5), 10), O.c2f_weights(prog, (0.1, 0.5), 4)
+
+    def oracle_step(ray_idx, u):
+        for p in list(pc2.values()) + list(wp2.values()) + [lat2]:
+            p.grad = None
+        out = O.inn_train_step(pc2, wp2, lat2, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", it / 100000, ga_weight=4, w3d=w3, wview=wv)
+        out["loss"].backward()
+        return float(out["loss_render"])
+
+    res = {}
+    for name, fn in (("reference", ref_step), ("oracle", oracle_step), ("reference_again", ref_step), ("oracle_again", oracle_step)):
+        ts, vals = [], []
+        for ray_idx, u in draws:
+            t0 = time.perf_counter()
+            vals.append(fn(ray_idx, u))
+            ts.append(time.perf_counter() - t0)
+        res[name] = dict(best_s=min(ts[1:]), median_s=sorted(ts[1:])[len(ts[1:]) // 2], loss_render=vals[-1])
+    evals = B * R * S
+    t_ref = min(res["reference"]["best_s"], res["reference_again"]["best_s"])
+    t_or = min(res["oracle"]["best_s"], res["oracle_again"]["best_s"])
+    doc = dict(what="cfg-3-like barf_inn_llff train step (fwd + losses + bwd), torch CPU, identical inputs; best of 3 after 1 warm-up, two interleaved rounds",
+               shape=f"{B} views x {R} rays x {S} samples on {H}x{W} images = {evals} MLP evaluations per step", threads=torch.get_num_threads(),
+               reference_s=round(t_ref, 4), oracle_s=round(t_or, 4), reference_samples_per_s=round(evals / t_ref), oracle_samples_per_s=round(evals / t_or),
+               oracle_over_reference_time=round(t_or / t_ref, 4), within_10_percent=bool(abs(t_or / t_ref - 1) <= 0.10),
+               loss_render_reference=res["reference"]["loss_render"], loss_render_oracle=res["oracle"]["loss_render"], rounds=res)
+    with open(os.path.join(ROOT, "profiles", "r2_oracle_calibration.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps({k: v for k, v in doc.items() if k != "rounds"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

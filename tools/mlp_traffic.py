@@ -22,7 +22,9 @@ NAMES = {"mlp_fwd_kernel<true>": "mlp_fwd_train", "mlp_fwd_kernel<false>": "mlp_
          "dw_gemm_kernel<4, 1, 1, 9>": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce"}
 ALGO = {  # algorithmic bytes per sample: reads / writes of the workspaces, fp32
     "mlp_fwd_train": dict(read=16.0, write=9384.0), "mlp_fwd": dict(read=16.0, write=16.0),
-    "mlp_bwd_dx": dict(read=672.0, write=9344.0), "mlp_bwd_dw_wide_batch": dict(read=7 * 2 * 256 * 4.0, write=0.0),
+    # dX reads: 288 B sign masks + 384 B parked skip / view gradients (written and read back) + 384 B saved encodings (for d point,
+    # d direction) + d_rgb 12 + d_sigma 4 + rgb 12 + raw density 4 + depth 4
+    "mlp_bwd_dx": dict(read=1092.0, write=9344.0 + 384.0), "mlp_bwd_dw_wide_batch": dict(read=7 * 2 * 256 * 4.0, write=0.0),
     "mlp_bwd_dw_skinny_batch": dict(read=(320 + 320 + 257 + 131) * 4.0, write=0.0), "mlp_bwd_dw_colour": dict(read=(128 + 288) * 4.0, write=0.0)}
 
 
