@@ -68,8 +68,8 @@ class Dataset(torch.utils.data.Dataset):
         ratio = opt.data.get("center_crop")
         self.crop_H = int(self.raw_H * ratio) if ratio is not None else self.raw_H
         self.crop_W = int(self.raw_W * ratio) if ratio is not None else self.raw_W
-        if not opt.H or not opt.W:
-            opt.H, opt.W = self.crop_H, self.crop_W
+        if not (opt.H and opt.W):                          # no explicit size: render at the (cropped) file resolution
+            opt.H, opt.W = (self.crop_H, self.crop_W)
         self.root = opt.data.get("root") or "data/llff"
         self.path = os.path.join(self.root, opt.data.scene)
         self.path_image = os.path.join(self.path, "images")
@@ -95,8 +95,7 @@ class Dataset(torch.utils.data.Dataset):
         self.list = [(names[i], rig[i], bounds[i]) for i in ids]
         self._w2c = w2c[ids]
 
-    def __len__(self):
-        return len(self.list)
+    def __len__(self): return len(self.list)
 
     # ---- cameras
     def get_all_camera_poses(self, opt):
@@ -119,16 +118,16 @@ class Dataset(torch.utils.data.Dataset):
 
     # ---- images
     def get_image(self, opt, idx):
-        import PIL.Image
-        with PIL.Image.open(os.path.join(self.path_image, self.list[idx][0])) as im:
+        from PIL import Image
+        with Image.open(os.path.join(self.path_image, self.list[idx][0])) as im:
             return im.copy() if im.mode in ("RGB", "L") else im.convert("RGB")
 
     def preprocess_image(self, opt, image):
         if (self.crop_H, self.crop_W) != (self.raw_H, self.raw_W):            # data.center_crop given
             x0, y0 = (image.width - self.crop_W) // 2, (image.height - self.crop_H) // 2
             image = image.crop((x0, y0, x0 + self.crop_W, y0 + self.crop_H))
-        if opt.data.image_size[0] is not None:
-            image = image.resize((opt.W, opt.H))
+        if (image.width, image.height) != (opt.W, opt.H) and opt.data.image_size[0] is not None:
+            image = image.resize(size=(opt.W, opt.H))
         pixels = np.array(image, dtype=np.uint8)
         pixels = pixels.reshape(pixels.shape[0], pixels.shape[1], -1)
         return torch.from_numpy(pixels).permute(2, 0, 1).float() / 255

@@ -1,26 +1,39 @@
-"""Val / eval tooling around the Graph: pose evaluation up to a similarity transform,
-the test-pose alignment the val / eval branch of `Graph.get_pose` consumes, full-image rendering through
-`render_by_slices` and the image / depth metrics.  Mirrors the evaluation methods of the reference's
-`Model` classes, taking the graph and the ground-truth poses explicitly instead of a dataset object:
+"""Val / eval tooling around the Graph.
 
-  LLFF (model/barf_inn_llff.py):  get_all_training_poses :156-169, prealign_cameras :171-187,
-        evaluate_camera_alignment :189-197, evaluate_full :199-216 (+ nerf_inn_llff.py:193-228),
-        evaluate_test_time_photometric_optim :218-234
-  DTU  (model/barf_inn_dtu.py):   evaluate_any_poses :116-137, evaluate_camera_alignment :139-170,
-        prealign_w2c_large_camera_systems :173-201, prealign_w2c_small_camera_systems :203-299,
-        validate :370-382, evaluate_full :437-465 (+ nerf_inn_dtu.py:205-262)
+What the reference spreads over its `Model` classes (LLFF: model/barf_inn_llff.py:156-234 + nerf_inn_llff.py:193-228; DTU:
+model/barf_inn_dtu.py:116-299, 370-382, 437-483 + nerf_inn_dtu.py:205-262) is organised here around three questions, with the
+reference's method names kept as the entry points its `Model`s (and ours) call:
 
-The renders run on the HIP path (graph.forward(mode="eval")); the pose algebra is [N,3,4]-sized host work.
+  1. where are the learnt training cameras?          `learnt_poses`            (get_all_training_poses)
+  2. how do they relate to the ground truth?         `align` -> aligned poses + a similarity record the graph stores, from which
+                                                     `Graph.get_pose` brings held-out ground-truth poses into the learnt frame
+                                                     (prealign_cameras / prealign_w2c_*_camera_systems, validate)
+  3. how well does a held-out view render?           `_score_view`: optional test-time pose refinement, full-image render on the HIP
+                                                     path (graph.forward(mode="eval"): a sweep over pixel ranges), image / depth metrics
+                                                     (evaluate_full, evaluate_test_time_photometric_optim)
+
+The pose algebra is [N,3,4]-sized host work (posealign.py, align_trajectories.py); every render runs through libniw_hip.so.
 """
-import numpy as np
+import math
+
 import torch
+from numpy.linalg import LinAlgError
 
 from . import camera, metrics, posealign
 from .align_trajectories import align_ate_c2b_use_a2b
 from .util import edict
 
 
-class _TestTimeRefinement:
+_detached = torch.no_grad()            # pose bookkeeping: never part of a graph
+
+
+class _Evaluator:
+    def __init__(self, opt, graph, pose_GT):
+        """pose_GT: ground-truth world-to-camera poses of the training views [N,3,4] (train_data.get_all_camera_poses)"""
+        self.opt, self.graph = opt, graph
+        self.pose_GT = torch.as_tensor(pose_GT).to(opt.device)
+
+    # ---- 3. held-out views
     def evaluate_test_time_photometric_optim(self, opt, var):
         """Test-time pose refinement (reference barf_inn_llff.py:218-234, barf_inn_dtu.py:467-483): the aligned ground-truth pose
         of a held-out view is still slightly off in the learnt frame; a 6-vector `var.se3_refine_test`, composed in front of it as
@@ -38,15 +51,25 @@ class _TestTimeRefinement:
             adam.step()
         return var
 
+    def _score_view(self, opt, view):
+        """-> (var after the eval render, rgb map [1,3,H,W], edict(psnr, ssim))"""
+        var = edict(view)
+        if opt.optim.test_photo:
+            var = self.evaluate_test_time_photometric_optim(opt, var)
+        with torch.no_grad():
+            var = self.graph.forward(opt, var, mode="eval")
+            rgb_map = var.rgb.reshape(-1, opt.H, opt.W, 3).movedim(-1, 1).contiguous()
+            score = edict(psnr=metrics.psnr(rgb_map, var.image).item(), ssim=metrics.ssim(rgb_map, var.image).item())
+        return var, rgb_map, score
+
+    def _pose_errors_after_alignment(self, opt):
+        self.graph.eval()
+        return self.evaluate_camera_alignment(opt, self.validate(opt), self.get_all_training_poses(opt)[1])
+
 
 # ------------------------------------------------------------------------------------------ LLFF
-class LLFFEvaluator(_TestTimeRefinement):
-    def __init__(self, opt, graph, pose_GT):
-        """pose_GT: ground-truth w2c poses of the training views [N,3,4] (train_data.get_all_camera_poses)"""
-        self.opt, self.graph = opt, graph
-        self.pose_GT = torch.as_tensor(pose_GT).to(opt.device)
-
-    @torch.no_grad()
+class LLFFEvaluator(_Evaluator):
+    @_detached
     def get_all_training_poses(self, opt):
         """-> (learnt w2c poses, ground truth): the per-view rigid motions registered by the alignment loss (`global_rigid`),
         applied on top of the initial pose every view starts from (the identity: barf_inn_llff.py:156-169)"""
@@ -54,140 +77,134 @@ class LLFFEvaluator(_TestTimeRefinement):
         start = self.graph.pose_eye.expand_as(learnt)
         return camera.pose.compose([learnt, start]), self.pose_GT
 
-    @torch.no_grad()
+    @_detached
     def prealign_cameras(self, opt, pose, pose_GT):
         """-> (learnt poses expressed in the ground-truth frame, sim3) (barf_inn_llff.py:171-187)"""
         pose, pose_GT = torch.as_tensor(pose).to(opt.device), torch.as_tensor(pose_GT).to(opt.device)
         sim3 = posealign.fit_sim3(pose, pose_GT)
         return posealign.transfer_poses(sim3, pose, to_gt=True), sim3
 
-    @torch.no_grad()
+    @_detached
     def evaluate_camera_alignment(self, opt, pose_aligned, pose_GT):
         """-> edict(R [N] rad, t [N]) (barf_inn_llff.py:189-197)"""
         return posealign.pose_errors(torch.as_tensor(pose_aligned), torch.as_tensor(pose_GT))
 
+    def validate(self, opt):
+        """fit the similarity, leave it on the graph for `Graph.get_pose` -> the aligned learnt poses"""
+        aligned, self.graph.sim3 = self.prealign_cameras(opt, *self.get_all_training_poses(opt))
+        return aligned
+
     def evaluate_full(self, opt, test_views, eps=1e-10):
-        """test_views: iterable of var dicts (idx, image [1,3,H,W], intr, pose) -> edict(error=pose errors,
-        res=[edict(psnr, ssim)], rgb / invdepth maps of the last view)"""
-        self.graph.eval()
-        pose, pose_GT = self.get_all_training_poses(opt)
-        pose_aligned, self.graph.sim3 = self.prealign_cameras(opt, pose, pose_GT)
-        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
-        res, maps = [], None
-        for var in test_views:
-            var = edict(var)
-            if opt.optim.test_photo:
-                var = self.evaluate_test_time_photometric_optim(opt, var)
-            with torch.no_grad():
-                var = self.graph.forward(opt, var, mode="eval")
-                invdepth = (1 - var.depth) / var.opacity if opt.camera.ndc else 1 / (var.depth / var.opacity + eps)
-                rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
-                invdepth_map = invdepth.view(-1, opt.H, opt.W, 1).permute(0, 3, 1, 2)
-                res.append(edict(psnr=metrics.psnr(rgb_map, var.image).item(), ssim=metrics.ssim(rgb_map.contiguous(), var.image).item()))
-                maps = edict(rgb=rgb_map, invdepth=invdepth_map)
-        return edict(error=error, res=res, maps=maps)
+        """test_views: iterable of var dicts (idx, image [1,3,H,W], intr, pose) -> edict(error = per-view pose errors,
+        res = [edict(psnr, ssim)], maps = rgb / inverse-depth images of the last view) (barf_inn_llff.py:199-216)"""
+        error = self._pose_errors_after_alignment(opt)
+        scores, maps = [], None
+        for view in test_views:
+            var, rgb_map, score = self._score_view(opt, view)
+            # expected inverse depth of the opaque part of each ray (NDC depth runs 0..1 towards infinity)
+            disparity = (1 - var.depth) / var.opacity if opt.camera.ndc else (var.depth / var.opacity + eps).reciprocal()
+            maps = edict(rgb=rgb_map, invdepth=disparity.reshape(-1, 1, opt.H, opt.W))
+            scores.append(score)
+        return edict(error=error, res=scores, maps=maps)
 
 
 # ------------------------------------------------------------------------------------------ DTU
-class DTUEvaluator(_TestTimeRefinement):
-    def __init__(self, opt, graph, pose_GT):
-        """graph: barf_inn_dtu.Graph (poses live on graph.pose_net); pose_GT: training w2c poses [N,3,4]"""
-        self.opt, self.graph, self.pose_GT = opt, graph, pose_GT.to(opt.device)
+def _frame_is_pinned(opt):
+    """two or more poses held at their ground truth fix the gauge: the learnt frame IS the ground-truth frame"""
+    return opt.pose.n_first_fixed_poses >= 2
 
-    @torch.no_grad()
+
+def _no_alignment(device):
+    return edict(R=torch.eye(3, device=device)[None], t=torch.zeros(1, 3, 1, device=device), s=1.0, type="traj_align")
+
+
+class DTUEvaluator(_Evaluator):
+    """graph: barf_inn_dtu.Graph (the poses live on graph.pose_net)"""
+
+    @_detached
     def get_all_training_poses(self, opt):
         net = self.graph.pose_net
         return camera.pose.compose([net.get_w2c_poses(), net.initial_poses_w2c]), self.pose_GT
 
-    @torch.no_grad()
+    @_detached
     def evaluate_camera_alignment(self, opt, pose_aligned_w2c, pose_GT_w2c):
-        """Rotation (rad) and camera-centre (world frame) errors, not averaged"""
-        a, g = camera.pose.invert(pose_aligned_w2c), camera.pose.invert(pose_GT_w2c)
-        return edict(R=camera.rotation_distance(a[..., :3], g[..., :3]), t=(a[..., 3] - g[..., 3]).norm(dim=-1))
+        """-> edict(R: rotation angle [N] rad, t: distance between the camera CENTRES [N]) (barf_inn_dtu.py:139-170)"""
+        centres = posealign.camera_centers(pose_aligned_w2c) - posealign.camera_centers(pose_GT_w2c)
+        return edict(R=camera.rotation_distance(pose_aligned_w2c[..., :3], pose_GT_w2c[..., :3]), t=centres.norm(dim=-1))
 
-    @torch.no_grad()
+    @_detached
     def prealign_w2c_large_camera_systems(self, opt, pose_w2c, pose_GT_w2c):
-        """sim3 trajectory alignment (Umeyama on the camera centres) -> (aligned w2c poses, est->gt similarity)"""
-        identity = edict(R=torch.eye(3, device=opt.device).unsqueeze(0), t=torch.zeros(1, 3, 1, device=opt.device), s=1., type="traj_align")
-        if opt.pose.n_first_fixed_poses > 1:
-            return pose_w2c, identity
+        """Umeyama similarity between the two trajectories of camera centres (barf_inn_dtu.py:173-201)
+        -> (aligned w2c poses, est->gt similarity record)"""
+        if _frame_is_pinned(opt):
+            return pose_w2c, _no_alignment(opt.device)
         try:
-            aligned_c2w, sim = align_ate_c2b_use_a2b(camera.pose.invert(pose_w2c), camera.pose.invert(pose_GT_w2c), method="sim3")
-            sim.type = "traj_align"
-            return camera.pose.invert(aligned_c2w[:, :3]), sim
-        except np.linalg.LinAlgError:
-            return pose_w2c, identity
+            moved_c2w, record = align_ate_c2b_use_a2b(camera.pose.invert(pose_w2c), camera.pose.invert(pose_GT_w2c), method="sim3")
+        except LinAlgError:                                # the SVD inside Umeyama did not converge
+            return pose_w2c, _no_alignment(opt.device)
+        record.type = "traj_align"
+        return camera.pose.invert(moved_c2w[:, :3]), record
 
-    @torch.no_grad()
+    @_detached
     def prealign_w2c_small_camera_systems(self, opt, pose_w2c, pose_GT_w2c):
-        """For < 10 views: try every ordered pair (a, b) - scale from the a-b baseline, rigid transform from
-        view a - and keep the candidate with the smallest (mean rot deg x mean trans) error."""
-        if opt.pose.n_first_fixed_poses > 1:
-            return pose_w2c, edict(R=torch.eye(3, device=opt.device).unsqueeze(0), t=torch.zeros(1, 3, 1, device=opt.device), s=1.)
-        src = camera.pad_poses(camera.pose.invert(pose_w2c))
-        dst = camera.pad_poses(camera.pose.invert(pose_GT_w2c))
-        n = min(src.shape[0], 10)
-        best = None
-        for a in range(n):
-            for b in range(n):
-                if a == b:
-                    continue
-                scale = torch.norm(dst[a, :3, 3] - dst[b, :3, 3]) / torch.norm(src[a, :3, 3] - src[b, :3, 3])
-                scaled = src.clone()
-                scaled[:, :3, 3] = scaled[:, :3, 3] * scale
-                T = dst[a] @ camera.pose_inverse_4x4(scaled[a])
-                aligned_w2c = camera.pose_inverse_4x4(T[None] @ scaled)[:, :3]
-                err = self.evaluate_camera_alignment(opt, aligned_w2c, pose_GT_w2c)
-                score = err.t.mean().item() * (err.R.mean().item() * 180. / np.pi)
-                if best is None or score < best[0]:
-                    best = (score, aligned_w2c, edict(R=T[:3, :3].unsqueeze(0), type="traj_align", t=T[:3, 3].reshape(1, 3, 1), s=scale))
-        return best[1], best[2]
+        """Few cameras (< 10) do not determine a similarity robustly, so every ORDERED PAIR (a, b) of views proposes one -- scale from
+        the ratio of the a-b baselines, rotation and translation by pinning camera a onto its ground truth -- and the proposal with the
+        smallest (mean rotation error in degrees) x (mean centre error) wins (barf_inn_dtu.py:203-299).  All proposals are evaluated
+        at once: [pairs, N] batched 4x4 algebra."""
+        if _frame_is_pinned(opt):
+            record = _no_alignment(opt.device)
+            record.pop("type")
+            return pose_w2c, record
+        est, truth = camera.pad_poses(camera.pose.invert(pose_w2c)), camera.pad_poses(camera.pose.invert(pose_GT_w2c))
+        n = min(est.shape[0], 10)
+        views = torch.arange(n, device=est.device)
+        a, b = (x.reshape(-1) for x in torch.meshgrid(views, views, indexing="ij"))
+        a, b = a[a != b], b[a != b]
+        centre = lambda T: T[..., :3, 3]
+        scale = (centre(truth)[a] - centre(truth)[b]).norm(dim=-1) / (centre(est)[a] - centre(est)[b]).norm(dim=-1)        # [pairs]
+        scaled = est[None].repeat(len(a), 1, 1, 1)
+        scaled[..., :3, 3] *= scale[:, None, None]
+        pin = truth[a] @ camera.pose_inverse_4x4(scaled[torch.arange(len(a), device=est.device), a])                                           # [pairs,4,4]
+        moved_w2c = camera.pose_inverse_4x4(pin[:, None] @ scaled)[..., :3, :]                                              # [pairs,N,3,4]
+        err = self.evaluate_camera_alignment(opt, moved_w2c, pose_GT_w2c[None])
+        score = err.t.mean(dim=-1) * torch.rad2deg(err.R.mean(dim=-1))
+        k = int(score.argmin())                                          # first minimum: the reference keeps the earliest best pair
+        return moved_w2c[k], edict(R=pin[k, :3, :3][None], type="traj_align", t=pin[k, :3, 3].reshape(1, 3, 1), s=scale[k])
 
     def _prealign(self, opt, pose, pose_GT, large_above):
-        fn = self.prealign_w2c_large_camera_systems if pose.shape[0] > large_above else self.prealign_w2c_small_camera_systems
-        return fn(opt, pose, pose_GT)
+        many = pose.shape[0] > large_above
+        return (self.prealign_w2c_large_camera_systems if many else self.prealign_w2c_small_camera_systems)(opt, pose, pose_GT)
 
-    @torch.no_grad()
+    @_detached
     def evaluate_any_poses(self, opt, pose_w2c, pose_GT_w2c):
-        stats = {}
-        error = self.evaluate_camera_alignment(opt, pose_w2c.detach(), pose_GT_w2c)
-        stats["error_R_before_align"] = error.R.mean() * 180. / np.pi
-        stats["error_t_before_align"] = error.t.mean()
-        pose_aligned, _ = self._prealign(opt, pose_w2c.detach(), pose_GT_w2c, large_above=10)
-        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT_w2c)
-        stats["error_R"] = error.R.mean() * 180. / np.pi
-        stats["error_t"] = error.t.mean()
-        return stats
+        """-> dict of mean rotation (degrees) / centre errors before and after the alignment (barf_inn_dtu.py:116-137)"""
+        pose_w2c = pose_w2c.detach()
+        report = {}
+        for suffix, poses in (("_before_align", pose_w2c), ("", self._prealign(opt, pose_w2c, pose_GT_w2c, large_above=10)[0])):
+            err = self.evaluate_camera_alignment(opt, poses, pose_GT_w2c)
+            report["error_R" + suffix], report["error_t" + suffix] = torch.rad2deg(err.R.mean()), err.t.mean()
+        return report
 
     def evaluate_poses(self, opt):
         return self.evaluate_any_poses(opt, *self.get_all_training_poses(opt))
 
-    @torch.no_grad()
+    @_detached
     def validate(self, opt):
-        """Install the est->gt similarity the val / eval branch of Graph.get_pose needs (barf_inn_dtu.py:370-382)"""
-        pose, pose_GT = self.get_all_training_poses(opt)
-        pose_aligned, self.graph.pose_net.sim3_est_to_gt_c2w = self._prealign(opt, pose, pose_GT, large_above=9)
-        return pose_aligned
+        """fit the est->gt similarity and leave it on the pose network, where the val / eval branch of Graph.get_pose reads it
+        (barf_inn_dtu.py:370-382) -> the aligned learnt poses"""
+        aligned, self.graph.pose_net.sim3_est_to_gt_c2w = self._prealign(opt, *self.get_all_training_poses(opt), large_above=9)
+        return aligned
 
     def evaluate_full(self, opt, test_views):
-        """-> edict(error, res=[edict(psnr, ssim, abs_err, rms_err)]); test views carry depth_gt /
-        valid_depth_gt / depth_range when the dataset has them (nerf_inn_dtu.py:205-262)"""
-        self.graph.eval()
-        pose, pose_GT = self.get_all_training_poses(opt)
-        pose_aligned = self.validate(opt)
-        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
-        scale = self.graph.pose_net.sim3_est_to_gt_c2w.s
-        res = []
-        for var in test_views:
-            var = edict(var)
-            if opt.optim.test_photo:
-                var = self.evaluate_test_time_photometric_optim(opt, var)
-            with torch.no_grad():
-                var = self.graph.forward(opt, var, mode="eval")
-                rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2).contiguous()
-                r = edict(psnr=metrics.psnr(rgb_map, var.image).item(), ssim=metrics.ssim(rgb_map, var.image).item(),
-                          abs_err=float("nan"), rms_err=float("nan"))
-                if "depth_gt" in var and float(scale) != 1.:
-                    r.abs_err, r.rms_err = metrics.compute_depth_metrics(var, float(scale))
-                res.append(r)
-        return edict(error=error, res=res)
+        """-> edict(error, res = [edict(psnr, ssim, abs_err, rms_err)]); depth errors for views that carry depth_gt / valid_depth_gt,
+        with the rendered depth brought to ground-truth units by the similarity's scale (nerf_inn_dtu.py:205-262)"""
+        error = self._pose_errors_after_alignment(opt)
+        scale = float(self.graph.pose_net.sim3_est_to_gt_c2w.s)
+        scores = []
+        for view in test_views:
+            var, _, score = self._score_view(opt, view)
+            score.abs_err = score.rms_err = math.nan
+            if "depth_gt" in var and scale != 1.0:
+                score.abs_err, score.rms_err = metrics.compute_depth_metrics(var, scale)
+            scores.append(score)
+        return edict(error=error, res=scores)

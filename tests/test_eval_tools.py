@@ -2,6 +2,7 @@
 (tests/golden/make_golden_eval.py -> eval_tools.npz): pose algebra, similarity alignment of the optimised
 poses (LLFF Procrustes, DTU pairwise / Umeyama), test-pose back-alignment, depth and image metrics.
 Host-side logic: runs without a GPU."""
+import math
 import os
 import types
 
@@ -93,3 +94,34 @@ def test_image_metrics():
     close(metrics.ssim(G["im_a"], G["im_b"]), G["im_ssim"], 1e-6)
     close(metrics.ssim(G["im_a"], G["im_b"], size_average=False), G["im_ssim_each"], 1e-6)
     close(metrics.psnr(G["im_a"], G["im_b"]), G["im_psnr"], 1e-6)
+
+
+def test_dtu_small_system_alignment_is_the_best_pairwise_proposal():
+    """the batched [pairs, N] evaluation picks the same proposal as trying the ordered pairs one at a time"""
+    torch.manual_seed(3)
+    n = 6
+    gt = camera.pose(R=camera.lie.so3_to_SO3(torch.randn(n, 3) * 0.4), t=torch.randn(n, 3))
+    sim_R, sim_t = camera.lie.so3_to_SO3(torch.randn(3) * 0.7), torch.randn(3)
+    c2w = camera.pose.invert(gt)
+    moved = torch.cat([sim_R @ c2w[..., :3] @ camera.lie.so3_to_SO3(torch.randn(n, 3) * 0.02),
+                       (0.6 * (sim_R @ c2w[..., 3:]) + sim_t[:, None]) + 0.01 * torch.randn(n, 3, 1)], dim=-1)
+    pred = camera.pose.invert(moved)
+    opt = edict(device="cpu", pose=edict(n_first_fixed_poses=0), optim=edict(test_photo=False))
+    ev = evaluation.DTUEvaluator(opt, graph=None, pose_GT=gt)
+    aligned, sim = ev.prealign_w2c_small_camera_systems(opt, pred, gt)
+    best = None
+    E, T = camera.pad_poses(camera.pose.invert(pred)), camera.pad_poses(camera.pose.invert(gt))
+    for a in range(n):
+        for b in range(n):
+            if a != b:
+                s = (T[a, :3, 3] - T[b, :3, 3]).norm() / (E[a, :3, 3] - E[b, :3, 3]).norm()
+                Es = E.clone()
+                Es[:, :3, 3] *= s
+                cand = camera.pose_inverse_4x4((T[a] @ camera.pose_inverse_4x4(Es[a]))[None] @ Es)[:, :3]
+                err = ev.evaluate_camera_alignment(opt, cand, gt)
+                score = err.t.mean().item() * math.degrees(err.R.mean().item())
+                if best is None or score < best[0]:
+                    best = (score, cand, s)
+    close(aligned, best[1], 1e-5)
+    close(float(sim.s), float(best[2]), 1e-6)
+    assert abs(float(sim.s) - 1 / 0.6) < 0.1
