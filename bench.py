@@ -311,35 +311,32 @@ def main():
     if world == 1 and not args.no_composite_scan:
         out["composite_scan"] = composite_scan(dev)
     if world == 1 and not args.no_forward_only and not args.shard_of:
-        # forward-only figure of SURVEY section 8d: one full 300x400 image through the eval path of the same graph
-        # (render_by_slices: slices of rand_rays rays), outside the timed training region
+        # forward-only figure of SURVEY section 8d: one full image through the eval path of the same graph, outside the timed
+        # training region.  Under no_grad render_by_slices is ONE niw_render_fwd call; the stage-by-stage sweep in the reference's
+        # slices of rand_rays rays (bit-identical image, tests/test_gpu_render_call.py) is timed beside it.
         with torch.no_grad():
             pose1, intr1 = torch.eye(3, 4, device=dev)[None], var0.intr[:1]
             kw = dict(depth_range=[1.2, 5.2]) if args.config == "cfg5" else {}
-            g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
-            torch.cuda.synchronize()
-            t_img = (time.perf_counter() - t1) / 2
-            # the same image in the largest slices one launch takes (nerf.eval_slice_rays; results are slice-independent)
-            opt.nerf.eval_slice_rays = opt.H * opt.W
-            g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw)
-            torch.cuda.synchronize()
-            t_big = (time.perf_counter() - t1) / 2
-            opt.nerf.eval_slice_rays = None
+
+            def time_image(render, reps=3):
+                render()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    render()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / reps
+
+            t_img = time_image(lambda: g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw))
+            t_sweep = time_image(lambda: g._sweep_image(opt, lambda first, count: g._render_pixels(opt, pose1, intr1, "eval", pixel_range=(first, count), **kw)))
         n_eval = opt.H * opt.W * (S + (S + Sf if Sf else 0))
+        frac = lambda t: round(n_eval / t * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4)
         out["forward_only"] = dict(value=n_eval / t_img, unit="ray-samples/s", ms_per_image=round(t_img * 1e3, 2),
                                    workload=f"one {opt.H}x{opt.W} image, {S} coarse" + (f" + {S + Sf} fine" if Sf else "") + " samples per ray, "
-                                            f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} slices of {opt.nerf.rand_rays} rays",
-                                   frac_of_fwd_roofline=round(n_eval / t_img * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4),
-                                   largest_slices=dict(value=n_eval / t_big, ms_per_image=round(t_big * 1e3, 2),
-                                                       frac_of_fwd_roofline=round(n_eval / t_big * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4)))
+                                            "one niw_render_fwd call",
+                                   frac_of_fwd_roofline=frac(t_img),
+                                   stage_by_stage=dict(value=n_eval / t_sweep, ms_per_image=round(t_sweep * 1e3, 2), frac_of_fwd_roofline=frac(t_sweep),
+                                                       slices=f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} of {opt.nerf.rand_rays} rays"))
     if world == 1 and not args.no_psnr_parity:
         # the "+ PSNR parity" half of the metric, bounded: 10 identical optimisation steps on the HIP path and on the CPU oracle
         from oracle import parity

@@ -167,6 +167,48 @@ int niw_draw_ray_idx(int64_t n_pixels, int64_t n, uint64_t seed, uint64_t draw, 
 int niw_convert_ndc(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view,
                     float near, float* center_ndc, float* ray_ndc, niw_stream_t stream);
 
+/* ------------------------------------------------------------------ gradient-free render of a pixel range, one call
+ * Graph.render under torch.no_grad() (model/nerf.py:293-319): rays of the pixels first_pixel .. first_pixel+n_pixels-1 of every
+ * view (camera.get_center_and_ray, camera.py:419-443) -> convert_NDC when `ndc` (camera.py:523-540) -> sample_depth
+ * (nerf.py:334-344) -> NeRF.forward_samples + composite (nerf.py:449-474) -> when n_fine > 0: sample_depth_from_pdf, cat, sort,
+ * the fine network and its composite (nerf.py:310-318).  With first_pixel = 0 and n_pixels = H*W it is the whole
+ * Graph.render_by_slices loop (nerf.py:321-332) in one call; the slice size of the reference only bounded its memory and has no
+ * effect on any value.  Results are bit-identical to calling the stages above one by one.
+ *
+ * niw_render_desc is a HOST struct (the only host pointer of this call besides the two band arrays inside it); every pointer
+ * member is a device pointer unless stated. */
+typedef struct niw_render_desc {
+    const float* intr;          /* [n_views,3,3] */
+    const float* pose;          /* [n_views,3,4] world->camera */
+    int32_t n_views, H, W;
+    int32_t ndc;                /* != 0: LLFF normalised device coordinates */
+    int64_t first_pixel, n_pixels;
+    float ndc_near;
+    float depth_min, depth_max; /* opt.nerf.depth.range (DTU: var.depth_range[0]) */
+    int32_t inverse_depth;      /* opt.nerf.depth.param == "inverse" */
+    int32_t n_samples, n_fine;  /* n_fine = 0: single pass */
+    int32_t density_activ;      /* enum niw_density_activ */
+    int32_t has_bg;             /* opt.nerf.setbg_opaque */
+    float bg;
+    const float* u;             /* [n_views*n_pixels, n_samples] stratified draws, or NULL: interval mid-points */
+    const float* unif;          /* inverse-CDF tables of niw_sample_pdf_merge (n_fine > 0) */
+    const float* bins;
+    const float* packed;        /* packed weights of the (coarse) network, niw_mlp_pack_weights */
+    const float* packed_fine;   /* fine network (n_fine > 0) */
+    const float* band_w3d;      /* HOST [10] or NULL */
+    const float* band_wview;    /* HOST [4] or NULL */
+    const float* band_dev;      /* device [14] or NULL (see niw_mlp_fwd) */
+    const float* band_w3d_fine; /* the same three for the fine network (each may be NULL) */
+    const float* band_wview_fine;
+    const float* band_dev_fine;
+} niw_render_desc;
+
+int64_t niw_render_fwd_workspace_floats(int n_views, int64_t n_pixels, int n_samples, int n_fine);
+/* rgb [n_views,n_pixels,3], depth, opacity [n_views,n_pixels]; the *_fine outputs are written when n_fine > 0 (else may be NULL).
+ * workspace: niw_render_fwd_workspace_floats() floats, 16-byte aligned. */
+int niw_render_fwd(const niw_render_desc* desc, float* workspace, float* rgb, float* depth, float* opacity,
+                   float* rgb_fine, float* depth_fine, float* opacity_fine, niw_stream_t stream);
+
 /* ------------------------------------------------------------------ NVP invertible warp
  * DeformNetwork.forward / .inverse (model/nvp/nvp_ndr.py:365-468, 471-567), per-point part.
  * The per-view / per-parameter preprocessing (weight norm g*v/|v| nvp_ndr.py:291-292, code

@@ -12,6 +12,19 @@ LIB_PATH = os.environ.get("NIW_LIB_PATH") or os.path.join(_HERE, "libniw_hip.so"
 
 _vp, _i, _i64, _u64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_double
 
+_i32 = ctypes.c_int32
+
+
+class RenderDesc(ctypes.Structure):
+    """niw_render_desc of include/niw.h, field for field"""
+    _fields_ = [("intr", _vp), ("pose", _vp), ("n_views", _i32), ("H", _i32), ("W", _i32), ("ndc", _i32),
+                ("first_pixel", _i64), ("n_pixels", _i64), ("ndc_near", _f), ("depth_min", _f), ("depth_max", _f),
+                ("inverse_depth", _i32), ("n_samples", _i32), ("n_fine", _i32), ("density_activ", _i32), ("has_bg", _i32), ("bg", _f),
+                ("u", _vp), ("unif", _vp), ("bins", _vp), ("packed", _vp), ("packed_fine", _vp),
+                ("band_w3d", ctypes.POINTER(_f)), ("band_wview", ctypes.POINTER(_f)), ("band_dev", _vp),
+                ("band_w3d_fine", ctypes.POINTER(_f)), ("band_wview_fine", ctypes.POINTER(_f)), ("band_dev_fine", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/niw.h one to one
 SIGNATURES = {
     "niw_version": (_i, []),
@@ -46,6 +59,8 @@ SIGNATURES = {
     "niw_align_solve": (_i, [_vp, _i, _vp, _vp]),
     "niw_align_loss": (_i, [_vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp]),
     "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _d, _f, _vp, _vp, _vp]),
+    "niw_render_fwd_workspace_floats": (_i64, [_i, _i64, _i, _i]),
+    "niw_render_fwd": (_i, [ctypes.POINTER(RenderDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp, _vp]),
 }
 

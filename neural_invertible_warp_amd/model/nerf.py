@@ -292,7 +292,39 @@ class Graph(_BaseGraph):
 
     def render_by_slices(self, opt, pose, intr=None, mode=None):
         """reference nerf.py:321-332 -> edict of [B, H*W, k] maps"""
+        if not torch.is_grad_enabled():
+            return self._render_image(opt, pose, intr)
         return self._sweep_image(opt, lambda first, count: self._render_pixels(opt, pose, intr, mode, pixel_range=(first, count)))
+
+    FUSED_SAMPLES = 1 << 26         # samples per niw_render_fwd call (its workspace: 24 B per sample, 1.6 GB at this size)
+
+    def _render_image(self, opt, pose, intr, depth_range=None):
+        """The gradient-free full-image render (val / eval / novel views) as library calls over pixel ranges (niw_render_fwd:
+        rays -> NDC -> depths -> field -> compositing [-> fine pass] in one call), normally ONE for the whole image.  Same
+        numbers as the stage-by-stage path, which stays in use wherever a gradient may be asked for."""
+        B, total, S = pose.shape[0], opt.H * opt.W, opt.nerf.sample_intvs
+        Sf = opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0
+        step = max(1, min(total, self.FUSED_SAMPLES // (B * (S + (S + Sf if Sf else 0)))))
+        fine = getattr(self, "nerf_fine", None) if Sf else None
+        image = None
+        with self._hold_weights():
+            for first in range(0, total, step):
+                count = min(step, total - first)
+                u = torch.rand(B * count, S, device=opt.device) if opt.nerf.sample_stratified else None
+                part = ops.render_fwd(
+                    intr, pose, opt.H, opt.W, (first, count), S, opt.nerf.depth.range if depth_range is None else depth_range,
+                    opt.nerf.depth.param == "inverse", self.nerf._state.packed(), self.nerf.band_weights(opt, ops.L3D),
+                    self.nerf.band_weights(opt, ops.LVIEW), opt.arch.density_activ, u=u, ndc_near=1.0 if opt.camera.ndc else None, n_fine=Sf,
+                    packed_fine=None if fine is None else fine._state.packed(), pdf_range=opt.nerf.depth.range,
+                    bg=opt.data.bgcolor if opt.nerf.setbg_opaque else None, band_dev=self.nerf.band_dev,
+                    bands_fine=None if fine is None else (fine.band_weights(opt, ops.L3D), fine.band_weights(opt, ops.LVIEW), fine.band_dev))
+                if count == total:
+                    return edict(part)
+                if image is None:
+                    image = edict({k: v.new_empty(B, total, v.shape[2]) for k, v in part.items()})
+                for k, v in part.items():
+                    image[k][:, first:first + count] = v
+        return image
 
     def sample_depth(self, opt, batch_size, num_rays=None, depth_range=None):
         """reference nerf.py:334-344 -> [B,R,S,1]; the stratified draw is torch.rand as in the

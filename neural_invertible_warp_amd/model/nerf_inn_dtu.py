@@ -73,6 +73,8 @@ class Graph(nerf_inn_llff.Graph):
 
     def render_by_slices(self, opt, pose, intr=None, mode=None, depth_range=None):
         """reference nerf_inn_dtu.py:511-522"""
+        if not torch.is_grad_enabled():
+            return self._render_image(opt, pose, intr, depth_range=depth_range)
         return self._sweep_image(opt, lambda first, count: self._render_pixels(opt, pose, intr, mode, pixel_range=(first, count),
                                                                                depth_range=depth_range))
 

@@ -158,6 +158,44 @@ def sample_pdf_merge(pdf, depth_coarse, Sf, depth_range):
     return fine, merged
 
 
+def render_fwd(intr, pose, H, W, pixel_range, n_samples, depth_range, inverse_depth, packed, band3d, bandview, activ, u=None, ndc_near=None,
+               n_fine=0, packed_fine=None, pdf_range=None, bg=None, band_dev=None, bands_fine=None):
+    """Gradient-free render of the pixels `pixel_range` = (first, count) of every view as ONE library call (niw_render_fwd): rays,
+    NDC (when `ndc_near` is given), stratified depths from `u` [B*count, S] (None: mid-points), field MLP, compositing and, when
+    n_fine > 0, the inverse-CDF / merge / fine-network pass.  `packed` / `packed_fine`: FieldState.packed() images; `bands_fine` = (band3d, bandview, band_dev) of the fine
+    network (None: all ones).
+    -> dict(rgb [B,count,3], depth [B,count,1], opacity [B,count,1] [, rgb_fine, depth_fine, opacity_fine])"""
+    intr, pose = _f32(intr, "intr"), _f32(pose, "pose")
+    B, dev = intr.shape[0], intr.device
+    first, count = int(pixel_range[0]), int(pixel_range[1])
+    if u is not None:
+        u = _f32(u, "u")
+        if u.numel() != B * count * n_samples:
+            raise _lib.NiwError(f"render_fwd: u has {u.numel()} elements for {B} x {count} rays x {n_samples} samples")
+    d = _lib.RenderDesc(intr=intr.data_ptr(), pose=pose.data_ptr(), n_views=B, H=H, W=W, ndc=0 if ndc_near is None else 1, first_pixel=first,
+                        n_pixels=count, ndc_near=0.0 if ndc_near is None else float(ndc_near), depth_min=float(depth_range[0]),
+                        depth_max=float(depth_range[1]), inverse_depth=1 if inverse_depth else 0, n_samples=n_samples, n_fine=n_fine,
+                        density_activ=ACT[activ], has_bg=0 if bg is None else 1, bg=0.0 if bg is None else float(bg),
+                        u=None if u is None else u.data_ptr(), packed=packed.data_ptr(), band_dev=None if band_dev is None else band_dev.data_ptr())
+    b3, bv = _farr(band3d, L3D), _farr(bandview, LVIEW)
+    d.band_w3d, d.band_wview = ctypes.cast(b3, ctypes.POINTER(ctypes.c_float)), ctypes.cast(bv, ctypes.POINTER(ctypes.c_float))
+    out = {k: torch.empty(B, count, c, device=dev, dtype=torch.float32) for k, c in (("rgb", 3), ("depth", 1), ("opacity", 1))}
+    tables = None
+    if n_fine:
+        tables = _pdf_tables(n_samples, n_fine, depth_range if pdf_range is None else pdf_range, dev)
+        d.unif, d.bins, d.packed_fine = tables[0].data_ptr(), tables[1].data_ptr(), packed_fine.data_ptr()
+        if bands_fine is not None:
+            f3, fv = _farr(bands_fine[0], L3D), _farr(bands_fine[1], LVIEW)
+            d.band_w3d_fine, d.band_wview_fine = ctypes.cast(f3, ctypes.POINTER(ctypes.c_float)), ctypes.cast(fv, ctypes.POINTER(ctypes.c_float))
+            d.band_dev_fine = None if bands_fine[2] is None else bands_fine[2].data_ptr()
+        out.update({k + "_fine": torch.empty_like(v) for k, v in list(out.items())})
+    ws = torch.empty(_lib.load().niw_render_fwd_workspace_floats(B, count, n_samples, n_fine), device=dev, dtype=torch.float32)
+    with timed("render_fwd", B * count * (n_samples + (n_samples + n_fine if n_fine else 0))):
+        _lib.call("niw_render_fwd", ctypes.byref(d), _p(ws), _p(out["rgb"]), _p(out["depth"]), _p(out["opacity"]), _p(out.get("rgb_fine")),
+                  _p(out.get("depth_fine")), _p(out.get("opacity_fine")), _stream())
+    return out
+
+
 def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
     """(lr / bias_correction1, sqrt(bias_correction2)) as torch.optim.Adam forms them: the two step-dependent scalars of the update"""
     return lr / (1.0 - beta1 ** step), math.sqrt(1.0 - beta2 ** step)

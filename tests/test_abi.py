@@ -103,6 +103,17 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.niw_mlp_fwd(p, p, p, p, None, 1 << 20, 64, None, None, None, 1, p, p, None, None) == -1 and "too many samples" in err()
     assert lib.niw_warp_prep_fwd(p, p, 65, p, p, p, p, None) == -1 and "views" in err()
     assert lib.niw_warp_prep_fwd(p, p, 0, p, p, p, p, None) == -1
+    # the one-call render: null descriptor, incomplete descriptor, pixel range outside the image, fine pass without its tables
+    assert lib.niw_render_fwd(None, p, p, p, p, None, None, None, None) == -1 and "null pointer" in err()
+    d = _lib.RenderDesc(n_views=1, H=4, W=4, first_pixel=0, n_pixels=16, n_samples=8)
+    assert lib.niw_render_fwd(ctypes.byref(d), p, p, p, p, None, None, None, None) == -1 and "cameras" in err()
+    d.intr = d.pose = d.packed = p
+    d.first_pixel = 8
+    assert lib.niw_render_fwd(ctypes.byref(d), p, p, p, p, None, None, None, None) == -1 and "outside" in err()
+    d.first_pixel, d.n_fine = 0, 8
+    assert lib.niw_render_fwd(ctypes.byref(d), p, p, p, p, None, None, None, None) == -1 and "fine pass" in err()
+    assert lib.niw_render_fwd_workspace_floats(2, 10, 8, 0) == 4 * 60 + 3 * 160 + 480
+    assert lib.niw_render_fwd_workspace_floats(2, 10, 8, 4) == 4 * 60 + 3 * 160 + 480 + 2 * 240 + 720
     # workspace queries are pure host arithmetic
     assert lib.niw_warp_prep_fwd_workspace_floats(18) == 3 * 18 * 128
     assert lib.niw_mlp_bwd_workspace_floats(4, 8) == 511 * (256 * 256 + 256) + 508 * (256 * 64 + 256) + 256 * (128 * 288 + 256)
