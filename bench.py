@@ -34,6 +34,7 @@ HBM GB/s), `forward_only` (one full 300x400 image through the eval path), `psnr_
 `cpu_baseline` (the CPU oracle's identical step on the host cores, bounded sample).  Each can be skipped with --no-<name>.
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -236,6 +237,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     loss_value = float(loss.all.detach())
+    if not math.isfinite(loss_value):
+        raise SystemExit(f"bench.py: the training loss is {loss_value} after {max(args.warmup, 3) + args.steps} iterations -- a timing of a diverged "
+                         "run is not a measurement")
     graphed = all(tr._captured is not None for tr, *_ in loads)
     # per-kernel device events: a few more iterations launched one by one (events cannot be recorded inside a replayed graph);
     # outside the timed region, same kernels, same shapes

@@ -450,6 +450,14 @@ int fill_args(WarpArgs& a, const float* w_emb, const float* view_b, const float*
 
 long long warp_ppad(int n_views, int64_t n_pts) { return ((long long)n_views * n_pts + 31) / 32 * 32; }
 
+// The factor rows are [row][ppad] with ppad = points rounded up to 32: the GEMMs reduce over all ppad columns, so the < 32 pad
+// columns of every row must be zero.  A kernel (not hipMemsetAsync): a memset NODE of a captured graph was observed to leave
+// stale pad columns on replays at full size (NaN parameters after the second replay), and only rows x pad elements need writing.
+__global__ void warp_zero_pad_kernel(float* ws, long long n_rows, long long ppad, int first_pad, int n_pad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows * n_pad) ws[(i / n_pad) * ppad + first_pad + (int)(i % n_pad)] = 0.f;
+}
+
 }  // namespace
 
 static_assert(NIW_WARP_WEMB_FLOATS == 3 * kWembBlock && NIW_WARP_WHEAD_FLOATS == 3 * kHeadBlock, "header constants");
@@ -488,8 +496,11 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
     const long long ppad = warp_ppad(n_views, n_pts);
     a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad;
     // padded columns of the factor rows must be zero
-    if (ppad != (long long)n_views * n_pts)
-        (void)hipMemsetAsync(workspace, 0, sizeof(float) * 3 * kRowsPerBlock * ppad, st);
+    if (const int n_pad = (int)(ppad - (long long)n_views * n_pts)) {
+        const long long n_rows = 3ll * kRowsPerBlock;
+        warp_zero_pad_kernel<<<(unsigned)((n_rows * n_pad + 255) / 256), 256, 0, st>>>(workspace, n_rows, ppad, (int)(ppad - n_pad), n_pad);
+        NIW_LAUNCH_CHECK("niw_warp_bwd (pad)");
+    }
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc2 = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(warp_bwd_kernel), kWarpLds, attr_set, "niw_warp_bwd")) return rc2;
     warp_bwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, st>>>(a);
