@@ -41,13 +41,12 @@ inline int niw_ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<
     return NIW_OK;
 }
 
-// Operand of the NT GEMM (niw_dw_gemm.hip): rows of samples, possibly blocked along the sample axis.
+// Operand of the NT GEMM (niw_dw_gemm.hip): feature-major rows of samples.
 struct NiwGemmOperand {
     const float* p;
     int rows;                 // valid rows (rows beyond are read as zero)
     long long batch_stride;   // floats between batches (blockIdx.y)
-    long long row_stride;     // floats between rows inside a block
-    long long blk_stride;     // floats between sample blocks (0 when the layout is a single block)
+    long long row_stride;     // floats between rows (>= the padded sample count)
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -10,6 +10,7 @@
 // kernel sums the partial tiles in a fixed order (deterministic; no float atomics) and
 // scatters the result into the state-dict layout of d_params.
 #include "niw_common.h"
+#include "niw_mlp_device.h"
 
 using namespace niw;
 
@@ -20,9 +21,8 @@ int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float*
 
 // C[n][k] = sum_m A[n][m] B[k][m] per batch; tile 256x256 (wide) or 256x64; partial tiles
 // [batch][nsplit][TN*TK + 256] (the trailing 256 floats are row sums of A (bias_side 1) or B (2)).
-// Operand addressing (NiwGemmOperand, niw_common.h): 32-sample slice `s` of row r sits at
-//   p + batch*batch_stride + (s / spb)*blk_stride + r*row_stride + (s % spb)*32.
-int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
+// Operand addressing (NiwGemmOperand, niw_common.h): 32-sample slice `s` of row r sits at p + batch*batch_stride + r*row_stride + s*32.
+int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long mpad, int batches, float* partial,
                        int bias_side, int* nsplit_out, hipStream_t st);
 
 namespace {
@@ -38,24 +38,32 @@ struct GemmBatch {
 };
 
 // WN x WK waves; each wave owns NBW x KBW blocks of 32x32 outputs.
+// Operand slices reach LDS through registers: per 32-sample step every thread issues LOADS 16-byte buffer loads -- ONE 32-bit
+// lane offset per operand, the row group and the step folded into the scalar offset, rows beyond the operand's valid rows cut
+// off by the descriptor's range (they read as zero) -- and writes them to the other LDS buffer half a step later.  (Round 2:
+// with a 64-bit address and an exec-mask branch per load the loads alone cost the wide kernel 11 %: both waves of a SIMD reach
+// them together, right after the barrier, so their ~100 address / branch instructions ran with the matrix pipe idle.)
 template <int WN, int WK, int NBW, int KBW>
-__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int spb, int steps_total, int steps_per_wg,
+__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
                                                                float* __restrict__ partial) {
     const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
     const int bias_side = batch.bias_side[blockIdx.y];
-    const float* __restrict__ A = opA.p;
-    const float* __restrict__ B = opB.p;
-    const int rowsA = opA.rows, rowsB = opB.rows;
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
     constexpr int ROWS = TN + TK;
     constexpr int LOADS = ROWS * 8 / NT;                  // float4 loads per thread per 32-sample step
-    static_assert(ROWS * 8 % NT == 0, "tile must divide over the threads");
+    constexpr int GROUP = NT / 8;                         // rows covered by one load of the whole workgroup
+    static_assert(ROWS * 8 % NT == 0 && TN % GROUP == 0, "tile must divide over the threads, each load entirely A or B");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WK, wk = wave % WK;
     const int i = lane & 31, h = lane >> 5;
     const int step0 = blockIdx.x * steps_per_wg;
     const int nsteps = min(steps_per_wg, steps_total - step0);
+    // descriptors end after the last valid row: loads of rows beyond return zero (host: rows * row_stride * 4 < 2^31)
+    const int strideA4 = (int)opA.row_stride * 4, strideB4 = (int)opB.row_stride * 4;
+    const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, min(opA.rows, TN) * strideA4, 0x00020000);
+    const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, min(opB.rows, TK) * strideB4, 0x00020000);
+    const int voffA = (tid >> 3) * strideA4 + (tid & 7) * 16, voffB = (tid >> 3) * strideB4 + (tid & 7) * 16;
 
     f32x16 acc[NBW][KBW];
 #pragma unroll
@@ -68,19 +76,11 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
 
     f32x4 stage[LOADS];
     auto gload = [&](int step) {
-        // 32-sample slice `step` of a row lives at  block(step / spb) * blk_stride + row * row_stride + (step % spb) * 32
-        const long long blk = step / spb;
-        const int within = (step % spb) * 32;
-        const float* Ab = A + blk * opA.blk_stride + within;
-        const float* Bb = B + blk * opB.blk_stride + within;
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
-            const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
-            const bool isA = row < TN;
-            const int rr = isA ? row : row - TN;
-            const bool ok = isA ? rr < rowsA : rr < rowsB;
-            const float* src = (isA ? Ab + (long long)rr * opA.row_stride : Bb + (long long)rr * opB.row_stride) + c4 * 4;
-            stage[k] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool isA = k * GROUP < TN;
+            const int g = isA ? k * GROUP : k * GROUP - TN;                 // first row of this load's row group
+            stage[k] = isA ? buf_load4(rsA, voffA, step * 128 + g * strideA4) : buf_load4(rsB, voffB, step * 128 + g * strideB4);
         }
     };
     auto lstore = [&](int buf) {
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
+#if !defined(NIW_DW_DIAG_NOLOAD) && !defined(NIW_DW_DIAG_NOGLOAD)
         if (s + 1 < nsteps) gload(step0 + s + 1);
+#endif
         const float* As = lds + buf * ROWS * kLdsStride;
         const float* Bs = As + TN * kLdsStride;
         // fragment reads of k-block kb+1 are issued before the MFMAs of k-block kb (the two waves of a SIMD are
@@ -127,8 +129,11 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
             // the next slice goes to the OTHER LDS buffer (free since the barrier that ended the previous step): write it
             // under the MFMAs of the last k-block instead of between the last MFMA and the barrier, where all eight waves
             // would queue 64 KB of ds_write with the matrix pipe idle
+#if !defined(NIW_DW_DIAG_NOLOAD) && !defined(NIW_DW_DIAG_NOLSTORE)
             if (kb == 2 && s + 1 < nsteps) lstore(buf ^ 1);
+#endif
         }
+#ifndef NIW_DW_DIAG_NOBIAS
         if (bias_side) {
             // row sums of the dY operand: thread t < rows sums its row of the staged slice
             const int nrows = bias_side == 1 ? TN : TK;
@@ -141,8 +146,17 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
                 }
             }
         }
+#endif
+#ifndef NIW_DW_DIAG_NOBARRIER
         __syncthreads();
+#endif
     }
+#ifdef NIW_DW_DIAG_NOLSTORE
+    if (nsteps > 1) { float z = 0.f;
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) z += stage[k][0] + stage[k][1] + stage[k][2] + stage[k][3];
+        bsum += z * 1e-30f; }
+#endif
     // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
     float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
 #pragma unroll
@@ -212,7 +226,7 @@ struct Piece {
 };
 
 template <int WN, int WK, int NBW, int KBW>
-int launch_gemm(const GemmBatch& batch, int spb, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
+int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
     // at least 8 slices per workgroup; one workgroup per CU, or -- for a batch of equal pieces -- just under two
@@ -230,22 +244,32 @@ int launch_gemm(const GemmBatch& batch, int spb, long long mpad, int batches, fl
     auto kern = dw_gemm_kernel<WN, WK, NBW, KBW>;
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM")) return rc;
-    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(batch, spb, steps_total, per, partial);
+    for (int b = 0; b < batches; ++b) {
+        // 32-bit byte offsets inside an operand (buffer addressing)
+        const long long ea = (long long)(batch.A[b].rows < TN ? batch.A[b].rows : TN) * batch.A[b].row_stride * 4;
+        const long long eb = (long long)(batch.B[b].rows < TK ? batch.B[b].rows : TK) * batch.B[b].row_stride * 4;
+        if (ea >= (1ll << 31) || eb >= (1ll << 31) || mpad > batch.A[b].row_stride || mpad > batch.B[b].row_stride) {
+            niw_set_error("NT GEMM: operand of %lld rows x %lld samples exceeds the 2 GiB reach of a buffer descriptor (or rows shorter than the reduction)",
+                          (long long)(ea >= eb ? batch.A[b].rows : batch.B[b].rows), mpad);
+            return NIW_ERR_INVALID_ARG;
+        }
+    }
+    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(batch, steps_total, per, partial);
     NIW_LAUNCH_CHECK("NT GEMM");
     *nsplit_out = nsplit;
     return NIW_OK;
 }
 
-int launch_shape(int wide, const GemmBatch& batch, int spb, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
+int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
-    if (wide == 2) return launch_gemm<4, 1, 1, 9>(batch, spb, mpad, batches, partial, nsplit_out, st);
-    return wide ? launch_gemm<4, 2, 2, 4>(batch, spb, mpad, batches, partial, nsplit_out, st)
-                : launch_gemm<8, 1, 1, 2>(batch, spb, mpad, batches, partial, nsplit_out, st);
+    if (wide == 2) return launch_gemm<4, 1, 1, 9>(batch, mpad, batches, partial, nsplit_out, st);
+    return wide ? launch_gemm<4, 2, 2, 4>(batch, mpad, batches, partial, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2>(batch, mpad, batches, partial, nsplit_out, st);
 }
 
 }  // namespace
 
-int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
+int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long mpad, int batches, float* partial,
                        int bias_side, int* nsplit_out, hipStream_t st) {
     // `batches` products whose operands are batch_stride floats apart
     if (batches < 1 || batches > kMaxBatch) {
@@ -258,7 +282,7 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, lo
         gb.B[b] = B; gb.B[b].p = B.p + (long long)b * B.batch_stride;
         gb.bias_side[b] = bias_side;
     }
-    return launch_shape(wide, gb, spb, mpad, batches, partial, nsplit_out, st);
+    return launch_shape(wide, gb, mpad, batches, partial, nsplit_out, st);
 }
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
@@ -314,12 +338,12 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         for (int b = 0; b < g.n; ++b) {
             const Piece& p = g.p[b];
             // workspaces are plain feature-major [row][Mpad]: row pitch Mpad, a single sample block
-            gb.A[b] = NiwGemmOperand{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad, 0};
-            gb.B[b] = NiwGemmOperand{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad, 0};
+            gb.A[b] = NiwGemmOperand{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad};
+            gb.B[b] = NiwGemmOperand{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad};
             gb.bias_side[b] = p.bias ? (p.transposed ? 2 : 1) : 0;
         }
         int nsplit = 0;
-        int rc = launch_shape(g.wide, gb, (int)(mpad / 32), mpad, g.n, partial + off, &nsplit, st);
+        int rc = launch_shape(g.wide, gb, mpad, g.n, partial + off, &nsplit, st);
         if (rc != NIW_OK) return rc;
         const long long tile = (long long)g.TN * g.TK + 256;
         for (int b = 0; b < g.n; ++b) {

@@ -19,7 +19,7 @@
 // fp32 MFMA path (niw_dw_gemm.hip) -- no atomics, deterministic.
 #include "niw_common.h"
 
-int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, int spb, long long mpad, int batches, float* partial,
+int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long mpad, int batches, float* partial,
                        int bias_side, int* nsplit_out, hipStream_t st);
 
 namespace {
@@ -509,13 +509,11 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
     float* p2 = p1 + 3ll * 256 * (256 * 256 + 256);
     const long long stride = (long long)kRowsPerBlock * ppad;
     int ns1 = 0, ns2 = 0;
-    // plain feature-major factor rows [row][ppad]: one "block" spanning every slice
-    const int spb = (int)(ppad / 32);
-    rc = niw_launch_nt_gemm(1, NiwGemmOperand{workspace + kRowGa * ppad, 256, stride, ppad, 0},
-                            NiwGemmOperand{workspace + kRowEa * ppad, 128, stride, ppad, 0}, spb, ppad, 3, p1, 0, &ns1, st);
+    rc = niw_launch_nt_gemm(1, NiwGemmOperand{workspace + kRowGa * ppad, 256, stride, ppad},
+                            NiwGemmOperand{workspace + kRowEa * ppad, 128, stride, ppad}, ppad, 3, p1, 0, &ns1, st);
     if (rc != NIW_OK) return rc;
-    rc = niw_launch_nt_gemm(0, NiwGemmOperand{workspace + kRowHa * ppad, 256, stride, ppad, 0},
-                            NiwGemmOperand{workspace + kRowGo * ppad, 4, stride, ppad, 0}, spb, ppad, 3, p2, 2, &ns2, st);
+    rc = niw_launch_nt_gemm(0, NiwGemmOperand{workspace + kRowHa * ppad, 256, stride, ppad},
+                            NiwGemmOperand{workspace + kRowGo * ppad, 4, stride, ppad}, ppad, 3, p2, 2, &ns2, st);
     if (rc != NIW_OK) return rc;
     warp_reduce_kernel<<<dim3((256 * 256 + 256 * 64 + 256 + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, n_views, d_w_emb, d_view_b, d_w_head);
     NIW_LAUNCH_CHECK("niw_warp_bwd (reduce)");
