@@ -11,6 +11,7 @@
 // scatters the result into the state-dict layout of d_params.
 #include "niw_common.h"
 #include "niw_mlp_device.h"
+#include <type_traits>
 
 using namespace niw;
 
@@ -28,6 +29,20 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
 namespace {
 
 constexpr int kLdsStride = 36;   // 32 samples + 4 pad floats per row
+#ifndef NIW_DW_SUMS_KB
+#define NIW_DW_SUMS_KB 0
+#endif
+#ifndef NIW_DW_PF_SKINNY
+#define NIW_DW_PF_SKINNY 2
+#endif
+#ifndef NIW_DW_PF_COLOUR
+#define NIW_DW_PF_COLOUR 2
+#endif
+#ifndef NIW_DW_COLOUR_288
+constexpr int kColourTK = 320;   // colour layer as 4 x 2 waves of 1 x 5 blocks (the 10th column block holds no valid row and is skipped)
+#else
+constexpr int kColourTK = 288;
+#endif
 
 // Up to kMaxBatch independent products per launch (blockIdx.y): the seven 256 x 256 weight gradients of a network, or its four
 // skinny pieces -- each with its own operand pair and bias side.
@@ -43,7 +58,10 @@ struct GemmBatch {
 // off by the descriptor's range (they read as zero) -- and writes them to the other LDS buffer half a step later.  (Round 2:
 // with a 64-bit address and an exec-mask branch per load the loads alone cost the wide kernel 11 %: both waves of a SIMD reach
 // them together, right after the barrier, so their ~100 address / branch instructions ran with the matrix pipe idle.)
-template <int WN, int WK, int NBW, int KBW>
+// SKIP: 32 x 32 output blocks that lie entirely beyond the valid rows of either operand (the 3-row colour head in a 64-column
+// tile, the 128-row operand in a 256-row tile, the 288 of 320 columns of the colour layer) issue no MFMAs -- the skinny
+// launches are bound by their padded matrix work, not by HBM.
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF>
 __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
                                                                float* __restrict__ partial) {
     const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
@@ -54,10 +72,15 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
     constexpr int GROUP = NT / 8;                         // rows covered by one load of the whole workgroup
     static_assert(ROWS * 8 % NT == 0 && TN % GROUP == 0, "tile must divide over the threads, each load entirely A or B");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WK, wk = wave % WK;
     const int i = lane & 31, h = lane >> 5;
     const int step0 = blockIdx.x * steps_per_wg;
+    bool live[NBW][KBW];
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y) live[x][y] = !SKIP || ((wn * NBW + x) * 32 < opA.rows && (wk * KBW + y) * 32 < opB.rows);
     const int nsteps = min(steps_per_wg, steps_total - step0);
     // descriptors end after the last valid row: loads of rows beyond return zero (host: rows * row_stride * 4 < 2^31)
     const int strideA4 = (int)opA.row_stride * 4, strideB4 = (int)opB.row_stride * 4;
@@ -74,45 +97,58 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
     float bsum = 0.f;
 
-    f32x4 stage[LOADS];
-    auto gload = [&](int step) {
+    // Register prefetch: the loads of step s + PF are issued at the start of step s and reach LDS half a step before they are
+    // needed (LDS stays double-buffered).  PF = 1 for the wide tile (a step is ~7 us of MFMA work: ample cover for an HBM read,
+    // and its 8 loads per thread leave no registers for a second stage); PF = 2 for the skinny and colour tiles, whose steps
+    // are 4-8x shorter than an HBM round trip under load -- with PF = 1 they were bound by that latency, not by MFMA or bytes.
+    f32x4 stage[PF][LOADS];
+    auto gload = [&](int step, int slot) {
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
             const bool isA = k * GROUP < TN;
             const int g = isA ? k * GROUP : k * GROUP - TN;                 // first row of this load's row group
-            stage[k] = isA ? buf_load4(rsA, voffA, step * 128 + g * strideA4) : buf_load4(rsB, voffB, step * 128 + g * strideB4);
+            stage[slot][k] = isA ? buf_load4(rsA, voffA, step * 128 + g * strideA4) : buf_load4(rsB, voffB, step * 128 + g * strideB4);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int slot) {
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
             const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<f32x4*>(lds + (buf * ROWS + row) * kLdsStride + c4 * 4) = stage[k];
+            *reinterpret_cast<f32x4*>(lds + (buf * ROWS + row) * kLdsStride + c4 * 4) = stage[slot][k];
         }
     };
-
-    if (nsteps > 0) {
-        gload(step0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
+    // one 32-sample step; `slot` = s % PF at compile time (the register stage that receives step s + PF, after step s + 1 has
+    // left stage (s + 1) % PF for LDS)
+    auto step_body = [&](int s, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
         const int buf = s & 1;
-#if !defined(NIW_DW_DIAG_NOLOAD) && !defined(NIW_DW_DIAG_NOGLOAD)
-        if (s + 1 < nsteps) gload(step0 + s + 1);
-#endif
+        if (s + PF < nsteps) gload(step0 + s + PF, slot);
         const float* As = lds + buf * ROWS * kLdsStride;
         const float* Bs = As + TN * kLdsStride;
         // fragment reads of k-block kb+1 are issued before the MFMAs of k-block kb (the two waves of a SIMD are
         // barrier-synchronised, so without this both sit in the LDS latency at the same time)
         f32x4 af[2][NBW], bf[2][KBW];
-        auto lread = [&](int kb, int slot) {
+        auto lread = [&](int kb, int fs) {
 #pragma unroll
             for (int x = 0; x < NBW; ++x)
-                af[slot][x] = *reinterpret_cast<const f32x4*>(As + ((wn * NBW + x) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+                af[fs][x] = *reinterpret_cast<const f32x4*>(As + ((wn * NBW + x) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
 #pragma unroll
             for (int y = 0; y < KBW; ++y)
-                bf[slot][y] = *reinterpret_cast<const f32x4*>(Bs + ((wk * KBW + y) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+                bf[fs][y] = *reinterpret_cast<const f32x4*>(Bs + ((wk * KBW + y) * 32 + i) * kLdsStride + kb * 8 + 4 * h);
+        };
+        auto row_sums = [&]() {
+            if (bias_side) {
+                // row sums of the dY operand: thread t < rows sums its row of the staged slice
+                const int nrows = bias_side == 1 ? TN : TK;
+                if (tid < nrows) {
+                    const float* rowp = (bias_side == 1 ? As : Bs) + tid * kLdsStride;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + c * 4);
+                        bsum += (v[0] + v[1]) + (v[2] + v[3]);
+                    }
+                }
+            }
         };
         lread(0, 0);
 #pragma unroll
@@ -123,40 +159,33 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
             for (int x = 0; x < NBW; ++x)
 #pragma unroll
                 for (int y = 0; y < KBW; ++y)
+                    if (live[x][y]) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[x][y] = mfma32(af[kb & 1][x][t], bf[kb & 1][y][t], acc[x][y]);
+                        for (int t = 0; t < 4; ++t) acc[x][y] = mfma32(af[kb & 1][x][t], bf[kb & 1][y][t], acc[x][y]);
+                    }
             __builtin_amdgcn_sched_barrier(0);
             // the next slice goes to the OTHER LDS buffer (free since the barrier that ended the previous step): write it
             // under the MFMAs of the last k-block instead of between the last MFMA and the barrier, where all eight waves
             // would queue 64 KB of ds_write with the matrix pipe idle
-#if !defined(NIW_DW_DIAG_NOLOAD) && !defined(NIW_DW_DIAG_NOLSTORE)
-            if (kb == 2 && s + 1 < nsteps) lstore(buf ^ 1);
-#endif
+            if (kb == 2 && s + 1 < nsteps) lstore(buf ^ 1, (slot + 1) % PF);
+            // bias sums of waves 0..3 go between two k-blocks, where their SIMD partners (waves 4..7) keep the matrix pipe busy
+            // (measured equal to placing them after the last k-block)
+            if (kb == NIW_DW_SUMS_KB) row_sums();
         }
-#ifndef NIW_DW_DIAG_NOBIAS
-        if (bias_side) {
-            // row sums of the dY operand: thread t < rows sums its row of the staged slice
-            const int nrows = bias_side == 1 ? TN : TK;
-            if (tid < nrows) {
-                const float* rowp = (bias_side == 1 ? As : Bs) + tid * kLdsStride;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + c * 4);
-                    bsum += (v[0] + v[1]) + (v[2] + v[3]);
-                }
-            }
-        }
-#endif
-#ifndef NIW_DW_DIAG_NOBARRIER
+        if (NIW_DW_SUMS_KB > 3) row_sums();
         __syncthreads();
-#endif
+    };
+
+    if (nsteps > 0) {
+        gload(step0, 0);
+        lstore(0, 0);
     }
-#ifdef NIW_DW_DIAG_NOLSTORE
-    if (nsteps > 1) { float z = 0.f;
-#pragma unroll
-        for (int k = 0; k < LOADS; ++k) z += stage[k][0] + stage[k][1] + stage[k][2] + stage[k][3];
-        bsum += z * 1e-30f; }
-#endif
+    if (PF == 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += PF) {
+        step_body(s, std::integral_constant<int, 0>{});
+        if (PF == 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+    }
     // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
     float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
 #pragma unroll
@@ -218,6 +247,10 @@ __global__ void dw_reduce_kernel(ReduceBatch batch, const float* __restrict__ pa
     }
 }
 
+// every group's partial tiles live side by side until the single reduction: <= 511 tiles of 256 x 256 (7 x 73 splits),
+// <= 508 of 256 x 64 (4 x 127), <= 256 of 128 x 320
+constexpr long long kPartialTileFloats = 511ll * (256 * 256 + 256) + 508ll * (256 * 64 + 256) + 256ll * (128 * 320 + 256);
+
 struct Piece {
     int layer;
     int a_row, a_rows;   // dY-side operand: first row in gradws / valid rows   (X side when transposed)
@@ -225,7 +258,7 @@ struct Piece {
     int n_off, k_off, transposed, bias, wide;   // wide: 256x256 tile, else 256x64
 };
 
-template <int WN, int WK, int NBW, int KBW>
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF>
 int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
@@ -241,7 +274,7 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     const int per = (steps_total + nsplit - 1) / nsplit;
     nsplit = (steps_total + per - 1) / per;
     const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
-    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW>;
+    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW, SKIP, PF>;
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM")) return rc;
     for (int b = 0; b < batches; ++b) {
@@ -262,9 +295,13 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
 
 int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
-    if (wide == 2) return launch_gemm<4, 1, 1, 9>(batch, mpad, batches, partial, nsplit_out, st);
-    return wide ? launch_gemm<4, 2, 2, 4>(batch, mpad, batches, partial, nsplit_out, st)
-                : launch_gemm<8, 1, 1, 2>(batch, mpad, batches, partial, nsplit_out, st);
+#ifndef NIW_DW_COLOUR_288
+    if (wide == 2) return launch_gemm<4, 2, 1, 5, true, NIW_DW_PF_COLOUR>(batch, mpad, batches, partial, nsplit_out, st);
+#else
+    if (wide == 2) return launch_gemm<4, 1, 1, 9, false, NIW_DW_PF_COLOUR>(batch, mpad, batches, partial, nsplit_out, st);
+#endif
+    return wide ? launch_gemm<4, 2, 2, 4, false, 1>(batch, mpad, batches, partial, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY>(batch, mpad, batches, partial, nsplit_out, st);
 }
 
 }  // namespace
@@ -287,9 +324,7 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
     (void)n_rays; (void)n_samples;
-    // every group's partial tiles live side by side until the single reduction: <= 511 tiles of 256 x 256 (7 x 73 splits),
-    // <= 508 of 256 x 64 (4 x 127), <= 256 of 128 x 288
-    return 511ll * (256 * 256 + 256) + 508ll * (256 * 64 + 256) + 256ll * (128 * 288 + 256);
+    return kPartialTileFloats;
 }
 
 extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
@@ -313,8 +348,10 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     hipStream_t st = (hipStream_t)stream;
     // dW pieces.  Non-transposed: tile rows = dY rows (gradws), tile columns = X slots (save).
     // Transposed (skinny dY: the density row, the 3 colour rows): tile rows = X slots, columns = dY rows.
-    // Four launches per network: [layers 1..7: seven 256 x 256 products] [four 256 x 64 pieces] [the colour layer, 128 x 288]
-    // [one reduction of all twelve partial-tile sets].
+    // Four launches per network: [layers 1..7: seven 256 x 256 products] [four 256 x 64 pieces] [the colour layer, 128 x 288 in a
+    // 128 x 320 tile] [one reduction of all twelve partial-tile sets].  (Tried: the density row as a 257th row of layer 7's
+    // product, formed on the vector ALU from the staged h6 slice -- the skinny launch lost 75 us of 506 at 523 k samples, but the
+    // wide kernel paid 80 us for the mere presence of the code and 50 more for running it.)
     static_assert(kGradY7 == 7 * 256, "dY blocks of layers 0..7 are uniformly strided");
     const Piece wide[7] = {
         // layer, a_row, a_rows, b_row, b_rows, n_off, k_off, transposed, bias, wide
@@ -329,7 +366,7 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0}};                 // colour rows (transposed)
     const Piece colour[1] = {{8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2}};   // feat rows and the 32 view-slot rows are contiguous
     struct Group { const Piece* p; int n, wide, TN, TK; };
-    const Group groups[3] = {{wide, 7, 1, 256, 256}, {skinny, 4, 0, 256, 64}, {colour, 1, 2, 128, 288}};
+    const Group groups[3] = {{wide, 7, 1, 256, 256}, {skinny, 4, 0, 256, 64}, {colour, 1, 2, 128, kColourTK}};
     ReduceBatch rb{};
     int n_pieces = 0, max_tile = 0;
     long long off = 0;
