@@ -63,7 +63,14 @@ struct RowWindow {
     const float* base;   // first row of the window
     int pitch4;          // Mpad * 4 bytes
     int voff4;           // (4*h*Mpad + m) * 4 bytes
-    __device__ __forceinline__ rsrc_t rsrc(int row) const { return make_rsrc(base + (long long)row * (pitch4 >> 2)); }
+    // The window base is wave-uniform by construction; readfirstlane says so to the compiler.  (Where it had kept such a base in
+    // VGPRs -- 66 stores of the training forward -- every use of the descriptor was wrapped in a readfirstlane / compare /
+    // exec-mask "waterfall" loop.)
+    __device__ __forceinline__ rsrc_t rsrc(int row) const {
+        const unsigned long long p = reinterpret_cast<unsigned long long>(base + (long long)row * (pitch4 >> 2));
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return make_rsrc(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo));
+    }
 };
 // row offset inside a 32-row block of accumulator register r (the lane half's +4 rows live in voff4)
 __device__ __forceinline__ constexpr int reg_row(int r) { return (r & 3) + 8 * (r >> 2); }

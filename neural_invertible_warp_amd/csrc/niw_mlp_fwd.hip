@@ -237,11 +237,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // All hot-loop memory traffic uses buffer addressing (see niw_mlp_device.h): host guarantees 128*Mpad < 2^31.
     const PackedWeights pw = packed_weights(a.packed, lane);
     const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)((4ll * h * a.Mpad + m) * 4), hoff = h * 64;
-    auto window = [&](int r) { return RowWindow{SAVE ? a.save + (long long)r * a.Mpad : nullptr, pitch4, voff4}; };
+    // row * Mpad as a 32 x 32 -> 64-bit product: it stays on the scalar ALU.  (As a 64 x 64-bit product of the kernel argument with
+    // the layer loop's row index it was formed by v_mad_u64_u32, the window bases lived in VGPRs and every store that used a
+    // descriptor built from them became a readfirstlane "waterfall" loop: 66 loops in the training kernel.)
+    const unsigned mpad32 = (unsigned)a.Mpad;
+    auto row_off = [&](int r) { return (long long)((unsigned long long)(unsigned)r * (unsigned long long)mpad32); };
+    auto window = [&](int r) { return RowWindow{SAVE ? a.save + row_off(r) : nullptr, pitch4, voff4}; };
     // ReLU sign-mask records of this wave (niw_common.h kSaveMask): record i = output of layer i (0..6), 7 = feat, 8 = hr
     const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     auto mask_rec = [&](int i) {
-        return SAVE ? reinterpret_cast<const char*>(a.save + (long long)kSaveMask * a.Mpad) + (wave_id * kMaskRecords + i) * kMaskRecBytes : nullptr;
+        return SAVE ? reinterpret_cast<const char*>(a.save + row_off(kSaveMask)) + (wave_id * kMaskRecords + i) * kMaskRecBytes : nullptr;
     };
     if (SAVE) {
         const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         float sig_raw = ep.sig_raw;
         if (a.noise != nullptr) sig_raw += a.noise[mc];
         if (h == 0) {
-            if (SAVE) (a.save + (long long)kSaveSigma * a.Mpad)[m] = sig_raw;
+            if (SAVE) (a.save + row_off(kSaveSigma))[m] = sig_raw;
             if (valid) a.sigma[m] = density_act(sig_raw, a.act);
         }
     }
