@@ -81,8 +81,11 @@ static_assert(bias_off(9) + 3 == NIW_NERF_PARAM_FLOATS, "parameter count");
 __host__ __device__ constexpr int fwd_kb(int l) {       // k-blocks of 8 slots
     return l == 0 ? 8 : l == 4 ? 40 : l == 8 ? 36 : l == 9 ? 16 : 32;
 }
+// The two skinny heads are NOT row blocks of the forward: the density row (1 output) and the colour layer 9 (3 outputs)
+// would each cost whole 32-row MFMA blocks (128 + 64 MFMAs of 8448 per 32 samples, 2.3 %) for 4 useful rows; the forward forms
+// them on the vector ALU in the MFMA gaps of layers 7 and 8 from the "head" section of the packed image (below).
 __host__ __device__ constexpr int fwd_nb(int l) {       // 32-row output blocks
-    return l == 7 ? 9 : l == 8 ? 4 : l == 9 ? 1 : 8;
+    return l == 8 ? 4 : l == 9 ? 0 : 8;
 }
 // Backward: dX[k][m] = sum_n W[n][k] dY[n][m]   (A = W^T, B = dY)
 __host__ __device__ constexpr int bwd_rb(int l) {       // reduction k-blocks (over n)
@@ -108,7 +111,10 @@ __host__ __device__ constexpr int bias_pack_off(int l) {     // [nb][h][16] floa
     for (int i = 0; i < l; ++i) o += fwd_nb(i) * 32;
     return o;
 }
-constexpr int kPackedFloats = bias_pack_off(kLayers);
+// head section: density weights in the operand order of layer 7's input registers [half][128], colour-layer weights in the
+// order of layer 8's output registers [channel][half][64], then {density bias, 3 colour biases}
+constexpr int kHeadSigOff = bias_pack_off(kLayers), kHeadRgbOff = kHeadSigOff + 256, kHeadBiasOff = kHeadRgbOff + 384;
+constexpr int kPackedFloats = kHeadBiasOff + 4;
 
 // reference column of an encoding slot (see DESIGN.md "encoding slot order"); -1 = zero pad.
 // slot = 8q + 4h + t; combo g = 2q + h; g == 0 -> raw xyz; else sincos pairs 2(g-1), 2(g-1)+1.

@@ -42,12 +42,24 @@ __device__ __forceinline__ int pack_source(int idx) {
         int row = out_row(l, rb * 8 + 4 * h + t), col = fwd_slot_col(l, ob * 32 + i);
         return (row >= 0 && col >= 0) ? weight_off(l) + row * layer_k(l) + col : -1;
     }
-    int l = 0;
-    while (l + 1 < kLayers && idx >= bias_pack_off(l + 1)) ++l;
-    int local = idx - bias_pack_off(l);
-    int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
-    int row = out_row(l, nb * 32 + acc_row(r, h));
-    return row >= 0 ? bias_off(l) + row : -1;
+    if (idx < kHeadSigOff) {
+        int l = 0;
+        while (l + 1 < kLayers && idx >= bias_pack_off(l + 1)) ++l;
+        int local = idx - bias_pack_off(l);
+        int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
+        int row = out_row(l, nb * 32 + acc_row(r, h));
+        return row >= 0 ? bias_off(l) + row : -1;
+    }
+    if (idx < kHeadRgbOff) {             // density row of layer 7 (reference row 0): register 4q+t of half h <-> input slot 8q+4h+t
+        int local = idx - kHeadSigOff, h = local >> 7, reg = local & 127;
+        return weight_off(7) + 8 * (reg >> 2) + 4 * h + (reg & 3);
+    }
+    if (idx < kHeadBiasOff) {            // colour layer 9: register nb*16+r of half h <-> input row nb*32 + acc_row(r, h)
+        int local = idx - kHeadRgbOff, c = local >> 7, h = (local >> 6) & 1, reg = local & 63;
+        return weight_off(9) + c * 128 + (reg >> 4) * 32 + acc_row(reg & 15, h);
+    }
+    int b = idx - kHeadBiasOff;
+    return b == 0 ? bias_off(7) : bias_off(9) + (b - 1);
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ packed) {
@@ -129,29 +141,62 @@ __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* _
 // layer's operand registers and (training) store it feature-major [row][Mpad].  Row of (nb, r, h) =
 // nb*32 + (r&3) + 8(r>>2) + 4h; the lane-dependent part (4h rows + sample m) is folded into ONE 32-bit
 // element offset `voff`, so every store is scalar-base + vector-offset.
-template <int NBOUT, bool RELU, bool SAVE>
+// HEAD 1 (layer 7): the density row as a dot product of the layer's INPUT registers with the head weights, one FMA per epilogue
+// call (128 calls = the 128 input registers of this lane; the two lane halves hold complementary slots and are added at the end).
+// HEAD 2 (layer 8): the three colour outputs accumulated from the layer's OUTPUT values as they are produced.
+template <int NBOUT, bool RELU, bool SAVE, int HEAD = 0>
 struct FwdEpilogue {
     const PackedWeights& pw;
     int bias_bytes;                      // byte offset of the layer's packed bias ([row block][half][16])
     int hoff;                            // this lane half's offset inside it: h * 64
     float (&out)[16 * NBOUT];
+    const float (&in)[128];              // the layer's input registers (HEAD 1 reads them; others pass them along unused)
     RowWindow win;                       // where the layer's output rows live in the activation workspace
-    float sig_raw;                       // kernel row 256 of layer 7 (row block NBOUT, register 0, half 0)
+    float sig_raw;                       // HEAD 1: this lane half's partial density dot product
     const char* mrec = nullptr;          // this wave's ReLU sign-mask record of the layer (wave-uniform; training only)
     int lane = 0;
     unsigned mbits[4] = {0u, 0u, 0u, 0u};   // this lane's sign bits: dword nb/2, bit 31 - (16*(nb&1) + r)  (pushed LSB-first)
+    float hw[HEAD == 1 ? 2 : 1][16] = {};   // HEAD 1: head weights of the current / next row block's 16 input registers
+    float cw[HEAD == 2 ? 192 : 1] = {};  // HEAD 2: colour-layer weights [channel][64] of this lane half
+    float col[3] = {0.f, 0.f, 0.f};      // HEAD 2: this lane half's partial colour outputs
 
-    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
+    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) {
+        pre_head(nb);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 v = buf_load4(pw.rsrc, hoff, bias_bytes + nb * 128 + g * 16);
             buf[4 * g] = v[0]; buf[4 * g + 1] = v[1]; buf[4 * g + 2] = v[2]; buf[4 * g + 3] = v[3];
         }
     }
+    // head weights: HEAD 1 fetches the 16 weights that epi(nb, .) multiplies, one row block ahead like the biases; HEAD 2 fetches
+    // all 192 at the start of the layer, behind the ring's first fragments (they are first used a whole row block later)
+    __device__ __forceinline__ void pre_head(int nb) {
+        if (HEAD == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = buf_load4(pw.rsrc, hoff * 8, 4 * kHeadSigOff + nb * 64 + g * 16);      // hoff * 8 = h * 512 bytes
+                hw[nb & 1][4 * g] = v[0]; hw[nb & 1][4 * g + 1] = v[1]; hw[nb & 1][4 * g + 2] = v[2]; hw[nb & 1][4 * g + 3] = v[3];
+            }
+        }
+        if (HEAD == 2 && nb == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const f32x4 v = buf_load4(pw.rsrc, hoff * 4, 4 * kHeadRgbOff + c * 512 + g * 16);  // hoff * 4 = h * 256 bytes
+                    cw[c * 64 + 4 * g] = v[0]; cw[c * 64 + 4 * g + 1] = v[1]; cw[c * 64 + 4 * g + 2] = v[2]; cw[c * 64 + 4 * g + 3] = v[3];
+                }
+        }
+    }
     __device__ __forceinline__ void epi(int nb, int r, float a, float p) {
         if (nb < NBOUT) {
             const float v = RELU ? fmaxf(a + p, 0.f) : a + p;
             out[nb * 16 + r] = v;
+            if (HEAD == 1) sig_raw = fmaf(hw[nb & 1][r], in[nb * 16 + r], sig_raw);
+            if (HEAD == 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = fmaf(cw[c * 64 + nb * 16 + r], v, col[c]);
+            }
             if (SAVE) buf_store1(v, win.rsrc(nb * 32), win.voff4, reg_row(r) * win.pitch4);
             if (SAVE && RELU) {
                 // v = max(x, 0): v > 0  <=>  its bit pattern, as a signed integer, is >= 1 (-0.0 and +0.0 give 0): med3 + shift-or
@@ -161,8 +206,6 @@ struct FwdEpilogue {
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{mbits[0], mbits[1], mbits[2], mbits[3]}, make_rsrc(mrec), lane * 16, 0, 0);
                 }
             }
-        } else if (r == 0) {
-            sig_raw = a + p;
         }
     }
 };
@@ -267,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     NIW_STAMP(0);
     // ---- layer 0: 63 -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, window(save_h(1)), 0.f, mask_rec(0), lane};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, act, window(save_h(1)), 0.f, mask_rec(0), lane};
         stream_layer<8, 0, 8, 8>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep);
         advance();
         NIW_STAMP(1);
@@ -275,14 +318,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- layers 1..3
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
         stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, l == 2 ? 12 : -1);
         advance();
         NIW_STAMP(1 + l);
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, window(save_h(5)), 0.f, mask_rec(4), lane};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, act, window(save_h(5)), 0.f, mask_rec(4), lane};
         stream_layer<32, 8, 8, 8>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep);
         advance();
         NIW_STAMP(5);
@@ -290,18 +333,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- layers 5, 6
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
+        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
         stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep);
         advance();
         NIW_STAMP(1 + l);
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(7), hoff, nxt, window(kSaveFeat), 0.f, mask_rec(7), lane};
-        stream_layer<32, 0, 9, 9>(pw, wp + fwd_pack_off(7) / 4, act, none, ep);
+        FwdEpilogue<8, true, SAVE, 1> ep{pw, 4 * bias_pack_off(7), hoff, nxt, act, window(kSaveFeat), 0.f, mask_rec(7), lane};
+        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(7) / 4, act, none, ep);
         advance();
         NIW_STAMP(8);
-        float sig_raw = ep.sig_raw;
+        // density row: the two lane halves hold complementary input slots
+        float sig_raw = ep.sig_raw + __shfl_xor(ep.sig_raw, 32) + buf_load1(pw.rsrc, 0, 4 * kHeadBiasOff);
         if (a.noise != nullptr) sig_raw += a.noise[mc];
         if (h == 0) {
             if (SAVE) (a.save + row_off(kSaveSigma))[m] = sig_raw;
@@ -309,17 +353,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         }
     }
     // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
+    // ---- colour layer 1 (128 -> 3, sigmoid) rides on layer 0's epilogue: three FMAs per hidden value as it is produced
     float hr[64];
     {
-        FwdEpilogue<4, true, SAVE> ep{pw, 4 * bias_pack_off(8), hoff, hr, window(kSaveHr), 0.f, mask_rec(8), lane};
+        FwdEpilogue<4, true, SAVE, 2> ep{pw, 4 * bias_pack_off(8), hoff, hr, act, window(kSaveHr), 0.f, mask_rec(8), lane};
         stream_layer<32, 4, 4, 4>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep);
         NIW_STAMP(9);
-    }
-    // ---- colour layer 1: 128 -> 3, sigmoid
-    {
-        float o[16];
-        FwdEpilogue<1, false, false> ep{pw, 4 * bias_pack_off(9), hoff, o, window(0), 0.f};
-        stream_layer<16, 0, 1, 1>(pw, wp + fwd_pack_off(9) / 4, hr, none, ep);
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = ep.col[c] + __shfl_xor(ep.col[c], 32) + buf_load1(pw.rsrc, 0, 4 * (kHeadBiasOff + 1 + c));
         NIW_STAMP(10);
         if (h == 0 && valid) {
 #pragma unroll
