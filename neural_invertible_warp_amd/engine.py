@@ -101,6 +101,9 @@ class INNTrainer:
         dev = latent.device
         self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets] +
                                           [list(self.warp_mlp.parameters()), [latent]], dev)
+        # the backward kernels write every group's gradient straight into its bucket segment (ops grad_sink): no .grad tensors, no
+        # per-parameter accumulation copies, no gather
+        self._install_grad_sinks()
         flats = self._flats()
         self.m = [torch.zeros_like(f) for f in flats]
         self.v = [torch.zeros_like(f) for f in flats]
@@ -128,6 +131,15 @@ class INNTrainer:
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)
 
+    def _install_grad_sinks(self):
+        """(re-)attach the bucket segments as gradient sinks: cheap, and done every iteration so that a module that was re-created
+        or re-flattened in between cannot train against a stale buffer"""
+        n = len(self.nets)
+        for i, net in enumerate(self.nets):
+            net.grad_sink = self.bucket.segment(i)
+        self.warp_mlp.grad_sink = (self.bucket.segment(n), self.bucket.segment(n + 1))
+        self.bucket.sunk = set(range(n + 2))
+
     def _flats(self):
         """The flat parameter buffers the kernels read, looked up every step: re-flattening (after .to() or an external
         re-assignment of parameter storage) replaces them, and Adam must update the buffer that is actually in use."""
@@ -154,9 +166,7 @@ class INNTrainer:
     # ------------------------------------------------------------------ one iteration
     def _forward_backward(self, var, it):
         opt = self.opt
-        for g in self.bucket.groups:
-            for p in g:
-                p.grad = None
+        self._install_grad_sinks()
         var = self.graph.forward(opt, var, mode="train", iter=it)
         loss = self.summarize_loss(self.graph.compute_loss(opt, var, mode="train"))
         loss.all.backward()

@@ -101,6 +101,7 @@ class NeRF(torch.nn.Module):
         self._state = ops.FieldState(flat)
         self.progress_host = None
         self.band_dev = None            # device tensor [14] of c2f band weights read by the kernel at run time (engine.StepConstants)
+        self.grad_sink = None           # flat buffer that receives this network's parameter gradients instead of .grad (ops.field_mlp)
 
     def tensorflow_init_weights(self, opt, linear, out=None):
         """Glorot-uniform weights and zero biases as the TensorFlow NeRF code initialises them (reference nerf.py:404-414): hidden
@@ -167,7 +168,7 @@ class NeRF(torch.nn.Module):
             noise = torch.randn(depth.shape, device=depth.device) * opt.nerf.density_noise_reg    # nerf.py:428-429
         return ops.field_mlp(self._state, self.field_parameters(), center, ray, depth,
                              self.band_weights(opt, ops.L3D), self.band_weights(opt, ops.LVIEW), opt.arch.density_activ, noise,
-                             band_dev=self.band_dev)
+                             band_dev=self.band_dev, grad_sink=self.grad_sink if mode == "train" else None)
 
     def forward(self, opt, points_3D, ray_unit=None, mode=None):
         """reference nerf.py:416-447: points [...,3], unit view directions [...,3] -> rgb [...,3],

@@ -71,6 +71,7 @@ class DeformNetwork(torch.nn.Module):
             setattr(self, f"lin{b}_c", _zero_linear(d_feature, d_feature))
         self._ea, self._eb = ea, eb
         self.window_dev = None      # device tensor [12] of annealing windows read by the kernels at run time (engine.StepConstants)
+        self.grad_sink = None       # (parameter-gradient buffer, code-gradient buffer) written instead of .grad (ops.warp_prepare)
 
     # ------------------------------------------------------------------ operand preparation
     def _ensure_flat(self):
@@ -106,7 +107,7 @@ class DeformNetwork(torch.nn.Module):
         weight norm (nvp_ndr.py:291-292), code projection (:381) and the latent half of the first layers,
         fused in niw_warp_prep_fwd / _bwd."""
         flat = self._ensure_flat()
-        return ops.warp_prepare(flat, list(self.parameters()), code)
+        return ops.warp_prepare(flat, list(self.parameters()), code, grad_sink=self.grad_sink)
 
     def _anneal(self, alpha_ratio):
         """-> (chan_w[6], index_window[6] | None).  reference_exact: the window multiplies whole points

@@ -257,7 +257,7 @@ class FieldState:
 
 class _FieldMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, state, band3d, bandview, band_dev, activ, noise, grad_mode, center, ray, depth, *params):
+    def forward(ctx, state, band3d, bandview, band_dev, activ, noise, grad_mode, grad_sink, center, ray, depth, *params):
         center, ray, depth = _f32(center, "center"), _f32(ray, "ray"), _f32(depth, "depth_samples")
         n_rays, S = depth.shape
         if center.shape != (n_rays, 3) or ray.shape != (n_rays, 3):
@@ -280,7 +280,7 @@ class _FieldMLP(torch.autograd.Function):
             _lib.call("niw_mlp_fwd", _p(packed), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
                       b3, bv, _p(band_dev), ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
-        ctx.save_ws, ctx.packed = save, packed
+        ctx.save_ws, ctx.packed, ctx.grad_sink = save, packed, grad_sink
         ctx.set_materialize_grads(False)
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(center, ray, depth, rgb)
@@ -297,8 +297,11 @@ class _FieldMLP(torch.autograd.Function):
         d_sigma = torch.zeros(n_rays, S, device=dev) if d_sigma is None else _f32(d_sigma, "d_sigma")
         gradws = torch.empty(GRAD_ROWS * ctx.mpad, device=dev, dtype=torch.float32)
         partial = torch.empty(lib.niw_mlp_bwd_workspace_floats(n_rays, S), device=dev, dtype=torch.float32)
-        d_params = torch.empty(NERF_PARAM_FLOATS, device=dev, dtype=torch.float32)
-        ray_grad = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
+        # grad_sink: the caller's flat gradient buffer in state-dict order (the engine's all-reduce / Adam bucket).  The kernels
+        # overwrite it in place and autograd receives no parameter gradients: no per-parameter accumulation copies, no gather.
+        sink = ctx.grad_sink
+        d_params = sink if sink is not None else torch.empty(NERF_PARAM_FLOATS, device=dev, dtype=torch.float32)
+        ray_grad = ctx.needs_input_grad[8] or ctx.needs_input_grad[9]
         d_both = torch.zeros(2, n_rays, 3, device=dev, dtype=torch.float32) if ray_grad else None     # accumulated by atomics: one fill for both
         d_center, d_ray = (d_both[0], d_both[1]) if ray_grad else (None, None)
         with timed("mlp_bwd_dx", n_rays * S):
@@ -312,25 +315,34 @@ class _FieldMLP(torch.autograd.Function):
         grads, off = [], 0
         for shp in ctx.param_shapes:
             n = math.prod(shp)
-            grads.append(d_params[off:off + n].view(shp))
+            grads.append(None if sink is not None else d_params[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, None, None, d_center, d_ray, None, *grads)
+        return (None, None, None, None, None, None, None, None, d_center, d_ray, None, *grads)
 
 
-def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None, band_dev=None):
+def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None, band_dev=None, grad_sink=None):
     """NeRF.forward_samples on flattened rays: center, ray [N,3], depth [N,S] -> rgb [N,S,3], sigma [N,S].
     band_dev: device tensor [14] = {band3d, bandview}; when given the kernel reads the c2f weights from it at run time.
     One launch takes fewer than 2^24 padded samples (32-bit byte offsets into the workspaces, niw_mlp_device.h); larger
-    batches are split over the rays (autograd sums the parameter gradients of the pieces)."""
+    batches are split over the rays (autograd sums the parameter gradients of the pieces).
+    grad_sink: flat float32 buffer [NERF_PARAM_FLOATS] that receives the parameter gradients of this call IN PLACE of the
+    Parameters' .grad (engine.INNTrainer: a segment of its gradient bucket); one call per backward pass may write it."""
     n_rays, S = depth.shape
     max_rays = ((1 << 24) - 256) // S
+    if grad_sink is not None and (not torch.is_grad_enabled() or not params):
+        grad_sink = None
+    if grad_sink is not None and (grad_sink.numel() != NERF_PARAM_FLOATS or grad_sink.dtype != torch.float32 or not grad_sink.is_contiguous()):
+        raise _lib.NiwError("field_mlp: grad_sink must be a contiguous float32 buffer of NERF_PARAM_FLOATS elements")
     if n_rays <= max_rays:
-        return _FieldMLP.apply(state, band3d, bandview, band_dev, activ, noise, torch.is_grad_enabled(), center, ray, depth, *params)
+        return _FieldMLP.apply(state, band3d, bandview, band_dev, activ, noise, torch.is_grad_enabled(), grad_sink, center, ray, depth, *params)
+    if grad_sink is not None:
+        raise _lib.NiwError("field_mlp: a batch beyond one launch's 2^24 samples is split into pieces whose gradients autograd sums; "
+                            "that cannot be combined with grad_sink")
     rgb, sigma = [], []
     with (state.hold() if not params else contextlib.nullcontext()):
         for a in range(0, n_rays, max_rays):
             b = min(a + max_rays, n_rays)
-            r, s_ = _FieldMLP.apply(state, band3d, bandview, band_dev, activ, None if noise is None else noise[a:b], torch.is_grad_enabled(), center[a:b], ray[a:b],
+            r, s_ = _FieldMLP.apply(state, band3d, bandview, band_dev, activ, None if noise is None else noise[a:b], torch.is_grad_enabled(), None, center[a:b], ray[a:b],
                                     depth[a:b], *params)
             rgb.append(r)
             sigma.append(s_)
@@ -421,7 +433,7 @@ class _WarpPrep(torch.autograd.Function):
     themselves are passed so that autograd routes their gradients."""
 
     @staticmethod
-    def forward(ctx, flat, code, *params):
+    def forward(ctx, flat, code, grad_sink, *params):
         code = _f32(code, "deformation_code")
         B = code.shape[0]
         dev = code.device
@@ -430,7 +442,7 @@ class _WarpPrep(torch.autograd.Function):
         w_head = torch.empty(WARP_WHEAD_FLOATS, device=dev)
         ws = torch.empty(_lib.load().niw_warp_prep_fwd_workspace_floats(B), device=dev)
         _lib.call("niw_warp_prep_fwd", _p(flat), _p(code), B, _p(ws), _p(w_emb), _p(view_b), _p(w_head), _stream())
-        ctx.flat = flat
+        ctx.flat, ctx.grad_sink = flat, grad_sink
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(code)
         ctx.set_materialize_grads(False)
@@ -444,21 +456,28 @@ class _WarpPrep(torch.autograd.Function):
         z = lambda g, n: torch.zeros(n, device=dev) if g is None else _f32(g, "grad")
         d_w_emb, d_view_b, d_w_head = z(d_w_emb, WARP_WEMB_FLOATS), z(d_view_b, B * 3 * 2 * 128), z(d_w_head, WARP_WHEAD_FLOATS)
         scratch = torch.empty(_lib.load().niw_warp_prep_bwd_workspace_floats(B), device=dev)
-        d_params = torch.empty(WARP_PARAM_FLOATS, device=dev)
-        d_code = torch.empty(B, 128, device=dev)
+        sink = ctx.grad_sink                         # (flat parameter gradient, code gradient) buffers of the caller, or None
+        d_params = sink[0] if sink is not None else torch.empty(WARP_PARAM_FLOATS, device=dev)
+        d_code = sink[1] if sink is not None else torch.empty(B, 128, device=dev)
         _lib.call("niw_warp_prep_bwd", _p(ctx.flat), _p(code), B, _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(scratch),
                   _p(d_params), _p(d_code), _stream())
         grads, off = [], 0
         for shp in ctx.param_shapes:
             n = math.prod(shp)
-            grads.append(d_params[off:off + n].view(shp))
+            grads.append(None if sink is not None else d_params[off:off + n].view(shp))
             off += n
-        return (None, d_code, *grads)
+        return (None, None if sink is not None else d_code, None, *grads)
 
 
-def warp_prepare(flat, params, code):
-    """-> (w_emb, view_b, w_head) in the operand layout of niw_warp_fwd."""
-    return _WarpPrep.apply(flat, code, *params)
+def warp_prepare(flat, params, code, grad_sink=None):
+    """-> (w_emb, view_b, w_head) in the operand layout of niw_warp_fwd.  grad_sink: (d_params [WARP_PARAM_FLOATS], d_code [B*128])
+    contiguous float32 buffers that receive the gradients in place of the Parameters' / the code's .grad."""
+    if grad_sink is not None:
+        if not torch.is_grad_enabled():
+            grad_sink = None
+        elif grad_sink[0].numel() != WARP_PARAM_FLOATS or grad_sink[1].numel() != code.numel():
+            raise _lib.NiwError("warp_prepare: grad_sink = (buffer of WARP_PARAM_FLOATS, buffer of code.numel()) float32 elements")
+    return _WarpPrep.apply(flat, code, grad_sink, *params)
 
 
 def warp_points(w_emb, view_b, w_head, pts, chan_w, index_window=None, ps_a=None, ps_b=None, inverse=False, window_dev=None,

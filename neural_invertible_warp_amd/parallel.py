@@ -65,10 +65,13 @@ class GradBucket:
         for s in self.sizes:
             self.offsets.append(self.offsets[-1] + s)
         self.flat = torch.zeros(self.offsets[-1], device=device, dtype=torch.float32)
+        self.sunk = set()      # groups whose backward kernels write their segment directly (ops grad_sink): gather() skips them
 
     def gather(self):
         """One concatenation kernel per group (not one copy per parameter: a step is ~100 tensors)."""
         for i, g in enumerate(self.groups):
+            if i in self.sunk:
+                continue
             seg = self.segment(i)
             if all(p.grad is not None for p in g):
                 torch.cat([p.grad.reshape(-1) for p in g], out=seg)
