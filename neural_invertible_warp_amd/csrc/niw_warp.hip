@@ -412,6 +412,19 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     if (a.d_pts && sub == 0) { a.d_pts[gi * 3] = gx[0]; a.d_pts[gi * 3 + 1] = gx[1]; a.d_pts[gi * 3 + 2] = gx[2]; }
 }
 
+// fixed-order sum over split-M partial tiles with 8 independent accumulators: 8 loads in flight per thread instead of an
+// nsplit-long chain of dependent cold reads (the order does not depend on timing)
+__device__ __forceinline__ float sum_tiles(const float* __restrict__ p, long long stride, int n) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 8 <= n; w += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += p[(long long)(w + k) * stride];
+    }
+    for (; w < n; ++w) s[0] += p[(long long)w * stride];
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
 // reduce the partial tiles of the two GEMM families and scatter into d_w_emb / d_view_b / d_w_head
 __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, const float* __restrict__ p2, int nsplit2,
                                    int n_views, float* __restrict__ d_w_emb, float* __restrict__ d_view_b, float* __restrict__ d_w_head) {
@@ -426,10 +439,7 @@ __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, co
         else if (part == 1 && c >= 32 && c < 32 + kEb) dst = d_w_emb + b * kWembBlock + kHid * kEa + u * kEb + (c - 32);
         else if (c >= 64 && c < 64 + n_views) dst = d_view_b + ((long long)(c - 64) * 3 + b) * 2 * kHid + part * kHid + u;
         if (!dst) return;
-        float s = 0.f;
-        const float* src = p1 + (long long)b * nsplit1 * T1 + idx;
-        for (int w = 0; w < nsplit1; ++w) s += src[(long long)w * T1];
-        *dst = s;
+        *dst = sum_tiles(p1 + (long long)b * nsplit1 * T1 + idx, T1, nsplit1);
     } else if (idx < 256 * 256 + 256 * 64 + 256) {
         const int j = idx - 256 * 256;                          // tile 2: [ha 0..127 | hb 128..255] x [d delta, d theta, d t0, d t1, ...]
         float* dst = nullptr;
@@ -443,10 +453,7 @@ __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, co
             else if (c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + 3 * kHid + (c - 1);
         }
         if (!dst) return;
-        float s = 0.f;
-        const float* src = p2 + (long long)b * nsplit2 * T2 + j;
-        for (int w = 0; w < nsplit2; ++w) s += src[(long long)w * T2];
-        *dst = s;
+        *dst = sum_tiles(p2 + (long long)b * nsplit2 * T2 + j, T2, nsplit2);
     }
 }
 

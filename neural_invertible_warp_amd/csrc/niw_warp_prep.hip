@@ -60,14 +60,23 @@ __global__ __launch_bounds__(256) void warp_prep_code_kernel(const float* __rest
     const float* Wc = P + kOffC + b * kBlkC;
     const float* bc = Wc + kLat * kLat;
     const float c0 = code[v * kLat + lane], c1 = code[v * kLat + 64 + lane];
-    // eight rows at a time: their loads and butterfly sums are independent and overlap (rolled, every row waited ~0.6 us for its
-    // own two loads: 21 us for a [B,128] x [128,128] product)
-#pragma unroll 8
+    // all 64 row loads of the wave are issued before the first butterfly: the kernel is one cold HBM round trip plus arithmetic
+    // (rolled, every row waited for its own two loads: 21 us for a [B,128] x [128,128] product; eight at a time still 21)
+    float w0[32], w1[32];
+#pragma unroll
     for (int jj = 0; jj < 32; ++jj) {
         const int j = wave * 32 + jj;
-        const float s = wave_sum(Wc[j * kLat + lane] * c0 + Wc[j * kLat + 64 + lane] * c1);
-        if (lane == 0) codeb[((long long)b * B + v) * kLat + j] = s + bc[j] + code[v * kLat + j];
+        w0[jj] = Wc[j * kLat + lane];
+        w1[jj] = Wc[j * kLat + 64 + lane];
     }
+    const float extra = lane < 32 ? bc[wave * 32 + lane] + code[v * kLat + wave * 32 + lane] : 0.f;
+    float mine = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) {
+        const float s = wave_sum(w0[jj] * c0 + w1[jj] * c1);
+        mine = lane == jj ? s : mine;
+    }
+    if (lane < 32) codeb[((long long)b * B + v) * kLat + wave * 32 + lane] = mine + extra;     // one coalesced store per wave
 }
 
 struct RowCtx { int b, part, u0; Layer l; };
@@ -89,17 +98,36 @@ __global__ __launch_bounds__(256) void warp_prep_fwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < B * kLat; i += blockDim.x) cb[i] = codeb[(long long)c.b * B * kLat + i];
     __syncthreads();
     float* we = w_emb + c.b * kWembBlock + (c.part ? kHid * kEa : 0);
+    // the four rows of the wave side by side: their loads are in flight together and their butterflies interleave
+    float e[kRowsPerWave], y0[kRowsPerWave], y1[kRowsPerWave], s[kRowsPerWave], bias[kRowsPerWave];
+#pragma unroll
     for (int r = 0; r < kRowsPerWave; ++r) {
-        const int u = c.u0 + r;
-        const float* vrow = P + l.v + u * l.K;
-        const float e = lane < l.E ? vrow[lane] : 0.f;                    // embedding columns
-        const float y0 = vrow[l.E + lane], y1 = vrow[l.E + 64 + lane];   // latent columns
-        const float s = P[l.g + u] / sqrtf(wave_sum(e * e + y0 * y0 + y1 * y1));
-        if (lane < l.E) we[u * l.E + lane] = e * s;
-        const float bias = P[l.bias + u];
-        for (int v = 0; v < B; ++v) {
-            const float d = wave_sum(y0 * cb[v * kLat + lane] + y1 * cb[v * kLat + 64 + lane]);
-            if (lane == 0) view_b[((v * 3 + c.b) * 2 + c.part) * kHid + u] = bias + s * d;
+        const float* vrow = P + l.v + (c.u0 + r) * l.K;
+        e[r] = lane < l.E ? vrow[lane] : 0.f;                             // embedding columns
+        y0[r] = vrow[l.E + lane]; y1[r] = vrow[l.E + 64 + lane];         // latent columns
+        s[r] = P[l.g + c.u0 + r];
+        bias[r] = P[l.bias + c.u0 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        s[r] = s[r] / sqrtf(wave_sum(e[r] * e[r] + y0[r] * y0[r] + y1[r] * y1[r]));
+        if (lane < l.E) we[(c.u0 + r) * l.E + lane] = e[r] * s[r];
+    }
+    for (int v = 0; v < B; ++v) {
+        const float c0 = cb[v * kLat + lane], c1 = cb[v * kLat + 64 + lane];
+        float d[kRowsPerWave];
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) d[r] = y0[r] * c0 + y1[r] * c1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int r = 0; r < kRowsPerWave; ++r) d[r] += __shfl_xor(d[r], o);
+        }
+        if (lane < kRowsPerWave) {
+            float dv = d[0], sv = s[0], bv = bias[0];
+#pragma unroll
+            for (int r = 1; r < kRowsPerWave; ++r) { dv = lane == r ? d[r] : dv; sv = lane == r ? s[r] : sv; bv = lane == r ? bias[r] : bv; }
+            view_b[((v * 3 + c.b) * 2 + c.part) * kHid + c.u0 + lane] = bv + sv * dv;
         }
     }
     if (blockIdx.x % kGroups == 0) {
