@@ -18,8 +18,8 @@ import sys
 
 SAMPLES = 4086 * 192
 NAMES = {"mlp_fwd_kernel<true>": "mlp_fwd_train", "mlp_fwd_kernel<false>": "mlp_fwd", "mlp_bwd_dx_kernel": "mlp_bwd_dx",
-         "dw_gemm_kernel<4, 2, 2, 4>": "mlp_bwd_dw_wide_batch", "dw_gemm_kernel<8, 1, 1, 2>": "mlp_bwd_dw_skinny_batch",
-         "dw_gemm_kernel<4, 1, 1, 9>": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce"}
+         "dw_gemm_kernel<4, 2, 2, 4": "mlp_bwd_dw_wide_batch", "dw_gemm_kernel<8, 1, 1, 2": "mlp_bwd_dw_skinny_batch",
+         "dw_gemm_kernel<4, 2, 1, 5": "mlp_bwd_dw_colour", "dw_gemm_kernel<4, 1, 1, 9": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce"}
 ALGO = {  # algorithmic bytes per sample: reads / writes of the workspaces, fp32
     "mlp_fwd_train": dict(read=16.0, write=9384.0), "mlp_fwd": dict(read=16.0, write=16.0),
     # dX reads: 288 B sign masks + 384 B parked skip / view gradients (written and read back) + 384 B saved encodings (for d point,
@@ -31,7 +31,7 @@ ALGO = {  # algorithmic bytes per sample: reads / writes o
 def per_kernel(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(mlp_fwd_kernel<\w+>|mlp_bwd_dx_kernel|dw_gemm_kernel<[\d, ]+>|dw_reduce_kernel)", r["Kernel_Name"])
+        m = re.search(r"(mlp_fwd_kernel<\w+>|mlp_bwd_dx_kernel|dw_gemm_kernel<\d, \d, \d, \d|dw_reduce_kernel)", r["Kernel_Name"])
         if m:
             agg[NAMES[m.group(1)]][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[NAMES[m.group(1)]]["dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
