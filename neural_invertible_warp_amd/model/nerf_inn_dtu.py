@@ -59,8 +59,13 @@ class Graph(nerf_inn_llff.Graph):
         loss = nerf.Graph.compute_loss(self, opt, var, mode=mode)
         if mode != "train" or opt.loss_weight.global_alignment is None:
             return loss
-        warped = torch.cat([var.grid_local, var.center_local], dim=1)
-        initial = torch.cat([var.grid_init, var.center_init], dim=1)
+        from .nvp import nvp_ndr
+        stack = nvp_ndr.stacked_points(var.grid_local, var.center_local)
+        if stack is not None:
+            warped, initial = stack
+        else:
+            warped = torch.cat([var.grid_local, var.center_local], dim=1)
+            initial = torch.cat([var.grid_init, var.center_init], dim=1)
         views = warped.shape[0]
         sharded = getattr(opt, "ray_shard", None) is not None
         elements = 3 * views * (2 * (opt.nerf.rand_rays // views) if sharded else warped.shape[1])

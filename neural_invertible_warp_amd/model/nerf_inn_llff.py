@@ -104,12 +104,17 @@ class Graph(nerf.Graph):
             return loss
         from .. import parallel
         backend = ALIGN_BACKEND or ops
-        unwarped = torch.cat([var.grid_cam, var.center_cam], dim=1)
-        warped = torch.cat([var.grid_3D, var.center], dim=1)
+        from .nvp import nvp_ndr
+        stack = nvp_ndr.stacked_points(var.grid_3D, var.center)
+        if stack is not None:                 # the warp's own [grid ; centre] input and output of this step
+            warped, unwarped = stack
+        else:
+            unwarped = torch.cat([var.grid_cam, var.center_cam], dim=1)
+            warped = torch.cat([var.grid_3D, var.center], dim=1)
         sharded = getattr(opt, "ray_shard", None) is not None
         poses = backend.rigid_registration(warped, unwarped, reduce_moments=parallel.all_reduce_sum_ if sharded else None)
         if hasattr(self, "global_rigid"):
-            self.global_rigid.weight.data = poses.reshape(-1, 12).clone()          # what pose evaluation reads (:570)
+            self.global_rigid.weight.data = poses.reshape(-1, 12)                  # what pose evaluation reads (:570); `poses` is a fresh tensor
         views, local_points = warped.shape[0], warped.shape[1]
         # mean over the GLOBAL batch: under sharding every rank contributes its share and the gradient all-reduce sums them
         elements = 3 * views * (2 * (opt.nerf.rand_rays // views) if sharded else local_points)

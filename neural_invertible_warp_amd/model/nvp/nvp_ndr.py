@@ -159,10 +159,46 @@ def embedding_anneal_ratio(opt, it):
     return 1
 
 
+class _SplitRays(torch.autograd.Function):
+    """warped [B,2n,3] = [grid ; centre] -> (ray = grid - centre, centre, grid), contiguous.  One node instead of two slices and a
+    subtraction: its backward writes d warped = [d grid + d ray ; d centre - d ray] in two launches, where autograd's own chain was
+    a negation, two zero-filled [B,2n,3] buffers, two slice copies and their sum."""
+
+    @staticmethod
+    def forward(ctx, warped, n):
+        grid, center = warped[:, :n].contiguous(), warped[:, n:].contiguous()
+        ctx.n, ctx.shape = n, warped.shape
+        ctx.set_materialize_grads(False)
+        return grid - center, center, grid
+
+    @staticmethod
+    def backward(ctx, d_ray, d_center, d_grid):
+        n = ctx.n
+        out = torch.empty(ctx.shape, device=(d_ray if d_ray is not None else d_center if d_center is not None else d_grid).device)
+        g, c = out[:, :n], out[:, n:]
+        if d_ray is None:
+            g.zero_() if d_grid is None else g.copy_(d_grid)
+            c.zero_() if d_center is None else c.copy_(d_center)
+        else:
+            g.copy_(d_ray) if d_grid is None else torch.add(d_grid, d_ray, out=g)
+            torch.neg(d_ray, out=c) if d_center is None else torch.sub(d_center, d_ray, out=c)
+        return out, None
+
+
 def warp_grid_and_center(net, code, grid, center, alpha_ratio):
     """grid, center [B,R,3] (gradient-free inputs) -> (ray, center_3D, grid_3D), each [B,R,3]: the points of every view go
-    through the view's warp as ONE batch [grid ; centre], rays are re-formed from the warped end points."""
+    through the view's warp as ONE batch [grid ; centre], rays are re-formed from the warped end points.  The two stacked
+    [B,2R,3] tensors (the warp's input and output) ride along on the results for the alignment loss (`stacked_points`)."""
     n = grid.shape[1]
-    warped = net.forward(code, torch.cat([grid, center], dim=1).unsqueeze(2), alpha_ratio=alpha_ratio).squeeze(2)
-    grid_3D, center_3D = warped[:, :n], warped[:, n:]
-    return grid_3D - center_3D, center_3D, grid_3D
+    stacked_in = torch.cat([grid, center], dim=1)
+    warped = net.forward(code, stacked_in.unsqueeze(2), alpha_ratio=alpha_ratio).squeeze(2)
+    ray, center_3D, grid_3D = _SplitRays.apply(warped, n)
+    grid_3D._niw_stack = center_3D._niw_stack = (warped, stacked_in)
+    return ray, center_3D, grid_3D
+
+
+def stacked_points(grid_3D, center_3D):
+    """-> (warped [B,2R,3], un-warped [B,2R,3]) when `grid_3D` / `center_3D` are the pair `warp_grid_and_center` returned (the
+    alignment loss then needs no concatenation, and its gradient no slice scatter), else None"""
+    st = getattr(grid_3D, "_niw_stack", None)
+    return st if st is not None and getattr(center_3D, "_niw_stack", None) is st else None
