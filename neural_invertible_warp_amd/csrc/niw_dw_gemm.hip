@@ -264,7 +264,10 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     const int steps_total = (int)(mpad / 32);
     // at least 8 slices per workgroup; one workgroup per CU, or -- for a batch of equal pieces -- just under two
     // full rounds of the 256 CUs in total (fewer, longer workgroups: less partial-tile traffic for the reducer)
-    const int cap = batches >= 4 ? (2 * 256 - 1) / batches : 256;
+    // (two rounds balance better at >= 130 k samples; below, one round halves the partial-tile traffic that then dominates:
+    // measured 216 / 350 / 601 us against 252 / 374 / 629 us for the whole dW group at 16 k / 32 k / 65 k samples)
+    const int rounds = steps_total <= 4096 ? 1 : 2;
+    const int cap = batches >= 4 ? (rounds * 256 - 1) / batches : 256;
     // short reductions (the warp's few thousand points, a 1/8 ray shard): fewer slices per workgroup, down to 2, until the
     // launch has a workgroup for every CU -- the partial tile each workgroup writes (<= 256 KB) is the price of a split
     int min_slices = 8;

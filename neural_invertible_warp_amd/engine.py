@@ -29,24 +29,26 @@ class StepConstants:
 
     def __init__(self, device, n_groups):
         assert self.HYPER + 8 * n_groups <= self.DRAW
-        self.host = torch.zeros(self.BYTES, dtype=torch.uint8)
-        if torch.device(device).type == "cuda":
-            self.host = self.host.pin_memory()
+        self.n_groups = n_groups
+        self.pinned = torch.device(device).type == "cuda"
         self.dev = torch.zeros(self.BYTES, dtype=torch.uint8, device=device)
         f = lambda buf, off, n: buf[off:off + 4 * n].view(torch.float32)
         self.band, self.window = f(self.dev, self.BAND, 14), f(self.dev, self.WINDOW, 12)
         self.hyper = [f(self.dev, self.HYPER + 8 * g, 2) for g in range(n_groups)]
         self.draw = self.dev[self.DRAW:self.DRAW + 8].view(torch.int64)
-        self._h = dict(band=f(self.host, self.BAND, 14), window=f(self.host, self.WINDOW, 12),
-                       hyper=f(self.host, self.HYPER, 2 * n_groups), draw=self.host[self.DRAW:self.DRAW + 8].view(torch.int64))
 
     def upload(self, band, window, hyper, draw):
-        h = self._h
-        h["band"].copy_(torch.tensor(band, dtype=torch.float32))
-        h["window"].copy_(torch.tensor(window, dtype=torch.float32))
-        h["hyper"].copy_(torch.tensor(hyper, dtype=torch.float32).reshape(-1))
-        h["draw"].fill_(int(draw))
-        self.dev.copy_(self.host, non_blocking=True)            # stream-ordered in front of the kernels that read it
+        """A FRESH pinned staging buffer per step: the copy is asynchronous and the host runs many steps ahead of the device, so a
+        single staging buffer would be overwritten with a later step's scalars before the device has read it (round 2: un-synchronised
+        graph replays trained with the pixel draws, bands and learning rates of steps still to come).  The caching host allocator
+        recycles a block only after the copy that read it has completed."""
+        host = torch.empty(self.BYTES, dtype=torch.uint8, pin_memory=self.pinned)
+        f = lambda off, n: host[off:off + 4 * n].view(torch.float32)
+        f(self.BAND, 14).copy_(torch.tensor(band, dtype=torch.float32))
+        f(self.WINDOW, 12).copy_(torch.tensor(window, dtype=torch.float32))
+        f(self.HYPER, 2 * self.n_groups).copy_(torch.tensor(hyper, dtype=torch.float32).reshape(-1))
+        host[self.DRAW:self.DRAW + 8].view(torch.int64).fill_(int(draw))
+        self.dev.copy_(host, non_blocking=True)                 # stream-ordered in front of the kernels that read it
 
 
 def _sched_gamma(lr0, lr_end, sched, max_iter, what):

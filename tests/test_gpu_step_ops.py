@@ -213,3 +213,29 @@ def test_hip_graph_replay_equals_eager_at_full_batch_size(cfg):
     for a, b in zip(runs[False], runs[True]):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * max(abs(a[k]), 1e-4), (k, a[k], b[k])
+
+
+def test_hip_graph_replays_without_host_synchronisation_use_their_own_step_constants():
+    """Round 2 regression: the per-step scalars (pixel-draw number, c2f bands, warp windows, Adam step sizes) reach the device by an
+    asynchronous copy from pinned memory.  With ONE staging buffer the host, running ahead, overwrote it before the device had read
+    it, and un-synchronised replays trained with the constants of later steps.  Twelve replays issued back to back (no read-back in
+    between) must leave the same parameters as twelve synchronised ones."""
+    from neural_invertible_warp_amd import configs, engine
+
+    def run(sync):
+        opt = configs.cfg3_barf_inn_llff(device=DEV)
+        opt.nerf.sample_stratified = False
+        opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = 5 * 40, 32, 40
+        opt.inn.real_nvp.max_pe_iter = 20
+        var0 = engine.synthetic_scene(opt, 5)
+        tr = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=11, hip_graph=True)
+        for _ in range(12):
+            tr.train_iteration(type(var0)(var0))
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return tr
+
+    a, b = run(True), run(False)
+    for fa, fb in zip(a._flats(), b._flats()):
+        assert (fa - fb).abs().max() <= 5e-4 * fa.abs().max()
