@@ -46,7 +46,8 @@ const char* niw_last_error_string(void);
 #define NIW_VENC_SLOTS 32         /* 3 + 6*L_view = 27 */
 #define NIW_NERF_PARAM_FLOATS 530052   /* 527,872 weights + 2,180 biases, state-dict order */
 
-/* rows of the saved-activation / saved-gradient workspaces (feature-major, [rows][Mpad]) */
+/* rows of the saved-activation / saved-gradient workspaces: NIW_*_ROWS * Mpad floats each, opaque to the caller (internally a
+ * feature-major [rows][Mpad] matrix stored as a quad-row image [rows / 4][Mpad][4]; the raw-density row and the mask records plain) */
 #define NIW_SAVE_ROWS 2346        /* enc 64 | h1..h7 7*256 | feat 256 | venc 32 | hr 128 | sigma_raw 1 | rgb(unused) 1 | ReLU bit masks 72 (9 KiB per 32 samples) */
 #define NIW_GRAD_ROWS 2336        /* dY0..dY6 7*256 | dY7 288 (row 256 = d sigma_raw) | dYrgb0 128 | dYrgb1 32 | stash 64+32 */
 

@@ -61,7 +61,10 @@ struct GemmBatch {
 // SKIP: 32 x 32 output blocks that lie entirely beyond the valid rows of either operand (the 3-row colour head in a 64-column
 // tile, the 128-row operand in a 256-row tile, the 288 of 320 columns of the colour layer) issue no MFMAs -- the skinny
 // launches are bound by their padded matrix work, not by HBM.
-template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF>
+// QUAD: the operands are quad-row images [row / 4][samples][4] (the field MLP's workspaces, niw_mlp_device.h): a 16-byte load is
+// four rows of one sample and goes to four LDS rows as ds_write_b32 (32 lanes = 32 consecutive samples of a row: conflict free).
+// Plain [row][samples] operands (the warp's factor rows) take the b128 path.
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD>
 __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
                                                                float* __restrict__ partial) {
     const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
@@ -84,9 +87,13 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
     const int nsteps = min(steps_per_wg, steps_total - step0);
     // descriptors end after the last valid row: loads of rows beyond return zero (host: rows * row_stride * 4 < 2^31)
     const int strideA4 = (int)opA.row_stride * 4, strideB4 = (int)opB.row_stride * 4;
-    const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, min(opA.rows, TN) * strideA4, 0x00020000);
-    const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, min(opB.rows, TK) * strideB4, 0x00020000);
-    const int voffA = (tid >> 3) * strideA4 + (tid & 7) * 16, voffB = (tid >> 3) * strideB4 + (tid & 7) * 16;
+    const int cutA = QUAD ? (min(opA.rows, TN) + 3) / 4 * 4 : min(opA.rows, TN), cutB = QUAD ? (min(opB.rows, TK) + 3) / 4 * 4 : min(opB.rows, TK);
+    const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, cutA * strideA4, 0x00020000);
+    const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, cutB * strideB4, 0x00020000);
+    // plain: thread -> (row tid / 8 of the group, 16-byte column tid % 8);  quad: thread -> (quad tid / 32 of the group, sample tid % 32)
+    const int voffA = QUAD ? (tid >> 5) * 4 * strideA4 + (tid & 31) * 16 : (tid >> 3) * strideA4 + (tid & 7) * 16;
+    const int voffB = QUAD ? (tid >> 5) * 4 * strideB4 + (tid & 31) * 16 : (tid >> 3) * strideB4 + (tid & 7) * 16;
+    constexpr int STEP_BYTES = QUAD ? 512 : 128;          // one 32-sample step along a row (plain) / along a quad (quad-row image)
 
     f32x16 acc[NBW][KBW];
 #pragma unroll
@@ -107,14 +114,20 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
         for (int k = 0; k < LOADS; ++k) {
             const bool isA = k * GROUP < TN;
             const int g = isA ? k * GROUP : k * GROUP - TN;                 // first row of this load's row group
-            stage[slot][k] = isA ? buf_load4(rsA, voffA, step * 128 + g * strideA4) : buf_load4(rsB, voffB, step * 128 + g * strideB4);
+            stage[slot][k] = isA ? buf_load4(rsA, voffA, step * STEP_BYTES + g * strideA4) : buf_load4(rsB, voffB, step * STEP_BYTES + g * strideB4);
         }
     };
     auto lstore = [&](int buf, int slot) {
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
-            const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<f32x4*>(lds + (buf * ROWS + row) * kLdsStride + c4 * 4) = stage[slot][k];
+            if (QUAD) {
+                const int row0 = k * GROUP + (tid >> 5) * 4, m = tid & 31;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[(buf * ROWS + row0 + j) * kLdsStride + m] = stage[slot][k][j];
+            } else {
+                const int idx = tid + k * NT, row = idx >> 3, c4 = idx & 7;
+                *reinterpret_cast<f32x4*>(lds + (buf * ROWS + row) * kLdsStride + c4 * 4) = stage[slot][k];
+            }
         }
     };
     // one 32-sample step; `slot` = s % PF at compile time (the register stage that receives step s + PF, after step s + 1 has
@@ -258,7 +271,7 @@ struct Piece {
     int n_off, k_off, transposed, bias, wide;   // wide: 256x256 tile, else 256x64
 };
 
-template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF>
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD>
 int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
@@ -277,7 +290,7 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     const int per = (steps_total + nsplit - 1) / nsplit;
     nsplit = (steps_total + per - 1) / per;
     const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
-    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW, SKIP, PF>;
+    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW, SKIP, PF, QUAD>;
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM")) return rc;
     for (int b = 0; b < batches; ++b) {
@@ -296,15 +309,16 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     return NIW_OK;
 }
 
+template <bool QUAD>
 int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
 #ifndef NIW_DW_COLOUR_288
-    if (wide == 2) return launch_gemm<4, 2, 1, 5, true, NIW_DW_PF_COLOUR>(batch, mpad, batches, partial, nsplit_out, st);
+    if (wide == 2) return launch_gemm<4, 2, 1, 5, true, NIW_DW_PF_COLOUR, QUAD>(batch, mpad, batches, partial, nsplit_out, st);
 #else
-    if (wide == 2) return launch_gemm<4, 1, 1, 9, false, NIW_DW_PF_COLOUR>(batch, mpad, batches, partial, nsplit_out, st);
+    if (wide == 2) return launch_gemm<4, 1, 1, 9, false, NIW_DW_PF_COLOUR, QUAD>(batch, mpad, batches, partial, nsplit_out, st);
 #endif
-    return wide ? launch_gemm<4, 2, 2, 4, false, 1>(batch, mpad, batches, partial, nsplit_out, st)
-                : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY>(batch, mpad, batches, partial, nsplit_out, st);
+    return wide ? launch_gemm<4, 2, 2, 4, false, 1, QUAD>(batch, mpad, batches, partial, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY, QUAD>(batch, mpad, batches, partial, nsplit_out, st);
 }
 
 }  // namespace
@@ -322,7 +336,7 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
         gb.B[b] = B; gb.B[b].p = B.p + (long long)b * B.batch_stride;
         gb.bias_side[b] = bias_side;
     }
-    return launch_shape(wide, gb, mpad, batches, partial, nsplit_out, st);
+    return launch_shape<false>(wide, gb, mpad, batches, partial, nsplit_out, st);
 }
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
@@ -356,6 +370,8 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     // product, formed on the vector ALU from the staged h6 slice -- the skinny launch lost 75 us of 506 at 523 k samples, but the
     // wide kernel paid 80 us for the mere presence of the code and 50 more for running it.)
     static_assert(kGradY7 == 7 * 256, "dY blocks of layers 0..7 are uniformly strided");
+    static_assert(kSaveEnc % 4 == 0 && kSaveH1 % 4 == 0 && kSaveFeat % 4 == 0 && kSaveHr % 4 == 0 && kGradY7 % 4 == 0 &&
+                  kGradRgb0 % 4 == 0 && kGradRgb1 % 4 == 0 && kSaveSigma % 4 == 0, "operands of the quad-row images start on whole quads");
     const Piece wide[7] = {
         // layer, a_row, a_rows, b_row, b_rows, n_off, k_off, transposed, bias, wide
         {1, 1 * 256, 256, save_h(1), 256, 0, 0, 0, 1, 1}, {2, 2 * 256, 256, save_h(2), 256, 0, 0, 0, 1, 1},
@@ -377,13 +393,13 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         GemmBatch gb{};
         for (int b = 0; b < g.n; ++b) {
             const Piece& p = g.p[b];
-            // workspaces are plain feature-major [row][Mpad]: row pitch Mpad, a single sample block
+            // workspaces are quad-row images of the feature-major [row][Mpad] matrix (every operand starts on a multiple of 4 rows)
             gb.A[b] = NiwGemmOperand{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad};
             gb.B[b] = NiwGemmOperand{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad};
             gb.bias_side[b] = p.bias ? (p.transposed ? 2 : 1) : 0;
         }
         int nsplit = 0;
-        int rc = launch_shape(g.wide, gb, mpad, g.n, partial + off, &nsplit, st);
+        int rc = launch_shape<true>(g.wide, gb, mpad, g.n, partial + off, &nsplit, st);
         if (rc != NIW_OK) return rc;
         const long long tile = (long long)g.TN * g.TK + 256;
         for (int b = 0; b < g.n; ++b) {

@@ -45,15 +45,18 @@ struct MaskEpilogue {
         const int keep = (int)(mk[nb >> 1] << (16 * (nb & 1) + r)) >> 31;
         const float g = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
         out[nb * 16 + r] = g;
-        buf_store1(g, grad.rsrc(nb * 32), grad.voff4, reg_row(r) * grad.pitch4);
+        if ((r & 3) == 3)                  // four consecutive rows of this lane: one 16-byte store (quad-row image, niw_mlp_device.h)
+            buf_store4(out[nb * 16 + r - 3], out[nb * 16 + r - 2], out[nb * 16 + r - 1], g, grad.rsrc(nb * 32), grad.voff4, 8 * (r >> 2) * grad.pitch4);
     }
 };
 // park a result in the workspace (d encoding slots of the skip connection, d view-encoding slots)
 struct StashEpilogue {
     RowWindow win;
+    float q[3] = {0.f, 0.f, 0.f};
     __device__ __forceinline__ void pre(int, float (&)[16]) const {}
     __device__ __forceinline__ void epi(int nb, int r, float a, float) {
-        buf_store1(a, win.rsrc(nb * 32), win.voff4, reg_row(r) * win.pitch4);
+        if ((r & 3) == 3) buf_store4(q[0], q[1], q[2], a, win.rsrc(nb * 32), win.voff4, 8 * (r >> 2) * win.pitch4);
+        else q[r & 3] = a;
     }
 };
 // add a parked result and keep the sum in registers
@@ -64,7 +67,10 @@ struct AddStashEpilogue {
     __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
         const rsrc_t r0 = win.rsrc(nb * 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[r] = buf_load1(r0, win.voff4, reg_row(r) * win.pitch4);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = buf_load4(r0, win.voff4, 8 * q * win.pitch4);
+            buf[4 * q] = v[0]; buf[4 * q + 1] = v[1]; buf[4 * q + 2] = v[2]; buf[4 * q + 3] = v[3];
+        }
     }
     __device__ __forceinline__ void epi(int nb, int r, float a, float p) { out[nb * 16 + r] = a + p; }
 };
@@ -73,13 +79,12 @@ struct AddStashEpilogue {
 // d/dx [w sin(f x)] = f * (w cos(f x)),  d/dx [w cos(f x)] = -f * (w sin(f x)).
 template <int L, int NQ>
 __device__ __forceinline__ void enc_backward(const float (&de)[4 * NQ], const float* __restrict__ enc_row0, long long mpad,
-                                             unsigned voff, int h, float (&dp)[3]) {
+                                             unsigned qoff, int h, float (&dp)[3]) {
     dp[0] = dp[1] = dp[2] = 0.f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        float e[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) e[t] = (enc_row0 + (long long)(8 * q + t) * mpad)[voff];
+        // rows 8q + 4h + {0..3} of this sample: one quad of the saved encoding (qoff = h*Mpad + m)
+        const f32x4 e = reinterpret_cast<const f32x4*>(enc_row0 + (long long)(8 * q) * mpad)[qoff];
         if (q == 0) {
             // half 0: raw coordinates; half 1: pairs 0 and 1
 #pragma unroll
@@ -112,11 +117,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
     const bool valid = m < a.M;
     const long long mc = valid ? m : a.M - 1;
-    const unsigned voff = (unsigned)(4ll * h * a.Mpad + m);     // plain feature-major [row][Mpad] (see niw_mlp_fwd.hip)
+    const unsigned qoff = (unsigned)((long long)h * a.Mpad + m);     // quad index of rows R + 4h .. R + 4h + 3 (R % 8 == 0) of this sample,
+                                                                      // counted from row R of a quad-row image (niw_mlp_device.h)
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
     const long long P = a.Mpad;
     const PackedWeights pw = packed_weights(a.packed, lane);
-    const int pitch4 = (int)(P * 4), voff4 = (int)((4ll * h * P + m) * 4);
+    const int pitch4 = (int)(P * 4), voff4 = (int)(((long long)h * P + m) * 16);
     auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };     // gradient rows
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
     // ReLU sign-mask records of this wave: record i = output of layer i (0..6), 7 = feat, 8 = hr; each is loaded while
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
             g = a.d_rgb[mc * 3 + t] * o * (1.f - o);
         }
         dy9[t] = g;
-        (a.grad + (long long)(kGradRgb1 + t) * P)[voff] = g;     // rows 4h+t of the 8-row slot block
     }
+    reinterpret_cast<f32x4*>(a.grad + (long long)kGradRgb1 * P)[qoff] = f32x4{dy9[0], dy9[1], dy9[2], dy9[3]};   // rows 4h + t of the 8-row slot block
     float dyr[64];
     {
         MaskEpilogue<4> ep{mk_cur, dyr, gwin(kGradRgb0)};
@@ -167,13 +173,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     {
         float g = 0.f;
         if (h == 0 && valid) {
-            const float raw = (a.save + (long long)kSaveSigma * P)[voff];
+            const float raw = (a.save + (long long)kSaveSigma * P)[m];          // plain row (h == 0 here)
             const float dact = a.act == NIW_ACT_RELU ? (raw > 0.f ? 1.f : 0.f) : (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
             g = a.d_sigma[mc] * dact;
         }
         dsig[0] = g;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) (a.grad + (long long)(kGradY7 + 256 + t) * P)[voff] = dsig[t];
+        reinterpret_cast<f32x4*>(a.grad + (long long)(kGradY7 + 256) * P)[qoff] = f32x4{dsig[0], dsig[1], dsig[2], dsig[3]};
     }
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
@@ -216,12 +221,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         AddStashEpilogue<2> ep{gwin(kGradStashEnc), denc};
         stream_layer<32, 0, 2, 2>(pw, wp + bwd_pack_off(0) / 4, dy, none, ep);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dvenc[r] = (a.grad + (long long)(kGradStashVenc + 8 * (r >> 2) + (r & 3)) * P)[voff];
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(a.grad + (long long)(kGradStashVenc + 8 * q) * P)[qoff];
+            dvenc[4 * q] = v[0]; dvenc[4 * q + 1] = v[1]; dvenc[4 * q + 2] = v[2]; dvenc[4 * q + 3] = v[3];
+        }
     }
     // ---- encodings -> point / direction -> ray gradients
     float dp[3], du[3];
-    enc_backward<NIW_L3D, 8>(denc, a.save + (long long)kSaveEnc * P, P, voff, h, dp);
-    enc_backward<NIW_LVIEW, 4>(dvenc, a.save + (long long)kSaveVenc * P, P, voff, h, du);
+    enc_backward<NIW_L3D, 8>(denc, a.save + (long long)kSaveEnc * P, P, qoff, h, dp);
+    enc_backward<NIW_LVIEW, 4>(dvenc, a.save + (long long)kSaveVenc * P, P, qoff, h, du);
     const long long ri = mc / a.S;
     const float d = a.depth[mc];
     const float rx = a.ray[ri * 3], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];

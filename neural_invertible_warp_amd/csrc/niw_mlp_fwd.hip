@@ -197,7 +197,8 @@ struct FwdEpilogue {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) col[c] = fmaf(cw[c * 64 + nb * 16 + r], v, col[c]);
             }
-            if (SAVE) buf_store1(v, win.rsrc(nb * 32), win.voff4, reg_row(r) * win.pitch4);
+            if (SAVE && (r & 3) == 3)      // registers r-3 .. r = four consecutive rows: one 16-byte store into the quad-row image
+                buf_store4(out[nb * 16 + r - 3], out[nb * 16 + r - 2], out[nb * 16 + r - 1], v, win.rsrc(nb * 32), win.voff4, 8 * (r >> 2) * win.pitch4);
             if (SAVE && RELU) {
                 // v = max(x, 0): v > 0  <=>  its bit pattern, as a signed integer, is >= 1 (-0.0 and +0.0 give 0): med3 + shift-or
                 mbits[nb >> 1] = (mbits[nb >> 1] << 1) | (unsigned)min(max(__builtin_bit_cast(int, v), 0), 1);
@@ -275,11 +276,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         encode_slots<NIW_L3D, 8>(p, w3, h, enc);
         encode_slots<NIW_LVIEW, 4>(u, wv, h, venc);
     }
-    // Workspace layout: plain feature-major [row][Mpad].  (A blocked [128-sample block][row][128]
-    // image was measured 10-14 % slower for this kernel and the dX chain on MI355X.)
+    // Workspace layout: the quad-row image of niw_mlp_device.h ([row / 4][Mpad][4]; rows >= kSaveSigma -- raw density and the mask
+    // records -- stay plain [row][Mpad]).  (A blocked [128-sample block][row][128] image was measured 10-14 % slower for this
+    // kernel and the dX chain on MI355X.)
     // All hot-loop memory traffic uses buffer addressing (see niw_mlp_device.h): host guarantees 128*Mpad < 2^31.
     const PackedWeights pw = packed_weights(a.packed, lane);
-    const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)((4ll * h * a.Mpad + m) * 4), hoff = h * 64;
+    const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)(((long long)h * a.Mpad + m) * 16), hoff = h * 64;
     // row * Mpad as a 32 x 32 -> 64-bit product: it stays on the scalar ALU.  (As a 64 x 64-bit product of the kernel argument with
     // the layer loop's row index it was formed by v_mad_u64_u32, the window bases lived in VGPRs and every store that used a
     // descriptor built from them became a readfirstlane "waterfall" loop: 66 loops in the training kernel.)
@@ -294,9 +296,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     if (SAVE) {
         const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) buf_store1(enc[i], we.rsrc(0), voff4, (8 * (i >> 2) + (i & 3)) * pitch4);
+        for (int q = 0; q < 8; ++q) buf_store4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3], we.rsrc(0), voff4, 8 * q * pitch4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) buf_store1(venc[i], wv.rsrc(0), voff4, (8 * (i >> 2) + (i & 3)) * pitch4);
+        for (int q = 0; q < 4; ++q) buf_store4(venc[4 * q], venc[4 * q + 1], venc[4 * q + 2], venc[4 * q + 3], wv.rsrc(0), voff4, 8 * q * pitch4);
     }
 
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
