@@ -41,7 +41,10 @@ struct MaskEpilogue {
     RowWindow grad;                      // where dY of the producing layer is stored
     __device__ __forceinline__ void pre(int, float (&)[16]) const {}
     __device__ __forceinline__ void epi(int nb, int r, float a, float) {
-        // sign-extended 1-bit field = all-ones / zero: the ReLU mask is one AND on the float's bits
+        // sign-extended 1-bit field = all-ones / zero: the ReLU mask is one AND on the float's bits.  (hipcc turns this into
+        // test-bit / compare / select, three VALU instructions; any inline asm that would pin v_bfe_i32 + v_and_b32 -- even an
+        // empty one that only hides the field's origin -- stops the unrolling of the layer loops and sends the register arrays
+        // to scratch.)
         const int keep = (int)(mk[nb >> 1] << (16 * (nb & 1) + r)) >> 31;
         const float g = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
         out[nb * 16 + r] = g;

@@ -200,8 +200,9 @@ struct FwdEpilogue {
             if (SAVE && (r & 3) == 3)      // registers r-3 .. r = four consecutive rows: one 16-byte store into the quad-row image
                 buf_store4(out[nb * 16 + r - 3], out[nb * 16 + r - 2], out[nb * 16 + r - 1], v, win.rsrc(nb * 32), win.voff4, 8 * (r >> 2) * win.pitch4);
             if (SAVE && RELU) {
-                // v = max(x, 0): v > 0  <=>  its bit pattern, as a signed integer, is >= 1 (-0.0 and +0.0 give 0): med3 + shift-or
-                mbits[nb >> 1] = (mbits[nb >> 1] << 1) | (unsigned)min(max(__builtin_bit_cast(int, v), 0), 1);
+                // v = max(x, 0) is +0.0 or positive: v > 0  <=>  bits(v) + 0x7fffffff carries into bit 31.  One add and one
+                // funnel shift per value ((mbits << 1) | bit 31 of the sum); the compare / select / or form cost three.
+                mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v) + 0x7fffffffu, 31);
                 if (nb == NBOUT - 1 && r == 15) {     // one coalesced 16 B/lane store per layer: the wave's 1 KiB record
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{mbits[0], mbits[1], mbits[2], mbits[3]}, make_rsrc(mrec), lane * 16, 0, 0);
