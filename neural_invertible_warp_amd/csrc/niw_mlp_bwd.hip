@@ -39,6 +39,8 @@ struct MaskEpilogue {
     u32x4 mk;                            // this lane's 16 bytes of the mask record of the layer input
     float (&out)[16 * NBOUT];
     RowWindow grad;                      // where dY of the producing layer is stored
+    static constexpr bool kAccInit = false;
+    __device__ __forceinline__ void acc_init(int, f32x16&) const {}
     __device__ __forceinline__ void pre(int, float (&)[16]) const {}
     __device__ __forceinline__ void epi(int nb, int r, float a, float) {
         // sign-extended 1-bit field = all-ones / zero: the ReLU mask is one AND on the float's bits.  (hipcc turns this into
@@ -56,6 +58,8 @@ struct MaskEpilogue {
 struct StashEpilogue {
     RowWindow win;
     float q[3] = {0.f, 0.f, 0.f};
+    static constexpr bool kAccInit = false;
+    __device__ __forceinline__ void acc_init(int, f32x16&) const {}
     __device__ __forceinline__ void pre(int, float (&)[16]) const {}
     __device__ __forceinline__ void epi(int nb, int r, float a, float) {
         if ((r & 3) == 3) buf_store4(q[0], q[1], q[2], a, win.rsrc(nb * 32), win.voff4, 8 * (r >> 2) * win.pitch4);
@@ -67,6 +71,8 @@ template <int NBOUT>
 struct AddStashEpilogue {
     RowWindow win;
     float (&out)[16 * NBOUT];
+    static constexpr bool kAccInit = false;
+    __device__ __forceinline__ void acc_init(int, f32x16&) const {}
     __device__ __forceinline__ void pre(int nb, float (&buf)[16]) const {
         const rsrc_t r0 = win.rsrc(nb * 32);
 #pragma unroll

@@ -99,8 +99,9 @@ __device__ __forceinline__ constexpr int reg_row(int r) { return (r & 3) + 8 * (
 //
 //   * weight fragments: one coalesced 16 B/lane buffer load per (row block, k-block), a ring keeps
 //     NIW_RING_DEPTH loads (>= 2048 MFMA cycles) in flight; the ring index is compile-time;
-//   * per-block epilogue inputs (bias / saved activation for the ReLU mask) are fetched by
-//     `pol.pre(nb, buf)` at the START of block nb and consumed during block nb+1;
+//   * per-block epilogue inputs (parked gradients, head weights) are fetched by `pol.pre(nb, buf)` at the START of block nb
+//     and consumed during block nb+1; a policy with kAccInit also supplies the block's INITIAL accumulator (the forward: the
+//     bias fragment, fetched one block ahead by `pol.acc_init`), so that its epilogue has no add;
 //   * `pol.epi(nb, r, acc_r, pre_r)` handles accumulator register r of block nb.
 //
 // `wp` points at the first fragment of the (sub-range of the) layer inside the packed image;
@@ -125,6 +126,11 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
     constexpr int G0 = GAPS >= 32 ? 8 : 0;                 // first gap used by the epilogue
     constexpr int GS = (GAPS - G0) / 16 > 0 ? (GAPS - G0) / 16 : 1;
     const int base = (int)(reinterpret_cast<const char*>(wp) - reinterpret_cast<const char*>(pw.base));   // wave-uniform
+    // Policies with kAccInit start every block's accumulation from a 16-register value of their own (the forward: the bias
+    // fragment, fetched one block ahead) instead of a literal zero, which takes the bias add out of the epilogue.
+    constexpr bool INIT = Policy::kAccInit;
+    f32x16 cin[2];
+    if (INIT) pol.acc_init(0, cin[0]);
     f32x4 ring[D];
 #pragma unroll
     for (int i = 0; i < D; ++i)
@@ -135,6 +141,7 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
     for (int nb = 0; nb < NB; ++nb) {
         f32x16& cur = acc[nb & 1];
         pol.pre(nb, pre[nb & 1]);
+        if (INIT && nb + 1 < NB) pol.acc_init(nb + 1, cin[(nb + 1) & 1]);
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
             const int i = nb * KB + q;
@@ -144,7 +151,7 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
             for (int t = 0; t < 4; ++t) {
                 const float bv = q < KB1 ? b1[4 * (q < KB1 ? q : 0) + t] : b2[4 * (q >= KB1 ? q - KB1 : 0) + t];
                 // the block's first MFMA takes a literal zero accumulator (no 16-register clear, no VALU->MFMA hazard)
-                cur = mfma32(a[t], bv, (q == 0 && t == 0) ? f32x16{0.f} : cur);
+                cur = mfma32(a[t], bv, (q == 0 && t == 0) ? (INIT ? cin[nb & 1] : f32x16{0.f}) : cur);
                 const int gap = 4 * q + t;
                 if (nb > 0 && gap >= G0 && (gap - G0) % GS == 0 && (gap - G0) / GS < 16) {
                     const int r = (gap - G0) / GS;

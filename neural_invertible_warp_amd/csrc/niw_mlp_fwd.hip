@@ -160,14 +160,16 @@ struct FwdEpilogue {
     float cw[HEAD == 2 ? 192 : 1] = {};  // HEAD 2: colour-layer weights [channel][64] of this lane half
     float col[3] = {0.f, 0.f, 0.f};      // HEAD 2: this lane half's partial colour outputs
 
-    __device__ __forceinline__ void pre(int nb, float (&buf)[16]) {
-        pre_head(nb);
+    static constexpr bool kAccInit = true;
+    // the block's accumulation starts from its bias fragment (this lane half's 16 rows)
+    __device__ __forceinline__ void acc_init(int nb, f32x16& c) const {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 v = buf_load4(pw.rsrc, hoff, bias_bytes + nb * 128 + g * 16);
-            buf[4 * g] = v[0]; buf[4 * g + 1] = v[1]; buf[4 * g + 2] = v[2]; buf[4 * g + 3] = v[3];
+            c[4 * g] = v[0]; c[4 * g + 1] = v[1]; c[4 * g + 2] = v[2]; c[4 * g + 3] = v[3];
         }
     }
+    __device__ __forceinline__ void pre(int nb, float (&)[16]) { pre_head(nb); }
     // head weights: HEAD 1 fetches the 16 weights that epi(nb, .) multiplies, one row block ahead like the biases; HEAD 2 fetches
     // all 192 at the start of the layer, behind the ring's first fragments (they are first used a whole row block later)
     __device__ __forceinline__ void pre_head(int nb) {
@@ -190,7 +192,10 @@ struct FwdEpilogue {
     }
     __device__ __forceinline__ void epi(int nb, int r, float a, float p) {
         if (nb < NBOUT) {
-            const float v = RELU ? fmaxf(a + p, 0.f) : a + p;
+            // the bias is already in the accumulator (acc_init).  ReLU as a signed-integer max of the bit pattern: positive floats
+            // are positive integers, negative ones (and -0.0) negative -- one v_max_i32, where fmaxf on a raw MFMA result costs a
+            // second v_max_f32 to canonicalise its operand
+            const float v = RELU ? __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), 0)) : a;
             out[nb * 16 + r] = v;
             if (HEAD == 1) sig_raw = fmaf(hw[nb & 1][r], in[nb * 16 + r], sig_raw);
             if (HEAD == 2) {
