@@ -224,7 +224,8 @@ int niw_render_fwd(const niw_render_desc* desc, float* workspace, float* rgb, fl
  * with the launch; window_dev: DEVICE array of 12 floats {chan_w[6], index_window[6]} or NULL -- when given it overrides the
  * two host arrays and is read by the kernel at run time (HIP-graph replays), with use_index_window saying whether the index
  * window applies; pt_scale_a / pt_scale_b [n_pts] (device) optional additional per-point scales.
- * inverse != 0 evaluates .inverse.  xin_save [n_views,n_pts,3,3] (block inputs) may be NULL. */
+ * inverse != 0 evaluates .inverse.  xin_save [n_views,n_pts,3,3] or NULL: the input point of each of the three coupling blocks,
+ * kept for niw_warp_bwd (forward warp only), which otherwise recomputes them -- a third of its work. */
 #define NIW_WARP_WEMB_FLOATS (3 * (128 * 26 + 128 * 13))
 #define NIW_WARP_WHEAD_FLOATS (3 * (128 + 1 + 3 * 128 + 3))
 #define NIW_WARP_PARAM_FLOATS 165900    /* DeformNetwork parameters, flat in parameters() order (see niw_warp_prep.hip) */
@@ -245,16 +246,17 @@ int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const
 int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
                  int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
                  int use_index_window, const float* pt_scale_a, const float* pt_scale_b, int inverse, float* out,
-                 niw_stream_t stream);
+                 float* xin_save, niw_stream_t stream);
 
 /* Backward of the forward warp.  d_out [n_views,n_pts,3] -> d_w_emb, d_view_b, d_w_head (same
  * shapes as the inputs, overwritten) and d_pts [n_views,n_pts,3] (may be NULL).
+ * xin_saved: what niw_warp_fwd wrote to xin_save for the same operands, or NULL.
  * workspace: niw_warp_bwd_workspace_floats() floats of scratch.  n_views <= 64 per call. */
 int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts);
 int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
                  int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
-                 int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* d_out, float* workspace,
-                 float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts, niw_stream_t stream);
+                 int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* xin_saved, const float* d_out,
+                 float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts, niw_stream_t stream);
 
 /* ------------------------------------------------------------------ global-alignment loss
  * Rotation of the rigid registration (Kabsch with reflection fix) behind `roma.rigid_points_registration`

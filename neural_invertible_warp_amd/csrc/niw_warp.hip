@@ -152,6 +152,8 @@ struct WarpArgs {
     const float* ps_a;
     const float* ps_b;
     const float* d_out;
+    const float* xin_in;    // backward: the block inputs the forward saved ([views][points][3 blocks][3]) or NULL (recompute them)
+    float* xin_save;        // forward: where to save them, or NULL
     float* out;
     float* d_pts;
     float* ws;
@@ -296,7 +298,13 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
     float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
     const float psa = (a.ps_a ? a.ps_a[p] : 1.f) * index_scale(win, p, 2), psb = (a.ps_b ? a.ps_b[p] : 1.f) * index_scale(win, p, 1);
     if (!a.inverse) {
-        for (int b = 0; b < 3; ++b) block_fwd(lw, lh, lv, win.cw, psa, psb, b, sub, x);
+        for (int b = 0; b < 3; ++b) {
+            if (a.xin_save && sub == 0) {
+                float* xs = a.xin_save + gi * 9 + b * 3;
+                xs[0] = x[0]; xs[1] = x[1]; xs[2] = x[2];
+            }
+            block_fwd(lw, lh, lv, win.cw, psa, psb, b, sub, x);
+        }
     } else {
         for (int b = 2; b >= 0; --b) block_inv(lw, lh, lv, win.cw, psa, psb, b, sub, x);
     }
@@ -319,7 +327,12 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
     const long long gi = (long long)view * a.n_pts + p;
     const float psa = (a.ps_a ? a.ps_a[p] : 1.f) * index_scale(win, p, 2), psb = (a.ps_b ? a.ps_b[p] : 1.f) * index_scale(win, p, 1);
     float xin[3][3];
-    {
+    if (a.xin_in) {              // the forward pass of this step left every block's input behind: a third of this kernel's work
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xin[b][c] = a.xin_in[gi * 9 + b * 3 + c];
+    } else {
         float x[3] = {a.pts[gi * 3], a.pts[gi * 3 + 1], a.pts[gi * 3 + 2]};
         for (int b = 0; b < 3; ++b) {
             xin[b][0] = x[0]; xin[b][1] = x[1]; xin[b][2] = x[2];
@@ -490,12 +503,13 @@ static_assert(NIW_WARP_WEMB_FLOATS == 3 * kWembBlock && NIW_WARP_WHEAD_FLOATS ==
 extern "C" int niw_warp_fwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
                             int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
                             int use_index_window, const float* pt_scale_a, const float* pt_scale_b, int inverse, float* out,
-                            niw_stream_t stream) {
+                            float* xin_save, niw_stream_t stream) {
     WarpArgs a{};
     int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b);
     if (rc != NIW_OK) return rc;
     NIW_REQUIRE(out, "niw_warp_fwd: null output");
-    a.out = out; a.inverse = inverse;
+    NIW_REQUIRE(!(inverse && xin_save), "niw_warp_fwd: block inputs are saved for the forward warp only");
+    a.out = out; a.inverse = inverse; a.xin_save = xin_save;
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc2 = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(warp_fwd_kernel), kWarpLds, attr_set, "niw_warp_fwd")) return rc2;
     warp_fwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, (hipStream_t)stream>>>(a);
@@ -510,8 +524,9 @@ extern "C" int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts) {
 
 extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
                             int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
-                            int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* d_out,
-                            float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts, niw_stream_t stream) {
+                            int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* xin_saved,
+                            const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                            niw_stream_t stream) {
     WarpArgs a{};
     int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b);
     if (rc != NIW_OK) return rc;
@@ -519,7 +534,7 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
     NIW_REQUIRE(n_views <= 64, "niw_warp_bwd: at most 64 views per call (got %d)", n_views);
     hipStream_t st = (hipStream_t)stream;
     const long long ppad = warp_ppad(n_views, n_pts);
-    a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad;
+    a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad; a.xin_in = xin_saved;
     // padded columns of the factor rows must be zero
     if (const int n_pad = (int)(ppad - (long long)n_views * n_pts)) {
         const long long n_rows = 3ll * kRowsPerBlock;

@@ -401,8 +401,11 @@ class _Warp(torch.autograd.Function):
         out = torch.empty_like(pts)
         cw = _farr(chan_w, 6)
         iw = None if index_window is None else _farr(index_window, 6)       # by value with the launch: no H2D copy, no sync
+        # training: the kernel leaves every coupling block's input point behind for the backward (which otherwise recomputes them)
+        xin = torch.empty(B, P, 3, 3, device=pts.device, dtype=torch.float32) if (not inverse and any(ctx.needs_input_grad)) else None
         _lib.call("niw_warp_fwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, cw, iw, _p(window_dev), 1 if use_index_window else 0,
-                  _p(ps_a), _p(ps_b), 1 if inverse else 0, _p(out), _stream())
+                  _p(ps_a), _p(ps_b), 1 if inverse else 0, _p(out), _p(xin), _stream())
+        ctx.xin = xin
         ctx.save_for_backward(w_emb, view_b, w_head, pts, ps_a, ps_b)
         ctx.cw, ctx.iw, ctx.inverse, ctx.window_dev, ctx.use_iw = cw, iw, inverse, window_dev, use_index_window
         return out
@@ -418,7 +421,8 @@ class _Warp(torch.autograd.Function):
         d_w_emb, d_view_b, d_w_head = torch.empty_like(w_emb), torch.empty_like(view_b), torch.empty_like(w_head)   # fully overwritten
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[3] else None
         _lib.call("niw_warp_bwd", _p(w_emb), _p(view_b), _p(w_head), _p(pts), B, P, ctx.cw, ctx.iw, _p(ctx.window_dev), 1 if ctx.use_iw else 0,
-                  _p(ps_a), _p(ps_b), _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
+                  _p(ps_a), _p(ps_b), _p(ctx.xin), _p(_f32(d_out, "d_out")), _p(ws), _p(d_w_emb), _p(d_view_b), _p(d_w_head), _p(d_pts), _stream())
+        ctx.xin = None
         return d_w_emb, d_view_b, d_w_head, d_pts, None, None, None, None, None, None, None
 
 

@@ -84,7 +84,7 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
         "niw_raygen": (None, None, None, 0, 2, 4, 8, 8, 0, None, None, None),
         "niw_draw_ray_idx": (64, 8, 1, 1, None, 0, 1, None, None),
         "niw_convert_ndc": (None, None, None, 2, 4, 1.0, None, None, None),
-        "niw_warp_fwd": (None,) * 4 + (2, 4, None, None, None, 0, None, None, 0, None, None),
+        "niw_warp_fwd": (None,) * 4 + (2, 4, None, None, None, 0, None, None, 0, None, None, None),
         "niw_warp_prep_fwd": (None, None, 2, None, None, None, None, None),
         "niw_warp_prep_bwd": (None, None, 2) + (None,) * 7,
         "niw_mse_fwd_bwd": (None, None, None, 2, 4, 64, 1.0, 1.0, None, None, None),

@@ -17,13 +17,13 @@ def main():
         view_b = torch.randn(B, 3, 2, 128, device=dev) * 0.1
         w_head = torch.randn(ops.WARP_WHEAD_FLOATS, device=dev) * 0.02
         pts = torch.randn(B, N, 3, device=dev)
-        out = torch.empty_like(pts); d_out = torch.randn_like(pts)
+        out = torch.empty_like(pts); d_out = torch.randn_like(pts); xin = torch.empty(B, N, 3, 3, device=dev)
         ws = torch.empty(_lib.load().niw_warp_bwd_workspace_floats(B, N), device=dev)
         dwe, dvb, dwh, dp = torch.empty_like(w_emb), torch.empty_like(view_b), torch.empty_like(w_head), torch.empty_like(pts)
         cw = ops._farr([1.0] * 6, 6); iw = ops._farr([0.3, 0.6, 1, 1, 1, 1], 6)
         st = ops._stream()
-        fwd = lambda: _lib.call("niw_warp_fwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, 0, P(out), st)
-        bwd = lambda: _lib.call("niw_warp_bwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, P(d_out), P(ws), P(dwe), P(dvb), P(dwh), P(dp), st)
+        fwd = lambda: _lib.call("niw_warp_fwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, 0, P(out), P(xin), st)
+        bwd = lambda: _lib.call("niw_warp_bwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, P(xin), P(d_out), P(ws), P(dwe), P(dvb), P(dwh), P(dp), st)
         def timed(fn):
             fn(); fn()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
