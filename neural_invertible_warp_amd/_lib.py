@@ -81,6 +81,9 @@ def load():
             f"{LIB_PATH} not found: the HIP library is not built. Run "
             "`make -C neural_invertible_warp_amd/csrc` (or __graft_entry__.build()). "
             "There is no CPU fallback for the render path.")
+    # PyTorch-ROCm ships its own HIP runtime; it must be the one this process uses.  Loaded first, libniw_hip.so would pull in the
+    # system copy instead, and kernels launched through it find "no ROCm-capable device" once torch has initialised the other one.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
