@@ -304,3 +304,100 @@ def test_photometric_loss_kernel_direct():
     # full image, no ray_idx (val / eval)
     full = torch.rand(B, H * W, 3, generator=gen)
     close(ops.mse_gather(g(full), g(image)), ((full - image.view(B, 3, H * W).permute(0, 2, 1)) ** 2).mean(), atol=1e-7, rtol=1e-6)
+
+
+def test_gradient_sinks_receive_what_autograd_would_accumulate():
+    """engine.INNTrainer hands the kernels its bucket segments as gradient sinks (ops.field_mlp / ops.warp_prepare grad_sink): the
+    sink must hold exactly the gradients that the Parameters' .grad would have received, and .grad must stay None."""
+    from neural_invertible_warp_amd import ops
+    p, names, state, params = _field(3)
+    gen = torch.Generator().manual_seed(5)
+    N, S = 37, 24
+    center, ray = g(torch.randn(N, 3, generator=gen) * 0.1), g(torch.randn(N, 3, generator=gen))
+    depth = g((torch.rand(N, S, generator=gen).sort(dim=1).values * 4 + 0.5).contiguous())
+    w_rgb, w_sig = g(torch.randn(N, S, 3, generator=gen)), g(torch.randn(N, S, generator=gen))
+
+    def run(sink):
+        for q in params:
+            q.grad = None
+        rgb, sigma = ops.field_mlp(state, params, center, ray, depth, [1.0] * 10, [1.0] * 4, "softplus", grad_sink=sink)
+        ((rgb * w_rgb).sum() + (sigma * w_sig).sum()).backward()
+
+    run(None)
+    ref = torch.cat([q.grad.reshape(-1) for q in params])
+    sink = torch.full((ops.NERF_PARAM_FLOATS,), float("nan"), device=DEV)
+    run(sink)
+    assert all(q.grad is None for q in params)
+    assert torch.equal(sink, ref)                      # same kernels, same order: bit-identical
+
+    # the warp's operand preparation: parameters and the per-view codes
+    net, wp = _warp_net()
+    code = g(O.make_latent(5, 4)).requires_grad_(True)
+    pts = g(torch.randn(4, 19, 1, 3, generator=gen))
+
+    def run_warp(sink):
+        net.grad_sink = sink
+        for q in net.parameters():
+            q.grad = None
+        code.grad = None
+        net.forward(code, pts, alpha_ratio=0.6).square().sum().backward()
+        net.grad_sink = None
+
+    run_warp(None)
+    ref_p, ref_c = torch.cat([q.grad.reshape(-1) for q in net.parameters()]), code.grad.reshape(-1).clone()
+    sp, sc = torch.full_like(ref_p, float("nan")), torch.full_like(ref_c, float("nan"))
+    run_warp((sp, sc))
+    assert all(q.grad is None for q in net.parameters()) and code.grad is None
+    assert torch.equal(sp, ref_p) and torch.equal(sc, ref_c)
+
+
+def test_warp_backward_from_saved_block_inputs_equals_recomputation():
+    """niw_warp_fwd may leave every coupling block's input point behind (xin_save) so that niw_warp_bwd skips its own forward sweep:
+    both routes must give the same gradients bit for bit, and the saved points must be the block inputs (block 0: the points)."""
+    import ctypes
+    from neural_invertible_warp_amd import _lib, ops
+    B, N = 3, 41
+    gen = torch.Generator().manual_seed(9)
+    w_emb = g(torch.randn(ops.WARP_WEMB_FLOATS, generator=gen) * 0.1)
+    view_b = g(torch.randn(B, 3, 2, 128, generator=gen) * 0.1)
+    w_head = g(torch.randn(ops.WARP_WHEAD_FLOATS, generator=gen) * 0.02)
+    pts, d_out = g(torch.randn(B, N, 3, generator=gen)), g(torch.randn(B, N, 3, generator=gen))
+    out, xin = torch.empty_like(pts), torch.empty(B, N, 3, 3, device=DEV)
+    P, st = ops._p, ops._stream()
+    cw, iw = ops._farr([1.0, 1.0, 0.7, 0.2, 0.0, 0.0], 6), ops._farr([0.3, 0.6, 1, 1, 1, 1], 6)
+    _lib.call("niw_warp_fwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, 0, P(out), P(xin), st)
+    assert torch.equal(xin[:, :, 0], pts)
+    ws = torch.empty(_lib.load().niw_warp_bwd_workspace_floats(B, N), device=DEV)
+
+    def bwd(saved):
+        o = [torch.empty_like(w_emb), torch.empty_like(view_b), torch.empty_like(w_head), torch.empty_like(pts)]
+        _lib.call("niw_warp_bwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, P(saved), P(d_out), P(ws),
+                  P(o[0]), P(o[1]), P(o[2]), P(o[3]), st)
+        return o
+
+    # (not bit for bit: the forward kernel and the backward kernel's own sweep are separately compiled copies of the same
+    # arithmetic, and the 2^5 pi band of the embedding amplifies a last-bit difference of a block input; measured 1e-6)
+    for a, b in zip(bwd(None), bwd(xin)):
+        assert (a - b).abs().max() <= 1e-5 * a.abs().max(), float((a - b).abs().max() / a.abs().max())
+    # the inverse warp has no saved inputs
+    with pytest.raises(_lib.NiwError):
+        _lib.call("niw_warp_fwd", P(w_emb), P(view_b), P(w_head), P(pts), B, N, cw, iw, None, 0, None, None, 1, P(out), P(xin), st)
+
+
+def test_ray_split_node_matches_plain_autograd():
+    """nvp_ndr._SplitRays ([grid ; centre] -> ray, centre, grid in one node) against slices and a subtraction, with every
+    combination of used / unused outputs"""
+    from neural_invertible_warp_amd.model.nvp.nvp_ndr import _SplitRays
+    gen = torch.Generator().manual_seed(2)
+    w = g(torch.randn(3, 10, 3, generator=gen))
+    gs = [g(torch.randn(3, 5, 3, generator=gen)) for _ in range(3)]
+    for use in ((1, 1, 1), (1, 0, 0), (0, 1, 1), (1, 1, 0), (0, 0, 1)):
+        a = w.clone().requires_grad_(True)
+        outs = _SplitRays.apply(a, 5)
+        sum((o * gi).sum() for o, gi, u in zip(outs, gs, use) if u).backward()
+        b = w.clone().requires_grad_(True)
+        ref = (b[:, :5] - b[:, 5:], b[:, 5:], b[:, :5])
+        sum((o * gi).sum() for o, gi, u in zip(ref, gs, use) if u).backward()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+        close(a.grad, b.grad, atol=1e-7)
