@@ -109,9 +109,25 @@ __device__ __forceinline__ constexpr int reg_row(int r) { return (r & 3) + 8 * (
 // sched_barrier(0) after every k-block pins this order (hipcc otherwise sinks the loads next to
 // their uses and gathers the epilogue at the end).
 // ---------------------------------------------------------------------------------------------
-template <int KB1, int KB2, int NB, int STRIDE, typename Policy>
+// What one layer hands to the next (NIW_LAYER_CARRY): the first NIW_RING_DEPTH weight fragments of the next layer, requested
+// while the current layer's last k-blocks run, and the bias fragment of its first row block -- otherwise every layer starts with
+// one exposed L2 round trip for each.
+struct LayerCarry {
+    f32x4 ring[NIW_RING_DEPTH];
+    f32x16 cin0;
+    bool valid = false;      // compile-time known at every use (the kernel bodies are straight-line)
+};
+struct NextLayer {
+    int w_base = -1;         // byte offset of the next layer's first fragment in the packed image (-1: nothing to prefetch)
+    int w_stride = 0;        // bytes between its consecutive k-blocks of row block 0 (STRIDE * 1024)
+    int bias_bytes = -1;     // byte offset of its packed bias (policies with kAccInit), or -1
+    int hoff = 0;
+};
+
+template <int KB1, int KB2, int NB, int STRIDE, typename Policy, bool CARRY_IN = false, bool CARRY_OUT = false>
 __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x4* __restrict__ wp, const float (&b1)[4 * KB1],
-                                             const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol, int stamp_base = -1) {
+                                             const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol, LayerCarry* carry = nullptr,
+                                             NextLayer next = NextLayer{}, int stamp_base = -1) {
 #ifdef NIW_STAMPS
 #define NIW_STAMP_L(k)                                                                                                     \
     do {                                                                                                                   \
@@ -129,12 +145,19 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
     // Policies with kAccInit start every block's accumulation from a 16-register value of their own (the forward: the bias
     // fragment, fetched one block ahead) instead of a literal zero, which takes the bias add out of the epilogue.
     constexpr bool INIT = Policy::kAccInit;
+    static_assert(!(CARRY_IN || CARRY_OUT) || (N % D == 0 && KB >= D), "carried rings need whole ring turns per layer");
     f32x16 cin[2];
-    if (INIT) pol.acc_init(0, cin[0]);
     f32x4 ring[D];
+    if (CARRY_IN) {
+        if (INIT) cin[0] = carry->cin0;
 #pragma unroll
-    for (int i = 0; i < D; ++i)
-        if (i < N) ring[i] = buf_load4(pw.rsrc, pw.lane16, base + ((i % KB) * STRIDE + i / KB) * 1024);
+        for (int i = 0; i < D; ++i) ring[i] = carry->ring[i];
+    } else {
+        if (INIT) pol.acc_init(0, cin[0]);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i < N) ring[i] = buf_load4(pw.rsrc, pw.lane16, base + ((i % KB) * STRIDE + i / KB) * 1024);
+    }
     f32x16 acc[2];
     float pre[2][16];
 #pragma unroll
@@ -142,11 +165,19 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
         f32x16& cur = acc[nb & 1];
         pol.pre(nb, pre[nb & 1]);
         if (INIT && nb + 1 < NB) pol.acc_init(nb + 1, cin[(nb + 1) & 1]);
+        if (CARRY_OUT && INIT && nb == NB - 1) {           // the next layer's first bias fragment
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = buf_load4(pw.rsrc, next.hoff, next.bias_bytes + g * 16);
+                carry->cin0[4 * g] = v[0]; carry->cin0[4 * g + 1] = v[1]; carry->cin0[4 * g + 2] = v[2]; carry->cin0[4 * g + 3] = v[3];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
             const int i = nb * KB + q;
             const f32x4 a = ring[i % D];
             if (i + D < N) ring[i % D] = buf_load4(pw.rsrc, pw.lane16, base + (((i + D) % KB) * STRIDE + (i + D) / KB) * 1024);
+            else if (CARRY_OUT) ring[i % D] = buf_load4(pw.rsrc, pw.lane16, next.w_base + (i + D - N) * next.w_stride);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float bv = q < KB1 ? b1[4 * (q < KB1 ? q : 0) + t] : b2[4 * (q >= KB1 ? q - KB1 : 0) + t];
@@ -169,6 +200,10 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
     NIW_STAMP_L(1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) pol.epi(NB - 1, r, acc[(NB - 1) & 1][r], pre[(NB - 1) & 1][r]);
+    if (CARRY_OUT) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) carry->ring[i] = ring[i];
+    }
     NIW_STAMP_L(2);
 }
 

@@ -315,11 +315,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         for (int i = 0; i < 128; ++i) act[i] = nxt[i];
     };
 
+    // every layer leaves the next one its first weight fragments and its first bias fragment (niw_mlp_device.h LayerCarry)
+    LayerCarry carry;
+    constexpr int kLayerBytes = 32 * 8 * 1024;       // one 256 -> 256 layer of the packed image
     NIW_STAMP(0);
     // ---- layer 0: 63 -> 256
     {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, act, window(save_h(1)), 0.f, mask_rec(0), lane};
-        stream_layer<8, 0, 8, 8>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep);
+        stream_layer<8, 0, 8, 8, decltype(ep), false, true>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep, &carry,
+                                                             NextLayer{4 * fwd_pack_off(1), 8 * 1024, 4 * bias_pack_off(1), hoff});
         advance();
         NIW_STAMP(1);
     }
@@ -327,14 +331,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
-        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, l == 2 ? 12 : -1);
+        const NextLayer nx = l < 3 ? NextLayer{4 * fwd_pack_off(1) + l * kLayerBytes, 8 * 1024, 4 * (bias_pack_off(1) + l * 256), hoff}
+                                   : NextLayer{4 * fwd_pack_off(4), 8 * 1024, 4 * bias_pack_off(4), hoff};
+        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, &carry, nx,
+                                                             l == 2 ? 12 : -1);
         advance();
         NIW_STAMP(1 + l);
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, act, window(save_h(5)), 0.f, mask_rec(4), lane};
-        stream_layer<32, 8, 8, 8>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep);
+        stream_layer<32, 8, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep, &carry,
+                                                             NextLayer{4 * fwd_pack_off(5), 8 * 1024, 4 * bias_pack_off(5), hoff});
         advance();
         NIW_STAMP(5);
     }
@@ -342,14 +350,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
-        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep);
+        const NextLayer nx = l < 6 ? NextLayer{4 * fwd_pack_off(5) + kLayerBytes, 8 * 1024, 4 * (bias_pack_off(5) + 256), hoff}
+                                   : NextLayer{4 * fwd_pack_off(7), 8 * 1024, 4 * bias_pack_off(7), hoff};
+        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep, &carry, nx);
         advance();
         NIW_STAMP(1 + l);
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
         FwdEpilogue<8, true, SAVE, 1> ep{pw, 4 * bias_pack_off(7), hoff, nxt, act, window(kSaveFeat), 0.f, mask_rec(7), lane};
-        stream_layer<32, 0, 8, 8>(pw, wp + fwd_pack_off(7) / 4, act, none, ep);
+        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(7) / 4, act, none, ep, &carry,
+                                                             NextLayer{4 * fwd_pack_off(8), 4 * 1024, 4 * bias_pack_off(8), hoff});
         advance();
         NIW_STAMP(8);
         // density row: the two lane halves hold complementary input slots
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     float hr[64];
     {
         FwdEpilogue<4, true, SAVE, 2> ep{pw, 4 * bias_pack_off(8), hoff, hr, act, window(kSaveHr), 0.f, mask_rec(8), lane};
-        stream_layer<32, 4, 4, 4>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep);
+        stream_layer<32, 4, 4, 4, decltype(ep), true, false>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep, &carry);
         NIW_STAMP(9);
         float o[3];
 #pragma unroll
