@@ -215,7 +215,8 @@ int niw_render_fwd(const niw_render_desc* desc, float* workspace, float* rgb, fl
  * The per-view / per-parameter preprocessing (weight norm g*v/|v| nvp_ndr.py:291-292, code
  * projection lin_c(code)+code :381, and the latent half of the first layers) is folded by the
  * host mirror into:
- *   w_emb   [3 blocks][ part a: 128x26 | part b: 128x13 ]   effective first-layer weights (embedding columns)
+ *   w_emb   [3 blocks][ part a: 128 rows of 28 | part b: 128 rows of 16 ]   effective first-layer weights: 26 / 13 embedding
+ *           columns per row, padded to 16-byte multiples (pad columns: written as zero, never read)
  *   view_b  [n_views][3][2][128]                            W[:,emb:] . code_b + bias   (per view)
  *   w_head  [3][ a: 1x128 + 1 | b: 3x128 + 3 ]              second-layer weights and biases
  * pts [n_views, n_pts, 3]; chan_w[6] (host) per-band window or NULL; index_window[6] (host) or NULL: the
@@ -226,7 +227,7 @@ int niw_render_fwd(const niw_render_desc* desc, float* workspace, float* rgb, fl
  * window applies; pt_scale_a / pt_scale_b [n_pts] (device) optional additional per-point scales.
  * inverse != 0 evaluates .inverse.  xin_save [n_views,n_pts,3,3] or NULL: the input point of each of the three coupling blocks,
  * kept for niw_warp_bwd (forward warp only), which otherwise recomputes them -- a third of its work. */
-#define NIW_WARP_WEMB_FLOATS (3 * (128 * 26 + 128 * 13))
+#define NIW_WARP_WEMB_FLOATS (3 * (128 * 28 + 128 * 16))
 #define NIW_WARP_WHEAD_FLOATS (3 * (128 + 1 + 3 * 128 + 3))
 #define NIW_WARP_PARAM_FLOATS 165900    /* DeformNetwork parameters, flat in parameters() order (see niw_warp_prep.hip) */
 

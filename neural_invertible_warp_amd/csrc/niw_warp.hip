@@ -25,7 +25,11 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
 namespace {
 
 constexpr int kHid = 128, kEa = 26, kEb = 13, kNF = 6;
-constexpr int kWembBlock = kHid * (kEa + kEb);          // 4992 floats per coupling block
+// w_emb / d_w_emb rows are padded to 28 / 16 floats: every row starts 16-byte aligned and is read from LDS as ds_read_b128
+// broadcasts (with packed 26- / 13-float rows every weight was its own ds_read_b32: one LDS instruction per FMA, and the
+// backward read every row twice)
+constexpr int kSa = 28, kSb = 16;
+constexpr int kWembBlock = kHid * (kSa + kSb);          // 5632 floats per coupling block
 constexpr int kHeadBlock = kHid + 1 + 3 * kHid + 3;      // 516
 constexpr float kPi32 = 3.14159274101257324f;            // fp32(pi): the band table is an fp32 tensor (embedder.py:26)
 
@@ -136,11 +140,20 @@ __device__ __forceinline__ void embed_bwd(const float (&e)[D * (1 + 2 * kNF)], c
     }
 }
 
-template <int E>
-__device__ __forceinline__ float dot_row(const float* __restrict__ w, const float (&e)[E]) {
+// one padded weight row from LDS as 16-byte reads (S floats, E of them meaningful)
+template <int S>
+__device__ __forceinline__ void load_row(const float* __restrict__ w, float (&r)[S]) {
+#pragma unroll
+    for (int c = 0; c < S; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + c);
+        r[c] = v[0]; r[c + 1] = v[1]; r[c + 2] = v[2]; r[c + 3] = v[3];
+    }
+}
+template <int E, int S>
+__device__ __forceinline__ float dot_row(const float (&r)[S], const float (&e)[E]) {
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < E; ++c) s += w[c] * e[c];
+    for (int c = 0; c < E; ++c) s += r[c] * e[c];
     return s;
 }
 
@@ -222,17 +235,23 @@ __device__ __forceinline__ float part_a(const float* lw, const float* lh, const 
     const float* hd = lh + b * kHeadBlock;
     const float* vb = lv + (b * 2 + 0) * kHid;
     float delta = 0.f;
-    for (int u = sub; u < kHid; u += kGroup) delta += hd[u] * softplus100(vb[u] + dot_row<kEa>(W + u * kEa, ea));
+    for (int u = sub; u < kHid; u += kGroup) {
+        float row[kSa];
+        load_row<kSa>(W + u * kSa, row);
+        delta += hd[u] * softplus100(vb[u] + dot_row<kEa, kSa>(row, ea));
+    }
     return group_sum(delta) + hd[kHid];
 }
 // part b: (theta, t0, t1) = head_b(softplus(W_b e + v_b))
 __device__ __forceinline__ void part_b(const float* lw, const float* lh, const float* lv, int b, int sub, const float (&eb)[kEb], float (&o)[3]) {
-    const float* W = lw + b * kWembBlock + kHid * kEa;
+    const float* W = lw + b * kWembBlock + kHid * kSa;
     const float* hd = lh + b * kHeadBlock + kHid + 1;
     const float* vb = lv + (b * 2 + 1) * kHid;
     o[0] = o[1] = o[2] = 0.f;
     for (int u = sub; u < kHid; u += kGroup) {
-        const float hh = softplus100(vb[u] + dot_row<kEb>(W + u * kEb, eb));
+        float row[kSb];
+        load_row<kSb>(W + u * kSb, row);
+        const float hh = softplus100(vb[u] + dot_row<kEb, kSb>(row, eb));
         o[0] += hd[u] * hh; o[1] += hd[kHid + u] * hh; o[2] += hd[2 * kHid + u] * hh;
     }
     o[0] = group_sum(o[0]) + hd[3 * kHid];
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
         float* ws = a.ws + (long long)b * kRowsPerBlock * a.ppad + gi;     // column gi of this block's rows
         const long long P = a.ppad;
         const float* Wa = lw + b * kWembBlock;
-        const float* Wb = Wa + kHid * kEa;
+        const float* Wb = Wa + kHid * kSa;
         const float* hda = lh + b * kHeadBlock;
         const float* hdb = hda + kHid + 1;
         const float* va = lv + (b * 2 + 0) * kHid;
@@ -371,14 +390,16 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
 #pragma unroll
         for (int k = 0; k < kEb; ++k) geb[k] = 0.f;
         for (int u = sub; u < kHid; u += kGroup) {
-            const float pre = vb[u] + dot_row<kEb>(Wb + u * kEb, eb);
+            float row[kSb];
+            load_row<kSb>(Wb + u * kSb, row);
+            const float pre = vb[u] + dot_row<kEb, kSb>(row, eb);
             const float gh = hdb[u] * go[0] + hdb[kHid + u] * go[1] + hdb[2 * kHid + u] * go[2];
             const Softplus100 act = softplus100_pair(pre);
             const float gp = gh * act.slope;
             NIW_WS(kRowGb + u, gp);
             NIW_WS(kRowHb + u, act.value);
 #pragma unroll
-            for (int k = 0; k < kEb; ++k) geb[k] += Wb[u * kEb + k] * gp;
+            for (int k = 0; k < kEb; ++k) geb[k] += row[k] * gp;
         }
 #pragma unroll
         for (int k = 0; k < kEb; ++k) geb[k] = group_sum(geb[k]);
@@ -391,13 +412,15 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
 #pragma unroll
         for (int k = 0; k < kEa; ++k) gea[k] = 0.f;
         for (int u = sub; u < kHid; u += kGroup) {
-            const float pre = va[u] + dot_row<kEa>(Wa + u * kEa, ea);
+            float row[kSa];
+            load_row<kSa>(Wa + u * kSa, row);
+            const float pre = va[u] + dot_row<kEa, kSa>(row, ea);
             const Softplus100 act = softplus100_pair(pre);
             const float gp = g_delta * hda[u] * act.slope;
             NIW_WS(kRowGa + u, gp);
             NIW_WS(kRowHa + u, act.value);
 #pragma unroll
-            for (int k = 0; k < kEa; ++k) gea[k] += Wa[u * kEa + k] * gp;
+            for (int k = 0; k < kEa; ++k) gea[k] += row[k] * gp;
         }
 #pragma unroll
         for (int k = 0; k < kEa; ++k) gea[k] = group_sum(gea[k]);
@@ -448,11 +471,12 @@ __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, co
         const int r = idx >> 8, c = idx & 255;                  // r: [ga 0..127 | gb 128..255], c: [ea 0..31 | eb 32..63 | views 64..127]
         const int part = r >> 7, u = r & 127;
         float* dst = nullptr;
-        if (part == 0 && c < kEa) dst = d_w_emb + b * kWembBlock + u * kEa + c;
-        else if (part == 1 && c >= 32 && c < 32 + kEb) dst = d_w_emb + b * kWembBlock + kHid * kEa + u * kEb + (c - 32);
+        bool pad = false;                                       // pad columns of the rows: overwritten with zero
+        if (part == 0 && c < kSa) { dst = d_w_emb + b * kWembBlock + u * kSa + c; pad = c >= kEa; }
+        else if (part == 1 && c >= 32 && c < 32 + kSb) { dst = d_w_emb + b * kWembBlock + kHid * kSa + u * kSb + (c - 32); pad = c - 32 >= kEb; }
         else if (c >= 64 && c < 64 + n_views) dst = d_view_b + ((long long)(c - 64) * 3 + b) * 2 * kHid + part * kHid + u;
         if (!dst) return;
-        *dst = sum_tiles(p1 + (long long)b * nsplit1 * T1 + idx, T1, nsplit1);
+        *dst = pad ? 0.f : sum_tiles(p1 + (long long)b * nsplit1 * T1 + idx, T1, nsplit1);
     } else if (idx < 256 * 256 + 256 * 64 + 256) {
         const int j = idx - 256 * 256;                          // tile 2: [ha 0..127 | hb 128..255] x [d delta, d theta, d t0, d t1, ...]
         float* dst = nullptr;

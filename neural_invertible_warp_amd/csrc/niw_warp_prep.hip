@@ -28,19 +28,21 @@ constexpr int kBlkB = kHid + kHid * kKb + kHid + 3 * kHid + 3;          // 18691
 constexpr int kBlkC = kLat * kLat + kLat;                               // 16512
 constexpr int kOffB = 3 * kBlkA, kOffC = kOffB + 3 * kBlkB;
 static_assert(kOffC + 3 * kBlkC == NIW_WARP_PARAM_FLOATS, "flat warp parameter count");
-constexpr int kWembBlock = kHid * (kEa + kEb), kHeadBlock = kHid + 1 + 3 * kHid + 3;
+constexpr int kSa = 28, kSb = 16;                                       // row pitch of w_emb / d_w_emb (26 / 13 columns + pad)
+constexpr int kWembBlock = kHid * (kSa + kSb), kHeadBlock = kHid + 1 + 3 * kHid + 3;
+static_assert(3 * kWembBlock == NIW_WARP_WEMB_FLOATS, "w_emb layout");
 constexpr int kMaxViews = 64;
 constexpr int kGroups = 8, kRowsPerWave = 4;            // a workgroup (4 waves) owns 16 of the 128 rows of one first layer
 constexpr int kParts = 2 * kGroups * 4;                 // d(code_b) partials per coupling block: (part, group, wave)
 static_assert(kGroups * 4 * kRowsPerWave == kHid, "row decomposition");
 
 struct Layer {                 // first layer of part a / b of block b inside the flat buffer
-    int g, v, bias, head, E, K, nhead;
+    int g, v, bias, head, E, K, nhead, S;     // S: row pitch of this part inside w_emb
 };
 __device__ __forceinline__ Layer layer_of(int b, int part) {
     Layer l;
-    if (part == 0) { l.bias = b * kBlkA; l.E = kEa; l.K = kKa; l.nhead = kHid + 1; }
-    else           { l.bias = kOffB + b * kBlkB; l.E = kEb; l.K = kKb; l.nhead = 3 * kHid + 3; }
+    if (part == 0) { l.bias = b * kBlkA; l.E = kEa; l.K = kKa; l.nhead = kHid + 1; l.S = kSa; }
+    else           { l.bias = kOffB + b * kBlkB; l.E = kEb; l.K = kKb; l.nhead = 3 * kHid + 3; l.S = kSb; }
     l.g = l.bias + kHid;
     l.v = l.g + kHid;
     l.head = l.v + kHid * l.K;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void warp_prep_fwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < B * kLat; i += blockDim.x) cb[i] = codeb[(long long)c.b * B * kLat + i];
     __syncthreads();
-    float* we = w_emb + c.b * kWembBlock + (c.part ? kHid * kEa : 0);
+    float* we = w_emb + c.b * kWembBlock + (c.part ? kHid * kSa : 0);
     // the four rows of the wave side by side: their loads are in flight together and their butterflies interleave
     float e[kRowsPerWave], y0[kRowsPerWave], y1[kRowsPerWave], s[kRowsPerWave], bias[kRowsPerWave];
 #pragma unroll
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void warp_prep_fwd_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < kRowsPerWave; ++r) {
         s[r] = s[r] / sqrtf(wave_sum(e[r] * e[r] + y0[r] * y0[r] + y1[r] * y1[r]));
-        if (lane < l.E) we[(c.u0 + r) * l.E + lane] = e[r] * s[r];
+        if (lane < l.S) we[(c.u0 + r) * l.S + lane] = lane < l.E ? e[r] * s[r] : 0.f;       // pad columns zero
     }
     for (int v = 0; v < B; ++v) {
         const float c0 = cb[v * kLat + lane], c1 = cb[v * kLat + 64 + lane];
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void warp_prep_bwd_kernel(const float* __restr
             db += t;
         }
         const float* vrow = P + l.v + u * l.K;
-        const float* dwe = d_w_emb + c.b * kWembBlock + (c.part ? kHid * kEa : 0) + u * l.E;
+        const float* dwe = d_w_emb + c.b * kWembBlock + (c.part ? kHid * kSa : 0) + u * l.S;
         const float e = lane < l.E ? vrow[lane] : 0.f, de = lane < l.E ? dwe[lane] : 0.f;
         const float y0 = vrow[l.E + lane], y1 = vrow[l.E + 64 + lane];
         const float n2 = wave_sum(e * e + y0 * y0 + y1 * y1);

@@ -427,7 +427,7 @@ class _Warp(torch.autograd.Function):
 
 
 WARP_PARAM_FLOATS = 165900
-WARP_WEMB_FLOATS = 3 * (128 * 26 + 128 * 13)
+WARP_WEMB_FLOATS = 3 * (128 * 28 + 128 * 16)      # rows padded to 16-byte multiples (include/niw.h)
 WARP_WHEAD_FLOATS = 3 * (128 + 1 + 3 * 128 + 3)
 
 

@@ -245,10 +245,10 @@ def test_warp_operand_preparation_against_float64_autograd():
     for b in range(3):
         cb = c64 @ p[f"lin{b}_c.weight"].t() + p[f"lin{b}_c.bias"] + c64
         per_view = []
-        for part, E in (("a", 26), ("b", 13)):
+        for part, E, S in (("a", 26, 28), ("b", 13, 16)):           # w_emb rows are padded to 28 / 16 floats (include/niw.h)
             v_, g_ = p[f"lin{b}_{part}_0.weight_v"], p[f"lin{b}_{part}_0.weight_g"]
             w = v_ * (g_ / v_.norm(dim=1, keepdim=True))
-            emb.append(w[:, :E].reshape(-1))
+            emb.append(torch.nn.functional.pad(w[:, :E], (0, S - E)).reshape(-1))
             per_view.append(cb @ w[:, E:].t() + p[f"lin{b}_{part}_0.bias"])                 # [B,128]
             head += [p[f"lin{b}_{part}_1.weight"].reshape(-1), p[f"lin{b}_{part}_1.bias"].reshape(-1)]
         vb.append(torch.stack(per_view, dim=1))                                           # [B,2,128]
