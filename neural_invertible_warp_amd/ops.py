@@ -14,6 +14,7 @@ NERF_PARAM_FLOATS = 530052
 SAVE_ROWS = 2346
 GRAD_ROWS = 2336
 L3D, LVIEW = 10, 4
+TRAIN_LAUNCH_SAMPLES = (1 << 31) // (288 * 4)          # samples per differentiable field_mlp launch (see field_mlp)
 ACT = {"relu": 0, "softplus": 1}
 
 
@@ -323,12 +324,16 @@ class _FieldMLP(torch.autograd.Function):
 def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=None, band_dev=None, grad_sink=None):
     """NeRF.forward_samples on flattened rays: center, ray [N,3], depth [N,S] -> rgb [N,S,3], sigma [N,S].
     band_dev: device tensor [14] = {band3d, bandview}; when given the kernel reads the c2f weights from it at run time.
-    One launch takes fewer than 2^24 padded samples (32-bit byte offsets into the workspaces, niw_mlp_device.h); larger
+    One launch takes fewer than 2^24 padded samples (32-bit byte offsets into the workspaces, niw_mlp_device.h), 1.86 M when
+    gradients are wanted (the dW GEMM reaches a 288-row operand through one 2 GiB descriptor); larger
     batches are split over the rays (autograd sums the parameter gradients of the pieces).
     grad_sink: flat float32 buffer [NERF_PARAM_FLOATS] that receives the parameter gradients of this call IN PLACE of the
     Parameters' .grad (engine.INNTrainer: a segment of its gradient bucket); one call per backward pass may write it."""
     n_rays, S = depth.shape
-    max_rays = ((1 << 24) - 256) // S
+    # one launch: < 2^24 padded samples (32-bit byte offsets inside a 32-row window); with gradients < 2^31 / (288 * 4) = 1.86 M,
+    # because the dW GEMM addresses a whole operand (up to 288 rows x samples x 4 bytes) through one 2 GiB buffer descriptor
+    training = torch.is_grad_enabled() and bool(params)
+    max_rays = ((TRAIN_LAUNCH_SAMPLES if training else (1 << 24)) - 256) // S
     if grad_sink is not None and (not torch.is_grad_enabled() or not params):
         grad_sink = None
     if grad_sink is not None and (grad_sink.numel() != NERF_PARAM_FLOATS or grad_sink.dtype != torch.float32 or not grad_sink.is_contiguous()):
@@ -336,8 +341,8 @@ def field_mlp(state, params, center, ray, depth, band3d, bandview, activ, noise=
     if n_rays <= max_rays:
         return _FieldMLP.apply(state, band3d, bandview, band_dev, activ, noise, torch.is_grad_enabled(), grad_sink, center, ray, depth, *params)
     if grad_sink is not None:
-        raise _lib.NiwError("field_mlp: a batch beyond one launch's 2^24 samples is split into pieces whose gradients autograd sums; "
-                            "that cannot be combined with grad_sink")
+        raise _lib.NiwError("field_mlp: a batch beyond one launch's sample limit (1.86 M with gradients, 2^24 without) is split into pieces "
+                            "whose gradients autograd sums; that cannot be combined with grad_sink")
     rgb, sigma = [], []
     with (state.hold() if not params else contextlib.nullcontext()):
         for a in range(0, n_rays, max_rays):

@@ -136,3 +136,41 @@ def test_mlp_batches_beyond_one_launch_are_split_over_rays():
         for a, b in ((0, 100), (65000, 65600), (N - 50, N)):                    # across and beyond the split point
             r2, s2 = ops.field_mlp(st, [], center[a:b], ray[a:b], depth[a:b], [1.0] * 10, [1.0] * 4, "softplus")
             assert torch.equal(rgb[a:b], r2) and torch.equal(sig[a:b], s2)
+
+
+def test_mlp_training_batches_beyond_the_gradient_launch_limit_are_split():
+    """With gradients one launch takes fewer than 2^31 / (288 * 4) = 1.86 M samples (the dW GEMM reaches a 288-row operand through one
+    2 GiB buffer descriptor).  2.36 M samples in one differentiable call: the wrapper splits over the rays and autograd sums the pieces; the
+    parameter gradient must equal the sum of the gradients of the same pieces run by hand (and be finite), and a gradient sink
+    -- which cannot be summed into -- must be refused loudly."""
+    from neural_invertible_warp_amd import _lib, ops
+    from oracle import niw_oracle as O
+    p = O.make_nerf_params(2)
+    names = [f"{n}.{k}" for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]
+    flat = torch.cat([p[n].reshape(-1) for n in names]).to(DEV)
+    params, off = [], 0
+    for n in names:
+        params.append(flat[off:off + p[n].numel()].view(p[n].shape).requires_grad_(True))
+        off += p[n].numel()
+    st = ops.FieldState(flat)
+    N, S = 18432, 128                                  # 2,359,296 samples
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    center, ray = torch.randn(N, 3, device=DEV, generator=gen) * 0.1, torch.randn(N, 3, device=DEV, generator=gen)
+    depth = (torch.rand(N, S, device=DEV, generator=gen).sort(dim=1).values * 4 + 0.5).contiguous()
+    w = torch.randn(N, S, 3, device=DEV, generator=gen)
+
+    def grads(pieces):
+        for q in params:
+            q.grad = None
+        for a, b in pieces:
+            rgb, sig = ops.field_mlp(st, params, center[a:b], ray[a:b], depth[a:b], [1.0] * 10, [1.0] * 4, "softplus")
+            ((rgb * w[a:b]).sum() + sig.sum()).backward()
+        return torch.cat([q.grad.reshape(-1) for q in params])
+
+    whole = grads([(0, N)])
+    cut = (ops.TRAIN_LAUNCH_SAMPLES - 256) // S        # where the wrapper cuts
+    by_hand = grads([(0, cut), (cut, N)])
+    assert torch.isfinite(whole).all()
+    assert (whole - by_hand).abs().max() <= 1e-6 * whole.abs().max()
+    with pytest.raises(_lib.NiwError):
+        ops.field_mlp(st, params, center, ray, depth, [1.0] * 10, [1.0] * 4, "softplus", grad_sink=torch.empty(ops.NERF_PARAM_FLOATS, device=DEV))
