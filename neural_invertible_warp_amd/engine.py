@@ -230,7 +230,10 @@ class INNTrainer:
     def _graph_iteration(self, var, it, replay=True):
         self._upload_constants(it)
         if self._captured is None or not replay:
-            if not replay or it < 2 or not self._capture(var, it):
+            self._eager_runs = getattr(self, "_eager_runs", 0)
+            if not replay or self._eager_runs < 2 or not self._capture(var, it):
+                # (two launch-by-launch iterations of THIS trainer come first, whatever `it` is: a resumed run starts at a large one)
+                self._eager_runs += 1
                 # warm-up (allocator, lazily built tables, kernel attributes) and fall-back: the same body, launch by launch, on the
                 # side stream the capture will use (autograd's gradient accumulators stay tied to the stream they first ran on)
                 side = self._side_stream()

@@ -239,3 +239,30 @@ def test_hip_graph_replays_without_host_synchronisation_use_their_own_step_const
     a, b = run(True), run(False)
     for fa, fb in zip(a._flats(), b._flats()):
         assert (fa - fb).abs().max() <= 5e-4 * fa.abs().max()
+
+
+def test_hip_graph_capture_after_a_resume_at_a_late_iteration():
+    """A resumed run enters train_iteration for the first time with a large iteration number: the trainer must still run its two
+    launch-by-launch warm-up iterations before capturing (the capture used to be attempted at once when `it >= 2`), and then track
+    the eager engine started at the same iteration."""
+    from neural_invertible_warp_amd import configs, engine
+
+    def run(hip_graph):
+        opt = configs.cfg3_barf_inn_llff(device=DEV)
+        opt.nerf.sample_stratified = False
+        opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = 5 * 40, 32, 4000
+        var0 = engine.synthetic_scene(opt, 5)
+        tr = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=3, hip_graph=hip_graph)
+        tr.it = 1234                                    # what checkpoint.restore_checkpoint leaves behind
+        for n in tr.nets:
+            n.set_progress(tr.it / opt.max_iter)
+        losses = [float(tr.train_iteration(type(var0)(var0)).render.detach()) for _ in range(6)]
+        return tr, losses
+
+    eager, l_e = run(False)
+    graph, l_g = run(True)
+    assert graph._captured is not None and graph.it == 1240
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 2e-4 * max(abs(a), 1e-3)
+    for fa, fb in zip(eager._flats(), graph._flats()):
+        assert (fa - fb).abs().max() <= 5e-4 * fa.abs().max()
