@@ -20,8 +20,26 @@ import shutil
 import torch
 
 
+def group_by_child(state_dict):
+    """`graph` section of a checkpoint -> {child module name: its own state dict}: one pass over the keys, split at the first dot
+    (what the reference does per child with util.get_child_state_dict, util.py:120-121)"""
+    groups = {}
+    for key, value in state_dict.items():
+        child, _, rest = key.partition(".")
+        if rest:
+            groups.setdefault(child, {})[rest] = value
+    return groups
+
+
 def get_child_state_dict(state_dict, key):
-    return {".".join(k.split(".")[1:]): v for k, v in state_dict.items() if k.startswith("{}.".format(key))}
+    return group_by_child(state_dict).get(key, {})
+
+
+def checkpoint_path(opt, resume=True):
+    """the file `--resume` names: the latest checkpoint, or the numbered copy of epoch / iteration `resume` (util.py:126-128)"""
+    if resume is True:
+        return os.path.join(opt.output_path, "model.ckpt")
+    return os.path.join(opt.output_path, "model", f"{resume}.ckpt")
 
 
 def _optimizers(trainer):
@@ -119,14 +137,15 @@ def save_checkpoint(opt, trainer, ep, it, latest=False, children=None):
 
 def restore_checkpoint(opt, trainer, load_name=None, resume=False):
     """reference util.py:124-145 -> (epoch, iter) when resuming, (None, None) when only loading weights"""
-    assert (load_name is None) == (resume is not False)
+    if (load_name is None) == (resume is False):
+        raise ValueError("restore_checkpoint: give either load_name (weights only) or resume (weights, optimizers, counters)")
     if resume:
-        load_name = "{0}/model.ckpt".format(opt.output_path) if resume is True else "{0}/model/{1}.ckpt".format(opt.output_path, resume)
+        load_name = checkpoint_path(opt, resume)
     checkpoint = torch.load(load_name, map_location=opt.device, weights_only=False)
+    per_child = group_by_child(checkpoint["graph"])
     for name, child in trainer.graph.named_children():
-        child_sd = get_child_state_dict(checkpoint["graph"], name)
-        if child_sd:
-            child.load_state_dict(child_sd)
+        if name in per_child:
+            child.load_state_dict(per_child[name])
     for net in trainer.nets:                                   # host copy of the c2f progress the kernels use
         if hasattr(net, "progress"):
             net.set_progress(float(net.progress.data))

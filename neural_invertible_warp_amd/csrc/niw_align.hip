@@ -18,7 +18,7 @@
 // Gradient.  R, t MINIMISE sum_i |R x_i + t - y_i|^2 = sum_i |x_i - R^T (y_i - t)|^2 over SO(3) x R^3, so the loss is
 // stationary in (R, t) and, by the envelope theorem, d loss / d x through (R, t) vanishes identically: the total derivative
 // is the direct term 2 e_i / n.  (Checked against autograd through the SVD in fp64: the two agree to 1e-17,
-// tests/test_align_loss.py.)  The reference differentiates through roma's SVD and obtains the same numbers plus roundoff; the
+// tests/test_gpu_step_ops.py::test_fused_alignment_loss_vs_oracle_autograd_through_svd and tests/test_parallel_gloo.py.)  The reference differentiates through roma's SVD and obtains the same numbers plus roundoff; the
 // DTU variant detaches the pose explicitly.
 #include "niw_common.h"
 #include "niw_kabsch_device.h"

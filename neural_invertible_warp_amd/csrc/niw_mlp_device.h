@@ -16,10 +16,6 @@
 #define NIW_STORE_AUX 2
 #endif
 
-#ifdef NIW_STAMPS
-extern __device__ unsigned long long niw_stamps[8192 * 16];
-#endif
-
 namespace niw {
 
 // band frequency 2^k * fp32(pi)  (reference: 2**arange(L) * np.pi evaluated in fp32, nerf.py:478)
@@ -127,17 +123,7 @@ struct NextLayer {
 template <int KB1, int KB2, int NB, int STRIDE, typename Policy, bool CARRY_IN = false, bool CARRY_OUT = false>
 __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x4* __restrict__ wp, const float (&b1)[4 * KB1],
                                              const float (&b2)[4 * (KB2 > 0 ? KB2 : 1)], Policy& pol, LayerCarry* carry = nullptr,
-                                             NextLayer next = NextLayer{}, int stamp_base = -1) {
-#ifdef NIW_STAMPS
-#define NIW_STAMP_L(k)                                                                                                     \
-    do {                                                                                                                   \
-        const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                                                \
-        if (stamp_base >= 0 && (threadIdx.x & 63) == 0 && w_ < 8192) niw_stamps[w_ * 16 + stamp_base + (k)] = __builtin_readcyclecounter(); \
-    } while (0)
-#else
-#define NIW_STAMP_L(k) do {} while (0)
-#endif
-    NIW_STAMP_L(0);
+                                             NextLayer next = NextLayer{}) {
     constexpr int KB = KB1 + KB2, N = NB * KB, D = NIW_RING_DEPTH, GAPS = 4 * KB;
     constexpr int G0 = GAPS >= 32 ? 8 : 0;                 // first gap used by the epilogue
     constexpr int GS = (GAPS - G0) / 16 > 0 ? (GAPS - G0) / 16 : 1;
@@ -148,43 +134,7 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
     static_assert(!(CARRY_IN || CARRY_OUT) || (N % D == 0 && KB >= D), "carried rings need whole ring turns per layer");
     f32x16 cin[2];
     f32x4 ring[D];
-#ifdef NIW_LDS_WEIGHTS
-    // EXPERIMENT: the workgroup's four waves stage every weight fragment ONCE through LDS -- stages of 8
-    // fragments (8 KiB), two buffers; wave w fetches fragments 2w, 2w+1 of a stage from L2 a stage ahead, all waves refill their
-    // rings from LDS.  One barrier per stage (32 MFMAs).  L2 -> L1 fragment traffic of the workgroup drops 4x.
-    static_assert(D == 8, "stages are ring turns");
-    __shared__ __attribute__((aligned(16))) float niw_wstage[2 * 8 * 256];
-    const int wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63;
-    constexpr int NSTG = (N + 7) / 8;
-    auto frag_off = [&](int f) { return base + ((f % KB) * STRIDE + f / KB) * 1024; };
-    auto gfetch = [&](int stg, f32x4 (&g)[2]) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int f = stg * 8 + 2 * wv_ + k;
-            g[k] = (stg < NSTG && f < N) ? buf_load4(pw.rsrc, pw.lane16, frag_off(f)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto lput = [&](int stg, const f32x4 (&g)[2]) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            *reinterpret_cast<f32x4*>(niw_wstage + (stg & 1) * 2048 + (2 * wv_ + k) * 256 + ln_ * 4) = g[k];
-    };
-    auto lget = [&](int f) { return *reinterpret_cast<const f32x4*>(niw_wstage + ((f >> 3) & 1) * 2048 + (f & 7) * 256 + ln_ * 4); };
-    f32x4 gst[2];
-    if (INIT) pol.acc_init(0, cin[0]);
-    __syncthreads();                                        // the previous layer's last stage has been read by every wave
-    gfetch(0, gst); lput(0, gst);
-    gfetch(1, gst); lput(1, gst);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-        if (i < N) ring[i] = lget(i);
-    __syncthreads();                                        // stage 0's buffer is overwritten at the first stage boundary
-    gfetch(2, gst);
-    if (false) {
-#else
     if (CARRY_IN) {
-#endif
         if (INIT) cin[0] = carry->cin0;
 #pragma unroll
         for (int i = 0; i < D; ++i) ring[i] = carry->ring[i];
@@ -212,17 +162,8 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
         for (int q = 0; q < KB; ++q) {
             const int i = nb * KB + q;
             const f32x4 a = ring[i % D];
-#ifdef NIW_LDS_WEIGHTS
-            if (i % 8 == 0 && i > 0) {                     // stage boundary: publish stage i/8 + 1, request stage i/8 + 2
-                lput(i / 8 + 1, gst);
-                __syncthreads();
-                gfetch(i / 8 + 2, gst);
-            }
-            if (i + D < N) ring[i % D] = lget(i + D);
-#else
             if (i + D < N) ring[i % D] = buf_load4(pw.rsrc, pw.lane16, base + (((i + D) % KB) * STRIDE + (i + D) / KB) * 1024);
             else if (CARRY_OUT) ring[i % D] = buf_load4(pw.rsrc, pw.lane16, next.w_base + (i + D - N) * next.w_stride);
-#endif
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float bv = q < KB1 ? b1[4 * (q < KB1 ? q : 0) + t] : b2[4 * (q >= KB1 ? q - KB1 : 0) + t];
@@ -242,16 +183,12 @@ __device__ __forceinline__ void stream_layer(const PackedWeights& pw, const f32x
                 if (G0 + r * GS >= GAPS) pol.epi(nb - 1, r, acc[(nb - 1) & 1][r], pre[(nb - 1) & 1][r]);
         }
     }
-    NIW_STAMP_L(1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) pol.epi(NB - 1, r, acc[(NB - 1) & 1][r], pre[(NB - 1) & 1][r]);
-#ifndef NIW_LDS_WEIGHTS
     if (CARRY_OUT) {
 #pragma unroll
         for (int i = 0; i < D; ++i) carry->ring[i] = ring[i];
     }
-#endif
-    NIW_STAMP_L(2);
 }
 
 }  // namespace niw

@@ -217,19 +217,6 @@ struct FwdEpilogue {
     }
 };
 
-// Diagnostic build only (-DNIW_STAMPS): per-layer s_memtime stamps of every wave, read back with
-// niw_debug_read_stamps().  Never compiled into the product library.
-#ifdef NIW_STAMPS
-__device__ unsigned long long niw_stamps[8192 * 16];   // (declared extern in niw_mlp_device.h)
-#define NIW_STAMP(i)                                                                                         \
-    do {                                                                                                     \
-        const int w_ = blockIdx.x * 4 + wave;                                                                \
-        if (lane == 0 && w_ < 8192) niw_stamps[w_ * 16 + (i)] = __builtin_readcyclecounter();                \
-    } while (0)
-#else
-#define NIW_STAMP(i) do {} while (0)
-#endif
-
 struct MlpFwdArgs {
     const float* packed;
     const float* center;
@@ -259,7 +246,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     const bool valid = m < a.M;
     const long long mc = valid ? m : a.M - 1;
     const long long ri = mc / a.S;
-    NIW_STAMP(11);
 
     // ---- sample point and unit view direction (camera.py:517-521, nerf.py:452)
     float p[3], u[3];
@@ -318,14 +304,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // every layer leaves the next one its first weight fragments and its first bias fragment (niw_mlp_device.h LayerCarry)
     LayerCarry carry;
     constexpr int kLayerBytes = 32 * 8 * 1024;       // one 256 -> 256 layer of the packed image
-    NIW_STAMP(0);
     // ---- layer 0: 63 -> 256
     {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, act, window(save_h(1)), 0.f, mask_rec(0), lane};
         stream_layer<8, 0, 8, 8, decltype(ep), false, true>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep, &carry,
                                                              NextLayer{4 * fwd_pack_off(1), 8 * 1024, 4 * bias_pack_off(1), hoff});
         advance();
-        NIW_STAMP(1);
     }
     // ---- layers 1..3
 #pragma unroll 1
@@ -333,10 +317,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
         const NextLayer nx = l < 3 ? NextLayer{4 * fwd_pack_off(1) + l * kLayerBytes, 8 * 1024, 4 * (bias_pack_off(1) + l * 256), hoff}
                                    : NextLayer{4 * fwd_pack_off(4), 8 * 1024, 4 * bias_pack_off(4), hoff};
-        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, &carry, nx,
-                                                             l == 2 ? 12 : -1);
+        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, &carry, nx);
         advance();
-        NIW_STAMP(1 + l);
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
@@ -344,7 +326,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         stream_layer<32, 8, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep, &carry,
                                                              NextLayer{4 * fwd_pack_off(5), 8 * 1024, 4 * bias_pack_off(5), hoff});
         advance();
-        NIW_STAMP(5);
     }
     // ---- layers 5, 6
 #pragma unroll 1
@@ -354,7 +335,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
                                    : NextLayer{4 * fwd_pack_off(7), 8 * 1024, 4 * bias_pack_off(7), hoff};
         stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep, &carry, nx);
         advance();
-        NIW_STAMP(1 + l);
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
@@ -362,7 +342,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(7) / 4, act, none, ep, &carry,
                                                              NextLayer{4 * fwd_pack_off(8), 4 * 1024, 4 * bias_pack_off(8), hoff});
         advance();
-        NIW_STAMP(8);
         // density row: the two lane halves hold complementary input slots
         float sig_raw = ep.sig_raw + __shfl_xor(ep.sig_raw, 32) + buf_load1(pw.rsrc, 0, 4 * kHeadBiasOff);
         if (a.noise != nullptr) sig_raw += a.noise[mc];
@@ -377,11 +356,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     {
         FwdEpilogue<4, true, SAVE, 2> ep{pw, 4 * bias_pack_off(8), hoff, hr, act, window(kSaveHr), 0.f, mask_rec(8), lane};
         stream_layer<32, 4, 4, 4, decltype(ep), true, false>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep, &carry);
-        NIW_STAMP(9);
         float o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = ep.col[c] + __shfl_xor(ep.col[c], 32) + buf_load1(pw.rsrc, 0, 4 * (kHeadBiasOff + 1 + c));
-        NIW_STAMP(10);
         if (h == 0 && valid) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-o[c]));
@@ -392,12 +369,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-#ifdef NIW_STAMPS
-extern "C" int niw_debug_read_stamps(unsigned long long* dst, int count) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(niw_stamps), sizeof(unsigned long long) * count);
-}
-#endif
-
 extern "C" int64_t niw_mlp_padded_rows(int64_t n_rays, int n_samples) {
     int64_t m = n_rays * (int64_t)n_samples;
     return (m + 127) / 128 * 128;

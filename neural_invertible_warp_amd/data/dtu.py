@@ -181,6 +181,10 @@ class Dataset(torch.utils.data.Dataset):
 
     def _resize_plan(self, h, w):
         dtu = self.opt.data.dtu
+        if dtu.get("crop") or dtu.get("crop_ratio"):
+            # empty in every reference yaml; the reference loader honours them when set (data/dtu.py:407-419) -- refuse rather than
+            # silently train on un-cropped images with un-cropped intrinsics
+            raise NotImplementedError("data.dtu.crop / data.dtu.crop_ratio are not implemented by this loader (unset in all reference configs)")
         size, factor = dtu.get("resize"), dtu.get("resize_factor")
         if factor:
             H, W = int(round(h * factor)), int(round(w * factor))

@@ -115,6 +115,10 @@ class INNTrainer:
         self.lrs = [(o.lr, o.get("lr_end"))] * n + [(o.lr_pose, o.get("lr_pose_end"))] * 2       # (checkpoint.py reads these)
         self.gammas = [g_main] * n + [g_pose] * 2
         self.trainable = [True] * n + [train_warp, train_latent]
+        if not (train_warp or train_latent):
+            # the reference would build torch.optim.Adam([]) here and fail inside it (barf_inn_llff.py:84-95)
+            raise NiwError("inn.optimize.enabled and warp_latent.optimize.enabled are both false: the pose optimizer has no parameters")
+        self._warmup_group = n if train_warp else n + 1          # param_groups[0] of the reference's optim_pose
         self.warmup_pose = o.get("warmup_pose")
         self.it = 0
         on_gpu = torch.device(opt.device).type == "cuda"
@@ -125,11 +129,7 @@ class INNTrainer:
             if opt.nerf.ray_sampler != "feistel":
                 raise NiwError("hip_graph=True needs ray_sampler='feistel' (torch.randperm cannot be replayed with a fresh draw)")
             self.consts = StepConstants(dev, len(self.bucket.groups))
-            for n in self.nets:
-                n.band_dev = self.consts.band
-            self.warp_mlp.window_dev = self.consts.window
-            self.graph.draw_dev = self.consts.draw
-        if world > 1:
+        if world > 1 or parallel.FORCE_COLLECTIVES:      # (a forced one-rank group shards 1-way: same arithmetic, collectives issued)
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)
 
@@ -149,9 +149,10 @@ class INNTrainer:
 
     def learning_rate(self, group, it):
         """lr of optimizer group `group` in 0-based iteration `it` (scheduler stepped `it` times; the reference's linear
-        pose warm-up touches param_groups[0] of optim_pose only, i.e. the warp network: barf_inn_llff.py:108-111)"""
+        pose warm-up touches param_groups[0] of optim_pose only (barf_inn_llff.py:108-111): the warp network when it is trained,
+        otherwise the latent table, which is then the first -- and only -- group of that optimizer, :84-95)"""
         lr = self.lrs[group][0] * self.gammas[group] ** it
-        if self.warmup_pose and group == len(self.nets):
+        if self.warmup_pose and group == self._warmup_group:
             lr *= min(1.0, it / self.warmup_pose)
         return lr
 
@@ -166,12 +167,28 @@ class INNTrainer:
         return loss
 
     # ------------------------------------------------------------------ one iteration
+    def _bind_constants(self, on):
+        """Point the modules at the device-resident step constants for the duration of ONE train iteration of this engine, and back
+        to None after it: every other caller of the same modules (validation, evaluation, a render between two steps) then gets
+        its c2f bands / annealing windows / pixel draw by value from the host state, as without hip_graph.  (Round 2 left the
+        pointers in place: a validate() before the first step rendered with an all-zero band table, later ones with the bands of
+        the previous train iteration.)"""
+        consts = self.consts if (on and self.hip_graph) else None
+        for n in self.nets:
+            n.band_dev = None if consts is None else consts.band
+        self.warp_mlp.window_dev = None if consts is None else consts.window
+        self.graph.draw_dev = None if consts is None else consts.draw
+
     def _forward_backward(self, var, it):
         opt = self.opt
         self._install_grad_sinks()
-        var = self.graph.forward(opt, var, mode="train", iter=it)
-        loss = self.graph.compute_loss(opt, var, mode="train")
-        self._backward_weighted(loss)
+        self._bind_constants(True)
+        try:
+            var = self.graph.forward(opt, var, mode="train", iter=it)
+            loss = self.graph.compute_loss(opt, var, mode="train")
+            self._backward_weighted(loss)
+        finally:
+            self._bind_constants(False)
         self.bucket.gather()
         return loss
 
@@ -245,11 +262,32 @@ class INNTrainer:
                 torch.cuda.current_stream().wait_stream(side)
                 return loss
         fb, adam, loss = self._captured
+        self._check_static_inputs(var)
         fb.replay()
         if adam is not None:                           # ranks exchange gradients between the two graphs
             self.bucket.all_reduce()
             adam.replay()
         return loss
+
+    def _check_static_inputs(self, var):
+        """A replay reads the batch tensors the capture saw, at the addresses it saw them.  A caller that hands over the same data in
+        new storage (a re-allocated image after .to(), another batch) gets it copied into the captured tensors when the shapes agree
+        -- stream-ordered in front of the replay -- and an error when they do not; a replay never trains silently on stale inputs."""
+        for k, ref in self._static_inputs.items():
+            t = var.get(k) if hasattr(var, "get") else getattr(var, k, None)
+            if t is None:
+                raise NiwError(f"train_iteration: the captured iteration reads var.{k}, which this call does not provide")
+            if not isinstance(t, torch.Tensor):
+                raise NiwError(f"train_iteration: var.{k} was a tensor when the iteration was captured, now {type(t).__name__}")
+            if t.data_ptr() == ref.data_ptr() and t.shape == ref.shape and t.dtype == ref.dtype:
+                continue
+            if t.shape != ref.shape or t.dtype != ref.dtype or t.device != ref.device:
+                raise NiwError(f"train_iteration: var.{k} is {tuple(t.shape)} {t.dtype} on {t.device}, the captured iteration was recorded with "
+                               f"{tuple(ref.shape)} {ref.dtype} on {ref.device}; build a new trainer (or hip_graph=False) for another batch shape")
+            ref.copy_(t)
+        for k, v in var.items():
+            if isinstance(v, torch.Tensor) and k not in self._static_inputs:
+                raise NiwError(f"train_iteration: var.{k} was not part of the captured iteration")
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -264,9 +302,13 @@ class INNTrainer:
         is an error (NiwError)."""
         import sys
         import torch.distributed as dist
-        live_group = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        live_group = parallel._collectives_live()
         if live_group and self.opt.loss_weight.get("global_alignment") is not None:
             return self._give_up_capture("the sharded alignment loss all-reduces its moments inside the forward")
+        if live_group and self.family == "dtu":
+            # INNPoseParams registers the warped onto the initial points in EVERY train forward (pose_models/inn.py:96-102), with or
+            # without the alignment term, and under ray sharding that registration all-reduces its Kabsch moments
+            return self._give_up_capture("the DTU pose network's sharded rigid registration all-reduces its moments inside the forward")
         self._static_inputs = {k: v for k, v in var.items() if isinstance(v, torch.Tensor)}      # must stay alive and in place
         torch.cuda.synchronize()
         try:
@@ -298,10 +340,7 @@ class INNTrainer:
         self.hip_graph_failed = True
         self._captured = None
         self.hip_graph = False
-        for n in self.nets:
-            n.band_dev = None
-        self.warp_mlp.window_dev = None
-        self.graph.draw_dev = None
+        self._bind_constants(False)
         return False
 
     def sync_state(self):

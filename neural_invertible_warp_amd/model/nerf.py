@@ -205,17 +205,20 @@ class Graph(_BaseGraph):
         if opt.nerf.fine_sampling:
             self.nerf_fine = NeRF(opt)
 
+    SAMPLED_MODES = ("train", "test-optim")        # modes that optimise on a random pixel subset (reference nerf.py:254)
+
     def forward(self, opt, var, mode=None):
-        """reference nerf.py:251-274"""
-        batch_size = len(var.idx)
+        """reference nerf.py:251-274: a random pixel subset when optimising, whole images otherwise (in slices of `nerf.rand_rays`
+        pixels whenever that bound is set).  The dead "render_train" branch of the reference is not carried over."""
         pose = self.get_pose(opt, var, mode=mode)
-        if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
-            var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.rand_rays // batch_size]
-            ret = self.render(opt, pose, intr=var.intr, ray_idx=var.ray_idx, mode=mode)
+        n_rays = opt.nerf.rand_rays
+        if n_rays and mode in self.SAMPLED_MODES:
+            var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:n_rays // len(var.idx)]
+            out = self.render(opt, pose, intr=var.intr, ray_idx=var.ray_idx, mode=mode)
         else:
-            ret = self.render_by_slices(opt, pose, intr=var.intr, mode=mode) if opt.nerf.rand_rays else \
-                self.render(opt, pose, intr=var.intr, mode=mode)
-        var.update(ret)
+            whole_image = self.render_by_slices if n_rays else self.render
+            out = whole_image(opt, pose, intr=var.intr, mode=mode)
+        var.update(out)
         return var
 
     def compute_loss(self, opt, var, mode=None):
@@ -375,24 +378,23 @@ class Model:
         self.sched = torch.optim.lr_scheduler.ExponentialLR(self.optim, gamma=gamma)
 
     def restore_checkpoint(self, opt):
-        import os
+        """reference util.py:124-145 as called from base.py:64-73: `--resume` (True = model.ckpt, a number = model/<n>.ckpt) restores
+        networks, optimizer, scheduler and the counters; `--load=<file>` restores the networks only.  Children of the graph that the
+        checkpoint does not mention keep their initialisation (partial checkpoints)."""
+        from .. import checkpoint
         self.epoch_start = self.iter_start = 0
-        name = None
-        if opt.resume:
-            name = "{0}/model.ckpt".format(opt.output_path) if opt.resume is True else "{0}/model/{1}.ckpt".format(opt.output_path, opt.resume)
-        elif opt.load is not None:
-            name = opt.load
-        if name is None:
+        path = checkpoint.checkpoint_path(opt, resume=opt.resume) if opt.resume else opt.load
+        if path is None:
             return
-        ck = torch.load(name, map_location=opt.device, weights_only=False)
-        for child_name, child in self.graph.named_children():
-            sd = {".".join(k.split(".")[1:]): v for k, v in ck["graph"].items() if k.startswith(child_name + ".")}
-            if sd:
-                child.load_state_dict(sd)
+        state = torch.load(path, map_location=opt.device, weights_only=False)
+        per_child = checkpoint.group_by_child(state["graph"])
+        for name, module in self.graph.named_children():
+            if name in per_child:
+                module.load_state_dict(per_child[name])
         if opt.resume:
-            self.optim.load_state_dict(ck["optim"])
-            self.sched.load_state_dict(ck["sched"])
-            self.epoch_start, self.iter_start = ck["epoch"] or 0, ck["iter"] or 0
+            for attr in ("optim", "sched"):
+                getattr(self, attr).load_state_dict(state[attr])
+            self.epoch_start, self.iter_start = state["epoch"] or 0, state["iter"] or 0
 
     def setup_visualizer(self, opt):
         pass

@@ -18,21 +18,36 @@ from . import configs
 from .util import edict
 
 
+def _split_flag(token):
+    """One command-line token -> (dotted key path as a list, yaml text of the value).  The three value-less spellings of the
+    reference's syntax (options.py:16-22) map onto yaml literals: `--key` true, `--key!` false, `--key=` null (empty text)."""
+    if not token.startswith("--") or len(token) < 3:
+        raise ValueError(f"option {token!r}: expected --key[.subkey...][=value]")
+    body = token[2:]
+    name, eq, text = body.partition("=")
+    if not eq:
+        name, text = (body[:-1], "false") if body.endswith("!") else (body, "true")
+    path = name.split(".")
+    if not all(path):
+        raise ValueError(f"option {token!r}: empty key component")
+    return path, text
+
+
 def parse_arguments(args):
-    opt_cmd = {}
-    for arg in args:
-        assert arg.startswith("--"), arg
-        if "=" not in arg[2:]:
-            key_str, value = (arg[2:-1], "false") if arg[-1] == "!" else (arg[2:], "true")
-        else:
-            key_str, value = arg[2:].split("=", 1)
-        keys = key_str.split(".")
-        sub = opt_cmd
-        for k in keys[:-1]:
-            sub = sub.setdefault(k, {})
-        assert keys[-1] not in sub, keys[-1]
-        sub[keys[-1]] = yaml.safe_load(value)
-    return edict(opt_cmd)
+    """`--a.b.c=value` tokens -> nested option tree (values parsed as yaml); a key given twice is an error, as in the reference."""
+    tree = {}
+    for token in args:
+        path, text = _split_flag(token)
+        node = tree
+        for part in path[:-1]:
+            node = node.setdefault(part, {})
+            if not isinstance(node, dict):
+                raise ValueError(f"option {token!r}: {part!r} already holds a value")
+        leaf = path[-1]
+        if leaf in node:
+            raise ValueError(f"option {token!r}: {'.'.join(path)} given twice")
+        node[leaf] = yaml.safe_load(text)
+    return edict(tree)
 
 
 def override_options(opt, opt_over):

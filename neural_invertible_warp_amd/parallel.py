@@ -17,13 +17,23 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+FORCE_COLLECTIVES = False      # issue the collectives of a ONE-rank group too (bench.py --force-dist: RCCL exercised on a 1-GPU box)
+
+
+def _collectives_live():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+def init_from_env(backend=None, force=False):
     """-> (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as set by
-    torch.distributed.run; backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU."""
+    torch.distributed.run; backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU.  `force`: create the group for a single
+    rank as well and send its (identity) all-reduces through the back end."""
+    global FORCE_COLLECTIVES
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    FORCE_COLLECTIVES = bool(force)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -41,7 +51,7 @@ def shard_ray_idx(ray_idx, rank, world):
 
 def all_reduce_sum_(t):
     """In-place SUM over ranks (identity without a process group): the [B,16] Kabsch moments of the alignment loss."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_live():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -87,7 +97,7 @@ class GradBucket:
         return self.flat
 
     def all_reduce(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _collectives_live():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.flat
 

@@ -19,7 +19,9 @@ reference implementation lives in the absent third-party package roma==1.4.1
 algorithm and is marked "parity unpinned".
 
 Every function cites the reference file:line it follows (paths relative to the
-reference repository root).  All tensors are fp32 on CPU.
+reference repository root).  All tensors are fp32; the functions follow the device of their inputs, so the
+same restatement can be run on the GPU by torch's own ROCm kernels (tests at BASELINE shapes, bench.py's
+`torch_rocm_baseline`) -- still the checker / a reported baseline, never the product path.
 """
 from __future__ import annotations
 
@@ -130,10 +132,10 @@ def make_latent(seed: int, n_views: int, dim: int = WARP_LAT) -> Tensor:
 # R1 / R2 / R3: ray generation
 # --------------------------------------------------------------------------------------
 
-def pixel_grid(H: int, W: int) -> Tensor:
+def pixel_grid(H: int, W: int, device=None) -> Tensor:
     """Pixel-centre grid, index = y*W + x; camera.py:369-374."""
-    y = torch.arange(H, dtype=torch.float32) + 0.5
-    x = torch.arange(W, dtype=torch.float32) + 0.5
+    y = torch.arange(H, dtype=torch.float32, device=device) + 0.5
+    x = torch.arange(W, dtype=torch.float32, device=device) + 0.5
     Y, X = torch.meshgrid(y, x, indexing="ij")
     return torch.stack([X, Y], dim=-1).reshape(-1, 2)
 
@@ -164,7 +166,7 @@ def unwarped_center_and_grid(H: int, W: int, intr: Tensor, ray_idx: Optional[Ten
                              pose_init: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """R1: camera.py:359-390 (get_unwarped_center_and_ray)."""
     B = intr.shape[0]
-    xy = pixel_grid(H, W).repeat(B, 1, 1)
+    xy = pixel_grid(H, W, intr.device).repeat(B, 1, 1)
     grid = img2cam(_hom(xy), intr)
     center = torch.zeros_like(grid)
     if pose_init is not None:
@@ -178,7 +180,7 @@ def unwarped_center_and_grid(H: int, W: int, intr: Tensor, ray_idx: Optional[Ten
 def center_and_ray(H: int, W: int, pose: Tensor, intr: Tensor) -> Tuple[Tensor, Tensor]:
     """R2: camera.py:419-443 (get_center_and_ray); pose is world->camera."""
     B = pose.shape[0]
-    xy = pixel_grid(H, W).repeat(B, 1, 1)
+    xy = pixel_grid(H, W, intr.device).repeat(B, 1, 1)
     grid = img2cam(_hom(xy), intr)
     center = torch.zeros_like(grid)
     grid = cam2world(grid, pose)
@@ -225,11 +227,11 @@ def warp_embed(x: Tensor, alpha_ratio: float, n_freq: int = WARP_MULTIRES, refer
             scale[(2 * i + 1) * d:(2 * i + 3) * d] *= w[i]
         shape = [1] * out.dim()
         shape[1] = out.shape[1]
-        return out * scale.view(shape)
+        return out * scale.view(shape).to(out.device)
     cw = torch.ones(out.shape[-1], dtype=out.dtype)
     for i in range(n_freq):
         cw[(2 * i + 1) * d:(2 * i + 3) * d] = w[i]
-    return out * cw
+    return out * cw.to(out.device)
 
 
 def _wn_weight(p: Params, name: str) -> Tensor:
@@ -327,7 +329,7 @@ def sample_depth(u, S: int, depth_range: Sequence[float], param: str) -> Tensor:
     """S1: Graph.sample_depth, model/nerf.py:334-344.  `u` is the stratified draw [B,R,S,1]
     (torch.rand in the reference) or the float 0.5."""
     lo, hi = depth_range
-    r = u + torch.arange(S, dtype=torch.float32)[None, None, :, None]
+    r = u + torch.arange(S, dtype=torch.float32, device=getattr(u, "device", None))[None, None, :, None]
     d = r / S * (hi - lo) + lo
     if param == "metric":
         return d
@@ -354,11 +356,11 @@ def c2f_weights(progress: float, barf_c2f: Optional[Sequence[float]], L: int) ->
 def positional_encoding(x: Tensor, L: int, band_w: Optional[Tensor] = None) -> Tensor:
     """P1: NeRF.positional_encoding, model/nerf.py:476-483 (+ c2f mask barf_inn_llff.py:437-439).
     Layout per coordinate: [sin f0..f(L-1), cos f0..f(L-1)]."""
-    freq = 2 ** torch.arange(L, dtype=torch.float32) * np.pi
+    freq = (2 ** torch.arange(L, dtype=torch.float32) * np.pi).to(x.device)       # (formed on the host: the same fp32 table everywhere)
     spec = x[..., None] * freq
     enc = torch.stack([spec.sin(), spec.cos()], dim=-2)
     if band_w is not None:
-        enc = enc * band_w
+        enc = enc * band_w.to(x.device)
     return enc.reshape(*x.shape[:-1], -1)
 
 
@@ -430,10 +432,10 @@ def sample_depth_from_pdf(pdf: Tensor, S: int, Sf: int, depth_range: Sequence[fl
     lo, hi = depth_range
     cdf = pdf.cumsum(dim=-1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
-    g = torch.linspace(0, 1, Sf + 1)
-    unif = (0.5 * (g[:-1] + g[1:])).repeat(*cdf.shape[:-1], 1)
+    g = torch.linspace(0, 1, Sf + 1)                                            # (host linspace, then moved: one table on every device)
+    unif = (0.5 * (g[:-1] + g[1:])).to(pdf.device).repeat(*cdf.shape[:-1], 1)
     idx = torch.searchsorted(cdf, unif, right=True)
-    bins = torch.linspace(lo, hi, S + 1).repeat(*cdf.shape[:-1], 1)
+    bins = torch.linspace(lo, hi, S + 1).to(pdf.device).repeat(*cdf.shape[:-1], 1)
     il, ih = (idx - 1).clamp(min=0), idx.clamp(max=S)
     dl, dh = bins.gather(2, il), bins.gather(2, ih)
     cl, ch = cdf.gather(2, il), cdf.gather(2, ih)

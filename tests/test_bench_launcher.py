@@ -1,0 +1,54 @@
+"""bench.py must be able to start its own ranks: `python bench.py --gpus N` with no rank environment re-launches itself under
+torch.distributed.run as a CHILD process, from a parent that has not imported torch (the GPU box refuses an exec or a
+fork from a GPU-initialised process).  CPU-only checks of that decision; the ranks themselves need a GPU."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_launcher_decision():
+    import bench
+    assert bench.needs_launcher(8, {})                                   # the driver's `python bench.py --gpus 8`
+    assert not bench.needs_launcher(1, {})                               # one GPU: run in place
+    assert not bench.needs_launcher(8, {"WORLD_SIZE": "8", "RANK": "3"})  # already a rank of torch.distributed.run
+    assert not bench.needs_launcher(2, {"RANK": "0"})
+
+
+def test_launcher_command_line():
+    import bench
+    argv = ["--gpus", "4", "--steps", "7", "--config", "cfg3"]
+    cmd = bench.launcher_command(4, argv, port=29876)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29876"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv
+
+
+def test_parent_does_not_import_torch_and_propagates_the_exit_code(tmp_path):
+    """The parent of a `--gpus 2` run: replaces torch.distributed.run by a stub module that records its arguments and exits 7; the
+    parent must hand the arguments over unchanged, never import torch, and exit with the child's code."""
+    stub = tmp_path / "torch" / "distributed"
+    stub.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (stub / "__init__.py").write_text("")
+    (stub / "run.py").write_text("import sys, json, os\n"
+                                 "open(os.environ['NIW_STUB_OUT'], 'w').write(json.dumps(sys.argv[1:]))\n"
+                                 "sys.exit(7)\n")
+    out = tmp_path / "argv.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(tmp_path), NIW_STUB_OUT=str(out))
+    probe = ("import sys, runpy\n"
+             "sys.argv = ['bench.py', '--gpus', '2', '--steps', '3', '--lean']\n"
+             "try:\n"
+             "    runpy.run_path(%r, run_name='__main__')\n"
+             "except SystemExit as e:\n"
+             "    assert 'torch.cuda' not in sys.modules and 'torch._C' not in sys.modules, 'parent initialised torch'\n"
+             "    sys.exit(e.code)\n" % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stdout, r.stderr)
+    import json
+    argv = json.loads(out.read_text())
+    assert "--nproc-per-node=2" in argv and argv[-5:] == ["--gpus", "2", "--steps", "3", "--lean"]

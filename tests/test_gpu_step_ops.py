@@ -266,3 +266,75 @@ def test_hip_graph_capture_after_a_resume_at_a_late_iteration():
         assert abs(a - b) <= 2e-4 * max(abs(a), 1e-3)
     for fa, fb in zip(eager._flats(), graph._flats()):
         assert (fa - fb).abs().max() <= 5e-4 * fa.abs().max()
+
+
+def test_eval_render_under_hip_graph_uses_the_host_bands_not_the_step_buffer():
+    """Round 2 advisor finding: with hip_graph=True the networks kept pointing at the device-resident step constants, so a render
+    outside a train iteration read the c2f bands / annealing windows of the LAST train step (all zeros before the first one).  A
+    full-image render and a gradient-free warped-pose render of a graph-mode trainer must equal those of an eager trainer in the
+    same state: before the first step, and after 5 steps (3 of them replays)."""
+    from neural_invertible_warp_amd import configs, engine, evaluation
+
+    def build(hip_graph):
+        opt = configs.cfg3_barf_inn_llff(device=DEV)
+        opt.H, opt.W = 12, 16
+        opt.nerf.sample_stratified = False
+        opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = 5 * 16, 32, 20        # progress moves through the c2f window [0.1, 0.5]
+        opt.inn.real_nvp.max_pe_iter = 10
+        var0 = engine.synthetic_scene(opt, 5)
+        return opt, var0, engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=5, hip_graph=hip_graph)
+
+    def renders(opt, var0, tr):
+        with torch.no_grad():
+            pose = torch.eye(3, 4, device=DEV)[None]
+            img = tr.graph.render_by_slices(opt, pose, intr=var0.intr[:1], mode="val")
+            ray_idx = torch.arange(0, opt.H * opt.W, 7, device=DEV)
+            val = tr.graph.render(opt, pose, intr=var0.intr[:1], ray_idx=ray_idx, mode="val")
+            # the learnt camera poses (warp of the pixel grid with the annealing window of the CURRENT iteration, then registration)
+            learnt, _ = evaluation.LLFFEvaluator(opt, tr.graph, var0.pose).get_all_training_poses(opt)
+        return img.rgb.clone(), val.rgb.clone(), learnt.clone()
+
+    (oe, ve, eager), (og, vg, graph) = build(False), build(True)
+    for steps in (0, 5):
+        for _ in range(steps):
+            eager.train_iteration(type(ve)(ve))
+            graph.train_iteration(type(vg)(vg))
+        if steps:
+            assert graph._captured is not None
+            assert 0.1 < graph.it / og.max_iter < 0.5, "the test must sit inside the c2f window"
+        for a, b in zip(renders(oe, ve, eager), renders(og, vg, graph)):
+            assert bool(torch.isfinite(b).all())
+            assert (a - b).abs().max() < (1e-6 if steps == 0 else 2e-3), (steps, float((a - b).abs().max()))
+        for n in graph.nets:
+            assert n.band_dev is None
+        assert graph.warp_mlp.window_dev is None and graph.graph.draw_dev is None
+
+
+def test_hip_graph_replay_refuses_or_refreshes_inputs_it_was_not_captured_with():
+    """Round 2 advisor finding: a replay reads the tensors saved at capture time and used to ignore the `var` it was handed.  Same
+    data in new storage is copied into the captured tensors (training continues on the NEW values); another shape is an error."""
+    from neural_invertible_warp_amd import configs, engine
+    from neural_invertible_warp_amd._lib import NiwError
+    opt = configs.cfg3_barf_inn_llff(device=DEV)
+    opt.H, opt.W = 12, 16
+    opt.nerf.sample_stratified = False
+    opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = 5 * 16, 32, 40
+    var0 = engine.synthetic_scene(opt, 5)
+    tr = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=5, hip_graph=True)
+    for _ in range(3):
+        tr.train_iteration(type(var0)(var0))
+    assert tr._captured is not None
+    # a constant image in NEW storage: the photometric loss of the next replay must be that of the new image
+    var1 = type(var0)(var0)
+    var1.image = torch.full_like(var0.image, 0.25)
+    assert var1.image.data_ptr() != var0.image.data_ptr()
+    loss_new = float(tr.train_iteration(var1).render.detach())
+    ref = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=5, hip_graph=False)
+    for _ in range(3):
+        ref.train_iteration(type(var0)(var0))
+    loss_ref = float(ref.train_iteration(type(var1)(var1)).render.detach())
+    assert abs(loss_new - loss_ref) <= 2e-3 * loss_ref, (loss_new, loss_ref)
+    var2 = type(var0)(var0)
+    var2.image = var0.image[:, :, :6].contiguous()
+    with pytest.raises(NiwError, match="captured iteration"):
+        tr.train_iteration(var2)

@@ -9,8 +9,12 @@ def test_parse_arguments_syntax():
                                  "--resume", "--cpu!", "--optim.lr=1.e-3", "--name=a=b"])
     assert o.model == "barf_inn_llff" and o.barf_c2f == [0.1, 0.5] and o.loss_weight.global_alignment == 4
     assert o.data.root is None and o.resume is True and o.cpu is False and o.optim.lr == 1e-3 and o.name == "a=b"
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError):
         options.parse_arguments(["model=x"])
+    with pytest.raises(ValueError, match="twice"):
+        options.parse_arguments(["--seed=1", "--seed=2"])
+    with pytest.raises(ValueError):
+        options.parse_arguments(["--optim=3", "--optim.lr=1"])
 
 
 def test_builtin_tree_and_overrides(tmp_path):
