@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import niw_oracle as O
-from tests.util import golden, t, check_grad_summary
+from tests.util import golden, t, check_grad_summary, check_grad_vs_fp64
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -291,12 +291,9 @@ def test_inn_train_step_dtu_golden():
     close(loss.render, gd["loss_render"], atol=1e-6)
     assert float(loss.global_alignment.detach()) >= 0            # detached Kabsch pose (nerf_inn_dtu.py:410-414)
     loss.render.backward()
-    for k, prm in graph.nerf.named_parameters():
-        if f"grad.{k}.norm" in gd:
-            check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=0.15)     # all bands active: see test_oracle_golden
-    for k, prm in pose_net.pose_embedding.named_parameters():
-        check_grad_summary(prm.grad, gd, f"grad.pose_embedding.{k}", rtol=0.15)
-    check_grad_summary(pose_net.pose_latent.weight.grad, gd, "grad.pose_latent.weight", rtol=0.15)
+    # gradients against the reference's FLOAT64 gradients of this step (inn_step_cfg5_fp64.npz) under the conditioning bound of
+    # tests/util.fp64_bound: all ten bands active, so any fp32 evaluation -- the reference's own included -- scatters at the percent level
+    _check_dtu_grads_vs_fp64(graph, pose_net, "cfg5")
 
 
 def test_inn_train_step_dtu_c2f_golden():
@@ -327,15 +324,28 @@ def test_inn_train_step_dtu_c2f_golden():
     loss = graph.compute_loss(opt, var, mode="train")
     close(loss.render, gd["loss_render"], atol=1e-6)
     loss.render.backward()
+    # every gradient against the reference's FLOAT64 gradient (inn_step_cfg5_fp64.npz), bound 2.3 % of max = 16 x the median
+    # deviation of the reference's own fp32 gradients from them (tests/util.fp64_bound); rounds 1-2 held the pose network to 15 % / 60 %
+    # of ONE fp32 evaluation.  The NeRF tensors are additionally held to 1e-2 of the reference's fp32 sample, as before.
     for k, prm in graph.nerf.named_parameters():
         if f"grad.{k}.norm" in gd:
             check_grad_summary(prm.grad, gd, f"grad.{k}", rtol=1e-2)
-    # warp gradients: world-scale inputs amplify fp32 roundoff to percent level in ANY fp32 evaluation (see test_oracle_golden)
+    _check_dtu_grads_vs_fp64(graph, pose_net, "cfg5_c2f")
+
+
+def _check_dtu_grads_vs_fp64(graph, pose_net, tag):
+    fx = golden("inn_step_cfg5_fp64")
+    rows = []
+    for k, prm in graph.nerf.named_parameters():
+        if f"{tag}.grad64.{k}.norm" in fx:
+            rows.append((k,) + check_grad_vs_fp64(prm.grad, fx, tag, k))
     for k, prm in pose_net.pose_embedding.named_parameters():
-        check_grad_summary(prm.grad, gd, f"grad.pose_embedding.{k}", rtol=0.15 if prm.numel() > 16 else 0.6)
-        if prm.numel() > 16:
-            assert abs(float(prm.grad.norm()) - float(gd[f"grad.pose_embedding.{k}.norm"])) <= 2e-2 * float(gd[f"grad.pose_embedding.{k}.norm"]), k
-    check_grad_summary(pose_net.pose_latent.weight.grad, gd, "grad.pose_latent.weight", rtol=0.05)
+        rows.append((k,) + check_grad_vs_fp64(prm.grad, fx, tag, f"pose_embedding.{k}"))
+    rows.append(("pose_latent.weight",) + check_grad_vs_fp64(pose_net.pose_latent.weight.grad, fx, tag, "pose_latent.weight"))
+    worst = max(rows, key=lambda r: r[1])
+    errs = sorted(r[1] for r in rows)
+    print(f"{tag}: HIP fp32 gradients vs the reference's float64 gradients over {len(rows)} tensors: median {errs[len(errs) // 2]:.2e}, "
+          f"worst {worst[1]:.2e} ({worst[0]}) of max; bound {worst[2]:.2e}")
 
 
 @pytest.mark.parametrize("tag", ["cfg3", "cfg2"])

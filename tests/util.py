@@ -53,3 +53,32 @@ class TorchAlign:
         from neural_invertible_warp_amd import camera
         e = target - camera.cam2world(source, poses.detach())
         return (e ** 2).sum() / float(n_norm if n_norm is not None else e.numel())
+
+
+def fp64_bound(fx, tag, key, floor=1e-3, factor=16.0):
+    """Tolerance for ONE fp32 evaluation of gradient `key` of the DTU step `tag` against the reference's float64 gradient
+    (tests/golden/inn_step_cfg5_fp64.npz, make_golden_dtu_fp64.py), relative to the gradient's scale (below).
+
+    The DTU pose network warps world points 3-4 units from the origin; its 2^5 pi band and the field's 2^9 pi band turn fp32 roundoff
+    into 1e-3 .. 1e-2 differences between ANY two fp32 evaluations of these gradients.  `<tag>.cond.<key>` records one sample of that
+    spread -- the deviation of the REFERENCE's own fp32 gradient from its float64 gradient; the oracle's fp32 evaluation (which in
+    float64 reproduces the reference's float64 gradients to 4e-8, tests/test_oracle_golden.py) is another and sits up to 10x further
+    out on single tensors.  Bound = `factor` x the median of the reference's deviations over all parameter tensors of the step +
+    `floor` (c2f step: 16 x 1.4e-3 + 1e-3 = 2.3 % of max; all ten bands active: 16 x 7.9e-3 = 12.8 %)."""
+    same = [float(v) for k, v in fx.items() if k.startswith(f"{tag}.cond.")]
+    return factor * float(np.median(same)) + floor
+
+
+def check_grad_vs_fp64(grad, fx, tag, key, **kw):
+    """-> (error, bound) of one fp32 gradient against the reference's float64 one; asserts error <= bound on the strided sample.
+    Scale of the comparison: max |g64| of the tensor -- for the 1- and 3-element head biases of the pose network (sums that cancel:
+    `lin2_a_1.bias` of the c2f step is 3 % of its layer's weight gradient) the max |g64| of the same layer's WEIGHT gradient."""
+    assert grad is not None, key
+    f = grad.detach().reshape(-1).double().cpu()
+    sample, stride = fx[f"{tag}.grad64.{key}.sample"].astype(np.float64), int(fx[f"{tag}.grad64.{key}.stride"])
+    bound = fp64_bound(fx, tag, key, **kw)
+    scale_key = key[:-len("bias")] + "weight" if (key.endswith("_1.bias") and f.numel() <= 16) else key
+    scale = max(float(fx[f"{tag}.grad64.{key}.amax"]), float(fx[f"{tag}.grad64.{scale_key}.amax"]), 1e-300)
+    err = float(np.abs(f[::stride].numpy() - sample).max()) / scale
+    assert err <= bound, f"{tag} {key}: {err:.3e} of scale from the float64 gradient, bound {bound:.3e}"
+    return err, bound
