@@ -132,6 +132,14 @@ int niw_composite_bwd(const float* ray, const float* rgb_s, const float* sigma_s
 int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, float depth_min, float depth_max,
                           int inverse, float* depth, niw_stream_t stream);
 
+/* The same with the stratified draw made inside the kernel (the reference draws torch.rand on the device at this point,
+ * model/nerf.py:337): u = Philox4x32-10(key = seed, counter = (sample index / 4, draw)) -> 24-bit uniform in [0,1).  `draw` numbers
+ * the draw (the training iteration: a resumed run continues the same stream); a non-NULL draw_dev (one uint64 in device memory)
+ * overrides it at run time (captured-graph replays).  u_out (optional, [n_rays,S]) receives the draws, so that a checker can
+ * reproduce the depths with niw_sample_stratified / the oracle. */
+int niw_sample_stratified_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n_rays, int n_samples,
+                              float depth_min, float depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream);
+
 /* Graph.sample_depth_from_pdf (model/nerf.py:346-365) followed by the cat + ascending sort of
  * Graph.render (model/nerf.py:313-315).  pdf [n_rays,S], depth_coarse [n_rays,S];
  * unif [Sf] = mid-points of linspace(0,1,Sf+1) (nerf.py:352-353) and bins [S+1] =

@@ -42,6 +42,7 @@ SIGNATURES = {
     "niw_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "niw_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_sample_stratified": (_i, [_vp, _i64, _i, _f, _f, _i, _vp, _vp]),
+    "niw_sample_stratified_rng": (_i, [_u64, _u64, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _vp]),
     "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "niw_raygen": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "niw_draw_ray_idx": (_i, [_i64, _i64, _u64, _u64, _vp, _i64, _i64, _vp, _vp]),

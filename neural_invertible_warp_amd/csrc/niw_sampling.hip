@@ -18,6 +18,42 @@ __global__ void sample_stratified_kernel(const float* __restrict__ u, long long 
     depth[i] = d;
 }
 
+// The same with the stratified draw made IN the kernel (the reference calls torch.rand on the device inside the
+// path, nerf.py:337).  Philox4x32-10 (Salmon et al., SC'11), counter = (index of the group of four consecutive samples, draw number),
+// key = seed: every group of four samples owns one counter value, so the stream is a pure function of (seed, draw, sample index) --
+// reproducible, resumable by the iteration number, independent of the launch geometry, and replayable from a captured graph with the
+// draw number read from device memory.  u = the upper 24 bits * 2^-24, in [0, 1) like torch.rand's float32.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ void sample_stratified_rng_kernel(unsigned long long seed, unsigned long long draw, const unsigned long long* __restrict__ draw_dev,
+                                             long long n, int S, float dmin, float dmax, int inverse, float* __restrict__ depth,
+                                             float* __restrict__ u_out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group of four consecutive samples
+    if (4 * g >= n) return;
+    if (draw_dev) draw = *draw_dev;
+    unsigned c[4] = {(unsigned)g, (unsigned)(g >> 32), (unsigned)draw, (unsigned)(draw >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long long i = 4 * g + t;
+        if (i >= n) break;
+        const float u = (float)(c[t] >> 8) * 5.9604644775390625e-08f;           // 2^-24
+        const float r = u + (float)(int)(i % S);
+        float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)S), dmax - dmin), dmin);
+        if (inverse) d = __fdiv_rn(1.f, niw::add_rn(d, 1e-8f));
+        depth[i] = d;
+        if (u_out) u_out[i] = u;
+    }
+}
+
 // ---------------------------------------------------------------- H1 + H2: nerf.py:346-365, 313-315
 // One wave per ray.  cdf in LDS (accumulated sequentially in fp64 and rounded per element, the
 // arithmetic of the CPU reference's cumsum), Sf binary searches, then a rank sort of the S+Sf
@@ -235,6 +271,17 @@ extern "C" int niw_sample_stratified(const float* u, int64_t n_rays, int n_sampl
     const long long n = n_rays * (long long)n_samples;
     sample_stratified_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, n, n_samples, depth_min, depth_max, inverse, depth);
     NIW_LAUNCH_CHECK("niw_sample_stratified");
+    return NIW_OK;
+}
+
+extern "C" int niw_sample_stratified_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n_rays, int n_samples,
+                                         float depth_min, float depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream) {
+    NIW_REQUIRE(depth, "niw_sample_stratified_rng: null output");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_sample_stratified_rng: empty input");
+    const long long n = n_rays * (long long)n_samples, groups = (n + 3) / 4;
+    sample_stratified_rng_kernel<<<(int)((groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        seed, draw, reinterpret_cast<const unsigned long long*>(draw_dev), n, n_samples, depth_min, depth_max, inverse, depth, u_out);
+    NIW_LAUNCH_CHECK("niw_sample_stratified_rng");
     return NIW_OK;
 }
 

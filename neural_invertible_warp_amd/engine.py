@@ -123,6 +123,9 @@ class INNTrainer:
         self.it = 0
         on_gpu = torch.device(opt.device).type == "cuda"
         opt.nerf.ray_sampler = ray_sampler or opt.nerf.get("ray_sampler") or ("feistel" if on_gpu else "randperm")
+        # stratified depth draws: inside the kernel (Philox) wherever the engine makes its own pixel draw; a harness that injects the
+        # reference's torch.randperm / torch.rand draws (ray_sampler="randperm") keeps torch.rand
+        opt.nerf.stratified_rng = opt.nerf.get("stratified_rng") or ("philox" if opt.nerf.ray_sampler == "feistel" else "torch")
         self.hip_graph = bool(hip_graph) and on_gpu
         self._captured = None
         if self.hip_graph:
@@ -246,6 +249,8 @@ class INNTrainer:
 
     def _graph_iteration(self, var, it, replay=True):
         self._upload_constants(it)
+        if self._captured is not None and replay:
+            self._check_static_inputs(var)             # (a capture made in THIS call replays the var it has just recorded)
         if self._captured is None or not replay:
             self._eager_runs = getattr(self, "_eager_runs", 0)
             if not replay or self._eager_runs < 2 or not self._capture(var, it):
@@ -262,7 +267,6 @@ class INNTrainer:
                 torch.cuda.current_stream().wait_stream(side)
                 return loss
         fb, adam, loss = self._captured
-        self._check_static_inputs(var)
         fb.replay()
         if adam is not None:                           # ranks exchange gradients between the two graphs
             self.bucket.all_reduce()

@@ -336,6 +336,15 @@ class Graph(_BaseGraph):
         rng = opt.nerf.depth.range if depth_range is None else depth_range
         num_rays = num_rays or opt.H * opt.W
         S = opt.nerf.sample_intvs
+        if opt.nerf.sample_stratified and opt.nerf.get("stratified_rng") == "philox":
+            # the draw happens inside the kernel (what the engine selects): stream keyed by (opt.seed, iteration of the draw, a
+            # counter of the sample_depth calls inside that iteration), replayable from a captured graph through `draw_dev`
+            self._depth_calls = getattr(self, "_depth_calls", 0) + 1
+            rank = (getattr(opt, "ray_shard", None) or (0, 1))[0]            # ranks render different rays: different streams
+            stream_seed = (int(getattr(opt, "seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5D1F + rank * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+            d = ops.sample_stratified_rng(stream_seed, getattr(self, "_depth_draw", self._depth_calls), batch_size * num_rays, S, rng,
+                                          opt.nerf.depth.param, opt.device, draw_dev=getattr(self, "draw_dev", None))
+            return d.view(batch_size, num_rays, S, 1)
         u = torch.rand(batch_size, num_rays, S, 1, device=opt.device) if opt.nerf.sample_stratified else None
         d = ops.sample_stratified(None if u is None else u.view(-1, S), batch_size * num_rays, S, rng, opt.nerf.depth.param, opt.device)
         return d.view(batch_size, num_rays, S, 1)

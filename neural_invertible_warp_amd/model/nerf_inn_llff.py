@@ -76,9 +76,10 @@ class Graph(nerf.Graph):
         ranks' default generators drift apart as soon as their stratified draws differ in size."""
         n = opt.nerf.rand_rays // batch_size
         rank, world = getattr(opt, "ray_shard", None) or (0, 1)
+        self._ray_draws = getattr(self, "_ray_draws", 0) + 1
+        number = self._ray_draws if draw is None else int(draw) + 1
+        self._depth_draw = number                  # the in-kernel stratified draw of this forward uses the same number (nerf.Graph.sample_depth)
         if opt.nerf.get("ray_sampler", "randperm") == "feistel":
-            self._ray_draws = getattr(self, "_ray_draws", 0) + 1
-            number = self._ray_draws if draw is None else int(draw) + 1
             return ops.draw_ray_idx(opt.H * opt.W, len(range(rank, n, world)), int(getattr(opt, "seed", 0) or 0), number, opt.device,
                                     first=rank, stride=world, draw_dev=getattr(self, "draw_dev", None))
         if world == 1:

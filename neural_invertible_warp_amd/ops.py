@@ -135,6 +135,18 @@ def sample_stratified(u, n_rays, S, depth_range, param, device):
     return out
 
 
+def sample_stratified_rng(seed, draw, n_rays, S, depth_range, param, device, draw_dev=None, return_u=False):
+    """Graph.sample_depth with the stratified draw made inside the kernel (niw_sample_stratified_rng: Philox keyed by `seed`,
+    counter = (sample, `draw`); `draw_dev` = uint64 device word overriding `draw` at run time) -> depth [n_rays,S] (, u)."""
+    if param not in ("metric", "inverse"):
+        raise KeyError(param)
+    out = torch.empty(n_rays, S, device=device, dtype=torch.float32)
+    u = torch.empty(n_rays, S, device=device, dtype=torch.float32) if return_u else None
+    _lib.call("niw_sample_stratified_rng", int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1), _p(draw_dev), n_rays, S,
+              float(depth_range[0]), float(depth_range[1]), 1 if param == "inverse" else 0, _p(out), _p(u), _stream())
+    return (out, u) if return_u else out
+
+
 _table_cache = {}
 
 

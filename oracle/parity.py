@@ -67,3 +67,84 @@ def psnr_trajectories(dev, steps=25, B=3, H=12, W=16, R=16, S=32, seed=7):
     finally:
         torch.rand, torch.randperm = rand, perm
     return psnr_gpu, psnr_cpu
+
+
+def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4, seed=0, draw_seed=0, oracle=True, log_every=50):
+    """Long-horizon parity on the demo scene (tools/teacher_student_demo.py: analytic density blobs rendered from perturbed poses,
+    training starts from identity poses): `steps` chained iterations of barf_inn_llff WITH the alignment term on
+      * the HIP engine (engine.INNTrainer: fused kernels, niw_adam_step), and
+      * the oracle (autograd + torch.optim.Adam) run on `dev` through torch's own kernels,
+    from identical weights, with identical pixel draws and stratified draws (numpy stream `draw_seed`).  fp32 trajectories of a
+    non-convex optimisation separate chaotically, so the yardstick is the spread between HIP runs that differ ONLY in `draw_seed`.
+    -> dict(it=[...], hip=dict(psnr=[...], rel_rot=[...]), oracle=dict(...))   (rel_rot: pairwise relative rotation error in degrees of
+    the poses registered from the step's warped points, against the scene's ground truth)"""
+    from neural_invertible_warp_amd import camera, configs, engine
+    from neural_invertible_warp_amd.util import edict
+    from tools.teacher_student_demo import render_teacher
+    H, W = size
+    B = views
+    opt = configs.cfg3_barf_inn_llff(device=dev, global_alignment=ga)
+    opt.H, opt.W, opt.data.image_size = H, W, [H, W]
+    opt.max_iter = steps
+    opt.nerf.sample_intvs, opt.nerf.rand_rays = S, R * B
+    opt.inn.real_nvp.max_pe_iter = steps // 2
+    gen = torch.Generator().manual_seed(seed)
+    pose_GT = camera.lie.se3_to_SE3(torch.randn(B, 6, generator=gen) * torch.tensor([0.06, 0.06, 0.03, 0.15, 0.15, 0.05])).to(dev)
+    intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(B, 1, 1).to(dev)
+    image = render_teacher(opt, pose_GT, intr)
+    tr = engine.INNTrainer(opt, B, warp_perturb=0.0, ray_sampler="randperm", seed=seed)
+    # identical initial weights on both sides: the oracle starts from a copy of the engine's (reference initialisation)
+    clone = lambda mod: {k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items() if k != "progress"}
+    pc, wp = clone(tr.graph.nerf), clone(tr.graph.warp_mlp)
+    lat = tr.graph.warp_latent.weight.detach().clone().requires_grad_(True)
+    o = opt.optim
+    opt_nerf = torch.optim.Adam(list(pc.values()), lr=o.lr)
+    opt_pose = torch.optim.Adam(list(wp.values()) + [lat], lr=o.lr_pose)
+    g_nerf = (o.lr_end / o.lr) ** (1.0 / opt.max_iter)
+    g_pose = (o.lr_pose_end / o.lr_pose) ** (1.0 / opt.max_iter)
+    Rg = pose_GT[:, :, :3]
+    rel_gt = Rg[:, None] @ Rg[None].transpose(-1, -2)
+
+    def rel_rot(grid_cam, center_cam, grid_3D, center_3D):
+        with torch.no_grad():
+            _, poses = O.global_alignment_loss(grid_cam.float(), center_cam.float(), grid_3D.float(), center_3D.float())
+            Rp = poses[:, :, :3]
+            rel = camera.rotation_distance(Rp[:, None] @ Rp[None].transpose(-1, -2), rel_gt)
+            return float(rel.sum() / (B * B - B)) * 57.29577951308232
+
+    rng = np.random.default_rng(1000 + draw_seed)
+    var0 = edict(idx=torch.arange(B), image=image, intr=intr)
+    out = dict(it=[], hip=dict(psnr=[], rel_rot=[]), oracle=dict(psnr=[], rel_rot=[]))
+    rand, perm = torch.rand, torch.randperm
+    try:
+        for it in range(steps):
+            u = torch.from_numpy(rng.uniform(0, 1, (B, R, S, 1)).astype(np.float32)).to(dev)
+            ray_idx = torch.from_numpy(rng.permutation(H * W)[:R].astype(np.int64)).to(dev)
+            log = (it % log_every == 0) or it == steps - 1
+            torch.rand, torch.randperm = (lambda *a, **k: u), (lambda *a, **k: ray_idx)
+            var = edict(var0)
+            loss = tr.train_iteration(var)
+            torch.rand, torch.randperm = rand, perm
+            if log:
+                out["it"].append(it)
+                out["hip"]["psnr"].append(psnr(float(loss.render.detach())))
+                out["hip"]["rel_rot"].append(rel_rot(var.grid_cam, var.center_cam, var.grid_3D, var.center))
+            if not oracle:
+                continue
+            prog = it / opt.max_iter
+            w3, wv = O.c2f_weights(prog, opt.barf_c2f, 10), O.c2f_weights(prog, opt.barf_c2f, 4)
+            for prm in list(pc.values()) + list(wp.values()) + [lat]:
+                prm.grad = None
+            ref = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", min(max(it / opt.inn.real_nvp.max_pe_iter, 0), 1),
+                                   ga_weight=ga, w3d=w3, wview=wv)
+            ref["loss"].backward()
+            for grp, lr0, gam in ((opt_nerf, o.lr, g_nerf), (opt_pose, o.lr_pose, g_pose)):
+                grp.param_groups[0]["lr"] = lr0 * gam ** it
+                grp.step()
+            if log:
+                cc, gc = O.unwarped_center_and_grid(H, W, intr, ray_idx)
+                out["oracle"]["psnr"].append(psnr(float(ref["loss_render"].detach())))
+                out["oracle"]["rel_rot"].append(rel_rot(gc, cc, ref["grid_3D"].detach(), ref["center"].detach()))
+    finally:
+        torch.rand, torch.randperm = rand, perm
+    return out

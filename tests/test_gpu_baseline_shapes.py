@@ -64,11 +64,18 @@ def _dev_params(seed_c, seed_w, seed_l, B, seed_f=None):
 
 
 def _compare_grads(named, ref, tol, report, prefix):
+    """every tensor relative to its own max |g|; the 1- and 3-element head biases of the warp (`*_1.bias`: sums over all points that
+    largely cancel -- 3 % of their layer's weight gradient in places) relative to the max of the same layer's WEIGHT gradient, the
+    scale of the terms they are summed from (tests/util.check_grad_vs_fp64 does the same)"""
     worst = 0.0
+    named = list(named)
     for k, prm in named:
         if k in ref and ref[k].grad is not None:
             assert prm.grad is not None, f"{prefix}{k}: no gradient on the HIP path"
             e = _rel(prm.grad, ref[k].grad)
+            if k.endswith("_1.bias") and prm.numel() <= 16:
+                w = ref[k[:-len("bias")] + "weight"].grad
+                e = float((prm.grad.detach() - ref[k].grad.detach()).abs().max() / torch.maximum(w.abs().max(), ref[k].grad.abs().max()))
             worst = max(worst, e)
             assert e < tol, f"{prefix}{k}: {e:.3e} of max, tolerance {tol}"
     report.append(f"{prefix}worst gradient error {worst:.2e} of max (tolerance {tol})")
@@ -99,7 +106,7 @@ def test_llff_train_step_at_baseline_shapes_vs_oracle_on_the_gpu(cfg):
         graph.warp_latent.weight.copy_(lat)
     image, intr, u, ray_idx = _inputs(B, R, S, seed=17)
     var = edict(idx=torch.arange(B), image=image, intr=intr)
-    with _Rng(u.view(B * R, S) if False else u, ray_idx):
+    with _Rng(u, ray_idx):
         var = graph.forward(opt, var, mode="train", iter=it)
     loss = graph.compute_loss(opt, var, mode="train")
     total = loss.render + (loss.render_fine if Sf else 0) + ((10.0 ** ga) * loss.global_alignment if ga is not None else 0)
@@ -117,10 +124,9 @@ def test_llff_train_step_at_baseline_shapes_vs_oracle_on_the_gpu(cfg):
     report.append(f"max |rgb - oracle| {float((var.rgb - ref['rgb']).abs().max()):.2e}")
     assert abs(float(loss.render.detach()) - float(ref["loss_render"].detach())) < 1e-6
     if Sf:
-        # The inverse-CDF positions are formed from a cumulative sum: this path uses the sequential fp64 sum of the CPU reference
-        # (pinned bit-near by the golden vectors), torch on the GPU a parallel fp32 scan; positions agree to fp32 rounding, and the
-        # 2^9 pi band turns that into a few 1e-5 on single rays -- the fine image is held to 1e-4 / 1e-3 and its loss to 1e-6.
-        torch.testing.assert_close(var.rgb_fine, ref["rgb_fine"], atol=1e-4, rtol=1e-3)
+        # (the inverse-CDF positions come from a cumulative sum -- here the sequential fp64 sum of the CPU reference, in torch on the
+        # GPU a parallel fp32 scan -- and still the fine image agrees at the coarse tolerance: measured 5.9e-6)
+        torch.testing.assert_close(var.rgb_fine, ref["rgb_fine"], atol=3e-5, rtol=2e-4)
         report.append(f"max |rgb_fine - oracle| {float((var.rgb_fine - ref['rgb_fine']).abs().max()):.2e}")
         assert abs(float(loss.render_fine.detach()) - float(ref["loss_render_fine"].detach())) < 1e-6
     if ga is not None:
@@ -175,8 +181,8 @@ def test_dtu_train_step_at_baseline_shape_vs_oracle_on_the_gpu():
     report = [f"cfg5: {B} x {R} x {S}, max |rgb - oracle| {float((var.rgb - ref['rgb']).abs().max()):.2e}"]
     _compare_grads(graph.nerf.named_parameters(), pc, 1e-2, report, "nerf.")
     # the pose network's gradients at world-scale inputs: see test_gpu_parity.test_inn_train_step_dtu_fp64 for the conditioning bound
-    _compare_grads(pose_net.pose_embedding.named_parameters(), wp, 5e-2, report, "pose_embedding.")
+    _compare_grads(pose_net.pose_embedding.named_parameters(), wp, 2e-2, report, "pose_embedding.")
     e = _rel(pose_net.pose_latent.weight.grad, lat.grad)
     report.append(f"pose_latent gradient error {e:.2e} of max")
-    assert e < 5e-2
+    assert e < 2e-2
     print("\n".join(report))
