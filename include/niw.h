@@ -53,10 +53,23 @@ const char* niw_last_error_string(void);
 
 enum niw_density_activ { NIW_ACT_RELU = 0, NIW_ACT_SOFTPLUS = 1 };
 
+/* Arithmetic of the field-MLP entry points (the `precision` argument; SURVEY section 8(b) "flags: exact-fp32 / bf16").
+ *   NIW_PREC_FP32    v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain.  The default everywhere, the mode of every headline number
+ *                    and of every parity claim at the reference's fp32 tolerance.
+ *   NIW_PREC_BF16X3  opt-in: every operand carried as two bf16 planes (16 significand bits), a product formed as
+ *                    hi*hi + hi*mid + mid*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (3/16 of the matrix-pipe time).
+ *   NIW_PREC_BF16    opt-in: the leading bf16 plane only (1/16 of the matrix-pipe time; SURVEY 8(c)'s bf16 tolerance class).
+ * A packed-weight image belongs to ONE precision class: fp32 images (niw_mlp_pack_weights*) for NIW_PREC_FP32, the split image of
+ * niw_mlp_pack_weights_prec for the two bf16 modes (one image serves both). */
+enum niw_precision { NIW_PREC_FP32 = 0, NIW_PREC_BF16X3 = 1, NIW_PREC_BF16 = 2 };
+
 /* Mpad: number of (ray,sample) rows rounded up to the 128-row workgroup tile. */
 int64_t niw_mlp_padded_rows(int64_t n_rays, int n_samples);
 /* floats of the packed-weight buffer written by niw_mlp_pack_weights */
 int64_t niw_mlp_packed_floats(void);
+/* bytes of the packed-weight image of a precision class (NIW_PREC_FP32: 4 * niw_mlp_packed_floats()), and its builder */
+int64_t niw_mlp_packed_bytes(int precision);
+int niw_mlp_pack_weights_prec(const float* params, int precision, void* packed, niw_stream_t stream);
 /* floats of the split-M partial-sum workspace used by niw_mlp_bwd */
 int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples);
 
@@ -81,10 +94,11 @@ int niw_mlp_pack_weights_indexed(const float* params, const int32_t* index, floa
  *   noise        [n_rays*n_samples] or NULL (density_noise_reg * randn, nerf.py:428-429)
  *   rgb [n_rays,n_samples,3], sigma [n_rays,n_samples]  (outputs)
  *   save         [NIW_SAVE_ROWS, Mpad] or NULL; non-NULL = training mode (activations kept
- *                for niw_mlp_bwd). */
+ *                for niw_mlp_bwd; the same fp32 workspace in every precision mode).
+ *   precision    enum niw_precision; `packed` must be the image of that class */
 int niw_mlp_fwd(const float* packed, const float* center, const float* ray,
                 const float* depth, const float* noise, int64_t n_rays, int n_samples,
-                const float* band_w3d, const float* band_wview, const float* band_dev, int density_activ,
+                const float* band_w3d, const float* band_wview, const float* band_dev, int density_activ, int precision,
                 float* rgb, float* sigma, float* save, niw_stream_t stream);
 
 /* Backward of niw_mlp_fwd (autograd of model/nerf.py:416-456).
@@ -92,23 +106,23 @@ int niw_mlp_fwd(const float* packed, const float* center, const float* ray,
  *   save: the buffer niw_mlp_fwd filled; gradws [NIW_GRAD_ROWS, Mpad] scratch;
  *   partial: niw_mlp_bwd_workspace_floats() scratch
  *   d_params [NIW_NERF_PARAM_FLOATS]: OVERWRITTEN with dL/dparams (state-dict order)
- *   d_center, d_ray [n_rays,3] or both NULL: ACCUMULATED (+=) gradients w.r.t. the rays
- *   (three routes of SURVEY section 8a: sample points and view directions; the ray-length
- *   route belongs to niw_composite_bwd). */
+ *   d_center, d_ray [n_rays,3] or both NULL: OVERWRITTEN with the gradients w.r.t. the rays -- per-sample terms summed per
+ *   ray in a fixed order, bit-reproducible from run to run (two of the three routes of SURVEY section 8a: sample points
+ *   and view directions; the ray-length route belongs to niw_composite_bwd). */
 int niw_mlp_bwd(const float* packed, const float* center, const float* ray,
-                const float* depth, int64_t n_rays, int n_samples, int density_activ,
+                const float* depth, int64_t n_rays, int n_samples, int density_activ, int precision,
                 const float* rgb, const float* d_rgb, const float* d_sigma,
                 const float* save, float* gradws, float* partial,
                 float* d_params, float* d_center, float* d_ray, niw_stream_t stream);
 
 /* The two passes of niw_mlp_bwd as separate entry points (niw_mlp_bwd = dx then dw):
- *   niw_mlp_bwd_dx: the register-chained dX chain; writes every dY into gradws, accumulates d_center/d_ray;
+ *   niw_mlp_bwd_dx: the register-chained dX chain; writes every dY into gradws, then d_center / d_ray (a second, small launch);
  *   niw_mlp_bwd_dw: dW = dY . X^T (split-M NT GEMMs on the fp32 MFMA path) + deterministic reduction. */
 int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
-                   int64_t n_rays, int n_samples, int density_activ,
+                   int64_t n_rays, int n_samples, int density_activ, int precision,
                    const float* rgb, const float* d_rgb, const float* d_sigma,
                    const float* save, float* gradws, float* d_center, float* d_ray, niw_stream_t stream);
-int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_rays, int n_samples, float* partial,
+int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_rays, int n_samples, int precision, float* partial,
                    float* d_params, niw_stream_t stream);
 
 /* ------------------------------------------------------------------ compositing
@@ -128,8 +142,11 @@ int niw_composite_bwd(const float* ray, const float* rgb_s, const float* sigma_s
                       float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream);
 
 /* ------------------------------------------------------------------ sampling
- * Graph.sample_depth (model/nerf.py:334-344).  u [n_rays,S] stratified draws or NULL (0.5). */
-int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, float depth_min, float depth_max,
+ * Graph.sample_depth (model/nerf.py:334-344).  u [n_rays,S] stratified draws or NULL (0.5).
+ * The range travels as doubles: the reference forms (depth_max - depth_min) from the yaml's Python floats in double precision and
+ * only then multiplies the fp32 tensor by it (5.2 - 1.2 is 4.0 that way, 3.9999998 when both ends are rounded to fp32 first); a range
+ * read from an fp32 tensor (DTU: var.depth_range) is exact in double either way. */
+int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, double depth_min, double depth_max,
                           int inverse, float* depth, niw_stream_t stream);
 
 /* The same with the stratified draw made inside the kernel (the reference draws torch.rand on the device at this point,
@@ -138,7 +155,7 @@ int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, float d
  * overrides it at run time (captured-graph replays).  u_out (optional, [n_rays,S]) receives the draws, so that a checker can
  * reproduce the depths with niw_sample_stratified / the oracle. */
 int niw_sample_stratified_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n_rays, int n_samples,
-                              float depth_min, float depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream);
+                              double depth_min, double depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream);
 
 /* Graph.sample_depth_from_pdf (model/nerf.py:346-365) followed by the cat + ascending sort of
  * Graph.render (model/nerf.py:313-315).  pdf [n_rays,S], depth_coarse [n_rays,S];
@@ -193,10 +210,11 @@ typedef struct niw_render_desc {
     int32_t ndc;                /* != 0: LLFF normalised device coordinates */
     int64_t first_pixel, n_pixels;
     float ndc_near;
-    float depth_min, depth_max; /* opt.nerf.depth.range (DTU: var.depth_range[0]) */
+    double depth_min, depth_max; /* opt.nerf.depth.range (DTU: var.depth_range[0]); doubles: see niw_sample_stratified */
     int32_t inverse_depth;      /* opt.nerf.depth.param == "inverse" */
     int32_t n_samples, n_fine;  /* n_fine = 0: single pass */
     int32_t density_activ;      /* enum niw_density_activ */
+    int32_t precision;          /* enum niw_precision: arithmetic of the field MLP; packed / packed_fine must be images of that class */
     int32_t has_bg;             /* opt.nerf.setbg_opaque */
     float bg;
     const float* u;             /* [n_views*n_pixels, n_samples] stratified draws, or NULL: interval mid-points */

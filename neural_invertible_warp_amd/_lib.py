@@ -18,8 +18,8 @@ _i32 = ctypes.c_int32
 class RenderDesc(ctypes.Structure):
     """niw_render_desc of include/niw.h, field for field"""
     _fields_ = [("intr", _vp), ("pose", _vp), ("n_views", _i32), ("H", _i32), ("W", _i32), ("ndc", _i32),
-                ("first_pixel", _i64), ("n_pixels", _i64), ("ndc_near", _f), ("depth_min", _f), ("depth_max", _f),
-                ("inverse_depth", _i32), ("n_samples", _i32), ("n_fine", _i32), ("density_activ", _i32), ("has_bg", _i32), ("bg", _f),
+                ("first_pixel", _i64), ("n_pixels", _i64), ("ndc_near", _f), ("depth_min", _d), ("depth_max", _d),
+                ("inverse_depth", _i32), ("n_samples", _i32), ("n_fine", _i32), ("density_activ", _i32), ("precision", _i32), ("has_bg", _i32), ("bg", _f),
                 ("u", _vp), ("unif", _vp), ("bins", _vp), ("packed", _vp), ("packed_fine", _vp),
                 ("band_w3d", ctypes.POINTER(_f)), ("band_wview", ctypes.POINTER(_f)), ("band_dev", _vp),
                 ("band_w3d_fine", ctypes.POINTER(_f)), ("band_wview_fine", ctypes.POINTER(_f)), ("band_dev_fine", _vp)]
@@ -35,14 +35,16 @@ SIGNATURES = {
     "niw_mlp_pack_weights": (_i, [_vp, _vp, _vp]),
     "niw_mlp_pack_index": (_i, [_vp, _vp]),
     "niw_mlp_pack_weights_indexed": (_i, [_vp, _vp, _vp, _vp]),
-    "niw_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "niw_mlp_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "niw_mlp_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "niw_mlp_bwd_dw": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "niw_mlp_packed_bytes": (_i64, [_i]),
+    "niw_mlp_pack_weights_prec": (_i, [_vp, _i, _vp, _vp]),
+    "niw_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "niw_mlp_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_mlp_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_mlp_bwd_dw": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "niw_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "niw_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "niw_sample_stratified": (_i, [_vp, _i64, _i, _f, _f, _i, _vp, _vp]),
-    "niw_sample_stratified_rng": (_i, [_u64, _u64, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "niw_sample_stratified": (_i, [_vp, _i64, _i, _d, _d, _i, _vp, _vp]),
+    "niw_sample_stratified_rng": (_i, [_u64, _u64, _vp, _i64, _i, _d, _d, _i, _vp, _vp, _vp]),
     "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "niw_raygen": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "niw_draw_ray_idx": (_i, [_i64, _i64, _u64, _u64, _vp, _i64, _i64, _vp, _vp]),

@@ -369,6 +369,24 @@ inline int group_lanes(int S) {
     const int need = (S + 3) / 4;
     return need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
 }
+// S = 1, as the reference behaves (nerf.py:461-462): the closing 1e10 interval is built from an EMPTY slice of the (empty) interval
+// tensor, so the single sample gets no interval at all -- every weight tensor is empty and rgb / depth / opacity are sums over nothing.
+__global__ void composite_single_sample_fwd_kernel(long long n_rays, int has_bg, float bg, float* __restrict__ rgb, float* __restrict__ depth,
+                                                   float* __restrict__ opacity) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float c = has_bg ? bg : 0.f;                       // rgb + bg * (1 - opacity) with opacity = 0
+    rgb[3 * r] = c; rgb[3 * r + 1] = c; rgb[3 * r + 2] = c;
+    depth[r] = 0.f;
+    opacity[r] = 0.f;
+}
+__global__ void composite_single_sample_bwd_kernel(long long n_rays, float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s, float* __restrict__ d_ray) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_rgb_s[3 * r + c] = d_ray[3 * r + c] = 0.f;
+    d_sigma_s[r] = 0.f;
+}
 }  // namespace
 
 extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s,
@@ -376,11 +394,13 @@ extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const flo
                                  float* rgb, float* depth, float* opacity, float* prob, niw_stream_t stream) {
     NIW_REQUIRE(ray && rgb_s && sigma_s && depth_s && rgb && depth && opacity, "niw_composite_fwd: null pointer");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_composite_fwd: empty input (n_rays=%lld, S=%d)", (long long)n_rays, n_samples);
-    // reference nerf.py:461-462 builds the closing 1e10 interval with empty_like(intervals[..., :1]): with a single sample
-    // that slice is empty, the sample gets NO interval and every output is zero with an empty prob -- not reproduced
-    NIW_REQUIRE(n_samples >= 2, "niw_composite_fwd: needs at least 2 samples per ray (the reference degenerates to all-zero outputs at S=1)");
     hipStream_t st = (hipStream_t)stream;
     const int S = n_samples;
+    if (S == 1) {      // the reference's degenerate case: zero outputs, EMPTY prob (`prob`, if given, is not written: it has no elements there)
+        composite_single_sample_fwd_kernel<<<(int)((n_rays + 255) / 256), 256, 0, st>>>(n_rays, has_bg, bg, rgb, depth, opacity);
+        NIW_LAUNCH_CHECK("niw_composite_fwd (S = 1)");
+        return NIW_OK;
+    }
     if (S % 4 == 0 && aligned16(rgb_s) && aligned16(sigma_s) && aligned16(depth_s) && (!prob || aligned16(prob))) {
         const int G = group_lanes(S);
         const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
@@ -403,7 +423,12 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
                                  const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_prob,
                                  float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream) {
     NIW_REQUIRE(ray && rgb_s && sigma_s && depth_s && d_rgb_s && d_sigma_s && d_ray, "niw_composite_bwd: null pointer");
-    NIW_REQUIRE(n_rays > 0 && n_samples >= 2, "niw_composite_bwd: need n_rays > 0 and S >= 2 (n_rays=%lld, S=%d)", (long long)n_rays, n_samples);
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_composite_bwd: empty input (n_rays=%lld, S=%d)", (long long)n_rays, n_samples);
+    if (n_samples == 1) {      // nothing depends on the inputs (see niw_composite_fwd)
+        composite_single_sample_bwd_kernel<<<(int)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(n_rays, d_rgb_s, d_sigma_s, d_ray);
+        NIW_LAUNCH_CHECK("niw_composite_bwd (S = 1)");
+        return NIW_OK;
+    }
     NIW_REQUIRE(n_samples <= 256 * kMaxChunks, "niw_composite_bwd: S=%d exceeds the %d samples per ray the chunk-prefix table holds",
                 n_samples, 256 * kMaxChunks);
     hipStream_t st = (hipStream_t)stream;

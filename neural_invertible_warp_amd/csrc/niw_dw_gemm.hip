@@ -20,6 +20,10 @@ int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float*
                           const float* d_sigma, const float* save, float* gradws, float* d_center, float* d_ray,
                           hipStream_t stream);
 
+int niw_launch_mlp_bwd_dx_fast(int precision, const void* image, const float* center, const float* ray, const float* depth, int64_t n_rays,
+                               int n_samples, int density_activ, const float* rgb, const float* d_rgb, const float* d_sigma, const float* save,
+                               float* gradws, float* d_center, float* d_ray, hipStream_t stream);
+
 // C[n][k] = sum_m A[n][m] B[k][m] per batch; tile 256x256 (wide) or 256x64; partial tiles
 // [batch][nsplit][TN*TK + 256] (the trailing 256 floats are row sums of A (bias_side 1) or B (2)).
 // Operand addressing (NiwGemmOperand, niw_common.h): 32-sample slice `s` of row r sits at p + batch*batch_stride + r*row_stride + s*32.
@@ -345,7 +349,7 @@ extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
 }
 
 extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
-                              int64_t n_rays, int n_samples, int density_activ,
+                              int64_t n_rays, int n_samples, int density_activ, int precision,
                               const float* rgb, const float* d_rgb, const float* d_sigma,
                               const float* save, float* gradws, float* d_center, float* d_ray, niw_stream_t stream) {
     NIW_REQUIRE(packed && center && ray && depth && rgb && d_rgb && d_sigma && save && gradws, "niw_mlp_bwd_dx: null pointer");
@@ -353,13 +357,18 @@ extern "C" int niw_mlp_bwd_dx(const float* packed, const float* center, const fl
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd_dx: empty input");
     NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_bwd_dx: unknown density activation %d", density_activ);
     NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 24), "niw_mlp_bwd_dx: too many samples per call");
+    NIW_REQUIRE(precision == NIW_PREC_FP32 || precision == NIW_PREC_BF16X3 || precision == NIW_PREC_BF16, "niw_mlp_bwd_dx: unknown precision %d", precision);
+    if (precision != NIW_PREC_FP32)
+        return niw_launch_mlp_bwd_dx_fast(precision, packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
+                                          d_center, d_ray, (hipStream_t)stream);
     return niw_launch_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
                                  d_center, d_ray, (hipStream_t)stream);
 }
 
-extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_rays, int n_samples, float* partial,
+extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_rays, int n_samples, int precision, float* partial,
                               float* d_params, niw_stream_t stream) {
     NIW_REQUIRE(save && gradws && partial && d_params, "niw_mlp_bwd_dw: null pointer");
+    NIW_REQUIRE(precision == NIW_PREC_FP32 || precision == NIW_PREC_BF16X3 || precision == NIW_PREC_BF16, "niw_mlp_bwd_dw: unknown precision %d", precision);
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_bwd_dw: empty input");
     const long long mpad = niw_mlp_padded_rows(n_rays, n_samples);
     hipStream_t st = (hipStream_t)stream;
@@ -415,12 +424,12 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
 }
 
 extern "C" int niw_mlp_bwd(const float* packed, const float* center, const float* ray,
-                           const float* depth, int64_t n_rays, int n_samples, int density_activ,
+                           const float* depth, int64_t n_rays, int n_samples, int density_activ, int precision,
                            const float* rgb, const float* d_rgb, const float* d_sigma,
                            const float* save, float* gradws, float* partial,
                            float* d_params, float* d_center, float* d_ray, niw_stream_t stream) {
-    int rc = niw_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, rgb, d_rgb, d_sigma, save, gradws,
+    int rc = niw_mlp_bwd_dx(packed, center, ray, depth, n_rays, n_samples, density_activ, precision, rgb, d_rgb, d_sigma, save, gradws,
                             d_center, d_ray, stream);
     if (rc != NIW_OK) return rc;
-    return niw_mlp_bwd_dw(save, gradws, n_rays, n_samples, partial, d_params, stream);
+    return niw_mlp_bwd_dw(save, gradws, n_rays, n_samples, precision, partial, d_params, stream);
 }

@@ -251,28 +251,38 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) gc[c] = gr[c] = 0.f;
     }
-    if (a.S % 32 == 0) {
-        // all 32 samples of the wave lie on one ray: reduce over the 32 lanes of a half first
+    // Per-sample ray gradients, parked as two quads in this wave's own columns of the first eight skip-stash rows (read for the last
+    // time by the layer above; the dW pass does not touch the stash).  ray_grad_reduce_kernel sums them per ray in a fixed order:
+    // d_center / d_ray are bit-reproducible (rounds 1-2 accumulated them with float atomics, whose order varies from run to run)
+    // and need no zero-fill.
+    reinterpret_cast<f32x4*>(a.grad + (long long)kGradStashEnc * P)[qoff] =
+        h == 0 ? f32x4{gc[0], gc[1], gc[2], gr[0]} : f32x4{gr[1], gr[2], 0.f, 0.f};
+}
+
+// d_center[r], d_ray[r] = sum over the S samples of ray r of the parked per-sample gradients: one wave per ray, every lane a strided
+// partial sum in sample order, then a fixed xor-shuffle tree.
+__global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __restrict__ stash, long long P, long long n_rays, int S,
+                                                              float* __restrict__ d_center, float* __restrict__ d_ray) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const f32x4* q0 = reinterpret_cast<const f32x4*>(stash) + r * S;
+    const f32x4* q1 = q0 + P;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = lane; s < S; s += 64) {
+        const f32x4 u = q0[s], v = q1[s];
+        acc[0] += u[0]; acc[1] += u[1]; acc[2] += u[2]; acc[3] += u[3]; acc[4] += v[0]; acc[5] += v[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+    }
+    if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                gc[c] += __shfl_xor(gc[c], o);
-                gr[c] += __shfl_xor(gr[c], o);
-            }
-        }
-        if (lane == 0 && valid) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                atomicAdd(a.d_center + ri * 3 + c, gc[c]);
-                atomicAdd(a.d_ray + ri * 3 + c, gr[c]);
-            }
-        }
-    } else if (h == 0 && valid) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicAdd(a.d_center + ri * 3 + c, gc[c]);
-            atomicAdd(a.d_ray + ri * 3 + c, gr[c]);
+            d_center[r * 3 + c] = acc[c];
+            d_ray[r * 3 + c] = acc[3 + c];
         }
     }
 }
@@ -288,5 +298,10 @@ int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float*
     a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
     mlp_bwd_dx_kernel<<<(int)(a.Mpad / 128), 256, 0, stream>>>(a);
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dX chain)");
+    if (a.ray_grad) {
+        ray_grad_reduce_kernel<<<(int)((n_rays + 3) / 4), 256, 0, stream>>>(gradws + (long long)kGradStashEnc * a.Mpad, a.Mpad, n_rays, n_samples,
+                                                                           d_center, d_ray);
+        NIW_LAUNCH_CHECK("niw_mlp_bwd (ray-gradient reduction)");
+    }
     return NIW_OK;
 }

@@ -1,0 +1,57 @@
+// Positional encoding of a point / unit direction in MFMA slot order, shared by the exact-fp32 forward (niw_mlp_fwd.hip) and the
+// fast-precision forward (niw_mlp_fast.hip): both form the encodings in fp32 with the same arithmetic.
+// Reference: NeRF.positional_encoding, model/nerf.py:476-483 (+ the c2f band mask, model/barf_inn_llff.py:427-442).
+#pragma once
+#include "niw_common.h"
+
+namespace niw {
+
+// One sincos pair (compile-time pair index per lane half, selected by h).  rev[c] = fl32(p_c*pi32)/(2 pi).
+template <int L>
+__device__ __forceinline__ void enc_pair(const double (&rev)[3], const float* __restrict__ w, int h, int pair0, int pair1,
+                                         float& s_out, float& c_out) {
+    // pair index -> (coordinate, band); pairs >= 3L are zero padding
+    const bool valid0 = pair0 < 3 * L, valid1 = pair1 < 3 * L;
+    const int c0 = valid0 ? pair0 / L : 0, k0 = valid0 ? pair0 % L : 0;
+    const int c1 = valid1 ? pair1 / L : 0, k1 = valid1 ? pair1 % L : 0;
+    const double t = h ? rev[c1] : rev[c0];
+    const int k = h ? k1 : k0;
+    const float wk = h ? w[k1] : w[k0];
+    float s, c;
+    sincos_band(t, k, s, c);
+    const bool valid = h ? valid1 : valid0;
+    s_out = valid ? s * wk : 0.f;
+    c_out = valid ? c * wk : 0.f;
+}
+
+// enc[4q+t] = feature of slot 8q+4h+t for this lane's half h
+template <int L, int NQ>
+__device__ __forceinline__ void encode_slots(const float (&p)[3], const float* __restrict__ w, int h, float (&enc)[4 * NQ]) {
+    double rev[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rev[c] = (double)mul_rn(p[c], 3.14159274101257324f) * 0.15915494309189533577;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        // combo g = 2q + h; g == 0: raw coordinates; else pairs 2(g-1), 2(g-1)+1
+        const int pa0 = 2 * (2 * q - 1), pa1 = 2 * (2 * q);      // first pair for h = 0 / h = 1
+        float s0, c0, s1, c1;
+        if (q == 0) {
+            enc_pair<L>(rev, w, 1, 0, 0, s0, c0);                   // only h = 1 lanes use these
+            enc_pair<L>(rev, w, 1, 1, 1, s1, c1);
+            enc[0] = h ? s0 : p[0];
+            enc[1] = h ? c0 : p[1];
+            enc[2] = h ? s1 : p[2];
+            enc[3] = h ? c1 : 0.f;
+        } else {
+            enc_pair<L>(rev, w, h, pa0, pa1, s0, c0);
+            enc_pair<L>(rev, w, h, pa0 + 1, pa1 + 1, s1, c1);
+            enc[4 * q + 0] = s0;
+            enc[4 * q + 1] = c0;
+            enc[4 * q + 2] = s1;
+            enc[4 * q + 3] = c1;
+        }
+    }
+}
+
+
+}  // namespace niw

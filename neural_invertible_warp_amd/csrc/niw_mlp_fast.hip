@@ -1,0 +1,366 @@
+// Field MLP in the opt-in fast-precision modes NIW_PREC_BF16X3 / NIW_PREC_BF16 (niw_mlp_fast.h): the same register-chained design as
+// niw_mlp_fwd.hip -- every wave owns 32 samples and carries them through all ten layers, the 32x32 accumulator of one layer being,
+// register for register, the B operand of the next -- on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each fp32 activation is split
+// into bf16 planes (hi, mid) as it leaves the accumulator: one v_cvt_pk_bf16_f32 per pair and plane, the residue x - hi formed exactly
+// in fp32.  Weights are split the same way once per optimizer step by the packing kernel.  Never the default: the headline numbers and
+// every parity claim at the reference's fp32 tolerance are the exact-fp32 kernels'; this path has its own, looser, stated tolerance
+// (tests/test_gpu_fast_precision.py).
+// Reference arithmetic evaluated: model/nerf.py:416-456, 476-483 (+ c2f mask, model/barf_inn_llff.py:427-442).
+#include "niw_common.h"
+#include "niw_mlp_device.h"
+#include "niw_mlp_encode.h"
+#include "niw_mlp_fast.h"
+
+using namespace niw;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// two fp32 values -> one dword of two bf16 (round to nearest even, NaN kept: v_cvt_pk_bf16_f32); element 0 in the low half
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// (hi, mid) planes of a pair: hi = bf16(x), mid = bf16(x - hi); x - hi is exact in fp32 (hi keeps the leading 8 significand bits)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid) {
+    hi = pack_bf16(a, b);
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = pack_bf16(a - ha, b - hb);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const unsigned (&b)[4], f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, u32x4_t{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// image builder (once per optimizer step): one thread per dword of the fragment sections / per float of the bias section
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int frag_source(int byte, int j) {
+    // -> index into the flat parameter vector of element j (0..7) of the fragment lane that owns `byte`, or -1 (zero padding)
+    const bool bwd = byte >= fast_bwd_off(0);
+    int l = 0;
+    if (!bwd) { while (l + 1 < kLayers && byte >= fast_fwd_off(l + 1)) ++l; }
+    else      { while (l + 1 < kLayers && byte >= fast_bwd_off(l + 1)) ++l; }
+    const int local = byte - (bwd ? fast_bwd_off(l) : fast_fwd_off(l));
+    const int frag = local / kFragBytes, lane = (local % 1024) / 16;
+    const int i = lane & 31, h = lane >> 5;
+    const int steps = bwd ? fast_rs(l) : fast_ks(l);
+    const int blk = frag / steps, q = frag % steps;
+    const int red = 16 * q + fast_perm(h, j);                     // reduction index of this element
+    const int row = out_row(l, bwd ? red : blk * 32 + i), col = fwd_slot_col(l, bwd ? blk * 32 + i : red);
+    return (row >= 0 && col >= 0) ? weight_off(l) + row * layer_k(l) + col : -1;
+}
+
+__global__ void pack_fast_kernel(const float* __restrict__ params, unsigned* __restrict__ image) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;          // dword index
+    if (d >= kFastImageBytes / 4) return;
+    const int byte = 4 * d;
+    if (byte >= fast_bias_off(0)) {
+        int l = 0;
+        while (l + 1 < kLayers && byte >= fast_bias_off(l + 1)) ++l;
+        const int local = (byte - fast_bias_off(l)) / 4;          // [nb][h][16]
+        const int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
+        const int row = out_row(l, nb * 32 + acc_row(r, h));
+        image[d] = __builtin_bit_cast(unsigned, row >= 0 ? params[bias_off(l) + row] : 0.f);
+        return;
+    }
+    const int plane = (byte % kFragBytes) / 1024, jp = (byte % 16) / 4;
+    const int s0 = frag_source(byte, 2 * jp), s1 = frag_source(byte, 2 * jp + 1);
+    const float w0 = s0 >= 0 ? params[s0] : 0.f, w1 = s1 >= 0 ? params[s1] : 0.f;
+    unsigned hi, mid;
+    split_pair(w0, w1, hi, mid);
+    image[d] = plane ? mid : hi;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// streaming register-chained layer on bf16 planes
+//   out[n][m] = sum_k A[n][k] B[k][m],  A = image fragments (L2 / L1), B = this lane's operand planes b1 then b2
+// Row blocks outer, k-steps inner, one dependent MFMA chain per block (a single chain of v_mfma_f32_32x32x16_bf16 issues back to back);
+// TERMS = 3: hi*hi + hi*mid + mid*hi per k-step, TERMS = 1: hi*hi.  A ring keeps D fragments (TERMS = 3: both planes) in flight; the
+// epilogue of block nb-1 -- ReLU, split into planes, stores -- is spread in PAIRS of accumulator registers over the k-steps of block nb.
+//   pol.acc_init(nb, c)            the 16-register value block nb accumulates from (its bias fragment), fetched one block ahead
+//   pol.epi2(nb, rp, a0, a1)       accumulator registers 2 rp, 2 rp + 1 of block nb
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kFastRing = 8;
+
+template <int KS1, int KS2, int NB, int TERMS, typename Policy>
+__device__ __forceinline__ void stream_layer_bf(const PackedWeights& pw, int w_base, const unsigned (&b1)[2][4 * KS1],
+                                                const unsigned (&b2)[2][4 * (KS2 > 0 ? KS2 : 1)], Policy& pol) {
+    constexpr int KS = KS1 + KS2, N = NB * KS, D = kFastRing, PL = TERMS >= 3 ? 2 : 1;
+    u32x4_t ring[D][PL];
+    auto fetch = [&](int i, int slot) {
+#pragma unroll
+        for (int p = 0; p < PL; ++p)
+            ring[slot][p] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pw.rsrc, pw.lane16, w_base + i * kFragBytes + p * 1024, 0));
+    };
+    f32x16 cin[2], acc[2];
+    pol.acc_init(0, cin[0]);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < N) fetch(i, i);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        f32x16& cur = acc[nb & 1];
+        if (nb + 1 < NB) pol.acc_init(nb + 1, cin[(nb + 1) & 1]);
+        cur = cin[nb & 1];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const int i = nb * KS + q;
+            u32x4_t a[PL];
+#pragma unroll
+            for (int p = 0; p < PL; ++p) a[p] = ring[i % D][p];
+            if (i + D < N) fetch(i + D, i % D);
+            unsigned bh[4], bm[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bh[t] = q < KS1 ? b1[0][4 * (q < KS1 ? q : 0) + t] : b2[0][4 * (q >= KS1 ? q - KS1 : 0) + t];
+                bm[t] = q < KS1 ? b1[1][4 * (q < KS1 ? q : 0) + t] : b2[1][4 * (q >= KS1 ? q - KS1 : 0) + t];
+            }
+            if (TERMS >= 3) {
+                cur = mfma_bf16(a[0], bm, cur);                  // the two small terms first, the leading term last
+                cur = mfma_bf16(a[PL - 1], bh, cur);
+            }
+            cur = mfma_bf16(a[0], bh, cur);
+            if (nb > 0) {
+#pragma unroll
+                for (int rp = q * 8 / KS; rp < (q + 1) * 8 / KS; ++rp) pol.epi2(nb - 1, rp, acc[(nb - 1) & 1][2 * rp], acc[(nb - 1) & 1][2 * rp + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) pol.epi2(NB - 1, rp, acc[(NB - 1) & 1][2 * rp], acc[(NB - 1) & 1][2 * rp + 1]);
+}
+
+// planes of an fp32 register array in B-operand order: dword r of a plane = values 2 r, 2 r + 1
+template <int NV>
+__device__ __forceinline__ void split_regs(const float (&v)[NV], unsigned (&planes)[2][NV / 2]) {
+#pragma unroll
+    for (int r = 0; r < NV / 2; ++r) split_pair(v[2 * r], v[2 * r + 1], planes[0][r], planes[1][r]);
+}
+
+// Forward epilogue: the bias is in the accumulator already (acc_init); ReLU; planes of the next layer's operand; training: the fp32
+// activation into the quad-row workspace and the ReLU sign bits into the wave's mask record -- byte for byte what the exact-fp32
+// forward leaves behind, so either backward can consume it.
+// KIND 0: hidden layer; 1: layer 7 (row block 8, register 0 of lane half 0 = raw density); 2: colour output (no ReLU, no planes).
+template <int NBOUT, bool SAVE, int KIND>
+struct FastFwdEpilogue {
+    const PackedWeights& pw;
+    int bias_bytes, hoff;                // packed bias of the layer ([row block][half][16] floats); h * 64
+    unsigned (&out)[2][8 * NBOUT];
+    RowWindow win;
+    const char* mrec;
+    int lane;
+    unsigned mbits[4] = {0u, 0u, 0u, 0u};
+    float keep[2] = {0.f, 0.f};          // registers 4g, 4g+1 waiting for 4g+2, 4g+3 (one 16-byte store per quad)
+    float head[4] = {0.f, 0.f, 0.f, 0.f};   // KIND 1: [0] = raw density; KIND 2: the three colour logits
+
+    __device__ __forceinline__ void acc_init(int nb, f32x16& c) const {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = buf_load4(pw.rsrc, hoff, bias_bytes + nb * 128 + g * 16);
+            c[4 * g] = v[0]; c[4 * g + 1] = v[1]; c[4 * g + 2] = v[2]; c[4 * g + 3] = v[3];
+        }
+    }
+    __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
+        if (KIND == 2) {                 // colour logits: rows 0..2 of the single row block = registers 0..2 of lane half 0
+            if (rp == 0) { head[0] = a0; head[1] = a1; }
+            if (rp == 1) head[2] = a0;
+            return;
+        }
+        if (KIND == 1 && nb == NBOUT) {  // the density row block: row 0 only
+            if (rp == 0) head[0] = a0;
+            return;
+        }
+        const float v0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a0), 0));
+        const float v1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a1), 0));
+        split_pair(v0, v1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
+        if (SAVE) {
+            if (rp & 1) buf_store4(keep[0], keep[1], v0, v1, win.rsrc(nb * 32), win.voff4, 8 * (rp >> 1) * win.pitch4);
+            else { keep[0] = v0; keep[1] = v1; }
+            mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v0) + 0x7fffffffu, 31);
+            mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v1) + 0x7fffffffu, 31);
+            if (nb == NBOUT - 1 && rp == 7)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{mbits[0], mbits[1], mbits[2], mbits[3]}, make_rsrc(mrec), lane * 16, 0, 0);
+        }
+    }
+};
+
+struct FastFwdArgs {
+    const unsigned char* image;
+    const float* center;
+    const float* ray;
+    const float* depth;
+    const float* noise;
+    float* rgb;
+    float* sigma;
+    float* save;
+    long long M, Mpad;
+    int S, act;
+    float w3d[NIW_L3D];
+    float wview[NIW_LVIEW];
+    const float* band_dev;
+};
+
+__device__ __forceinline__ float density_act_fast(float x, int kind) {
+    if (kind == NIW_ACT_RELU) return fmaxf(x, 0.f);
+    return x > 20.f ? x : log1pf(expf(x));      // F.softplus(beta=1, threshold=20)
+}
+
+template <int TERMS, bool SAVE>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool valid = m < a.M;
+    const long long mc = valid ? m : a.M - 1;
+    const long long ri = mc / a.S;
+    // ---- sample point and unit view direction, positional encodings: fp32, exactly as the exact-fp32 forward forms them
+    float p[3], u[3];
+    {
+        const float d = a.depth[mc];
+        const float rx = a.ray[ri * 3 + 0], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];
+        p[0] = add_rn(a.center[ri * 3 + 0], mul_rn(rx, d));
+        p[1] = add_rn(a.center[ri * 3 + 1], mul_rn(ry, d));
+        p[2] = add_rn(a.center[ri * 3 + 2], mul_rn(rz, d));
+        const float nrm = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+        u[0] = rx / nrm; u[1] = ry / nrm; u[2] = rz / nrm;
+    }
+    float enc[32], venc[16];
+    {
+        float w3[NIW_L3D], wv[NIW_LVIEW];
+#pragma unroll
+        for (int i = 0; i < NIW_L3D; ++i) w3[i] = a.band_dev ? a.band_dev[i] : a.w3d[i];
+#pragma unroll
+        for (int i = 0; i < NIW_LVIEW; ++i) wv[i] = a.band_dev ? a.band_dev[NIW_L3D + i] : a.wview[i];
+        encode_slots<NIW_L3D, 8>(p, w3, h, enc);
+        encode_slots<NIW_LVIEW, 4>(u, wv, h, venc);
+    }
+    const PackedWeights pw{make_rsrc(a.image), reinterpret_cast<const float*>(a.image), lane * 16};
+    const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)(((long long)h * a.Mpad + m) * 16), hoff = h * 64;
+    const unsigned mpad32 = (unsigned)a.Mpad;
+    auto row_off = [&](int r) { return (long long)((unsigned long long)(unsigned)r * (unsigned long long)mpad32); };
+    auto window = [&](int r) { return RowWindow{SAVE ? a.save + row_off(r) : nullptr, pitch4, voff4}; };
+    const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    auto mask_rec = [&](int i) {
+        return SAVE ? reinterpret_cast<const char*>(a.save + row_off(kSaveMask)) + (wave_id * kMaskRecords + i) * kMaskRecBytes : nullptr;
+    };
+    if (SAVE) {
+        const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) buf_store4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3], we.rsrc(0), voff4, 8 * q * pitch4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) buf_store4(venc[4 * q], venc[4 * q + 1], venc[4 * q + 2], venc[4 * q + 3], wv.rsrc(0), voff4, 8 * q * pitch4);
+    }
+    unsigned encp[2][16], vencp[2][8];
+    split_regs<32>(enc, encp);
+    split_regs<16>(venc, vencp);
+    const unsigned none[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    unsigned act[2][64], nxt[2][64];
+    auto advance = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) act[pl][i] = nxt[pl][i];
+    };
+    // ---- layer 0: 63 -> 256
+    {
+        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(0), hoff, nxt, window(save_h(1)), mask_rec(0), lane};
+        stream_layer_bf<4, 0, 8, TERMS>(pw, fast_fwd_off(0), encp, none, ep);
+        advance();
+    }
+    // ---- layers 1..3
+#pragma unroll 1
+    for (int l = 1; l <= 3; ++l) {
+        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(1) + (l - 1) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
+        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_fwd_off(1) + (l - 1) * (8 * 16 * kFragBytes), act, none, ep);
+        advance();
+    }
+    // ---- layer 4: cat[feat, points_enc] (319) -> 256
+    {
+        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(4), hoff, nxt, window(save_h(5)), mask_rec(4), lane};
+        stream_layer_bf<16, 4, 8, TERMS>(pw, fast_fwd_off(4), act, encp, ep);
+        advance();
+    }
+    // ---- layers 5, 6
+#pragma unroll 1
+    for (int l = 5; l <= 6; ++l) {
+        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(5) + (l - 5) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
+        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_fwd_off(5) + (l - 5) * (8 * 16 * kFragBytes), act, none, ep);
+        advance();
+    }
+    // ---- layer 7: 256 -> 256 features + the density row (row block 8)
+    {
+        FastFwdEpilogue<8, SAVE, 1> ep{pw, fast_bias_off(7), hoff, nxt, window(kSaveFeat), mask_rec(7), lane};
+        stream_layer_bf<16, 0, 9, TERMS>(pw, fast_fwd_off(7), act, none, ep);
+        advance();
+        float sig_raw = ep.head[0];
+        if (a.noise != nullptr) sig_raw += a.noise[mc];
+        if (h == 0) {
+            if (SAVE) (a.save + row_off(kSaveSigma))[m] = sig_raw;
+            if (valid) a.sigma[m] = density_act_fast(sig_raw, a.act);
+        }
+    }
+    // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
+    unsigned hr[2][32];
+    {
+        FastFwdEpilogue<4, SAVE, 0> ep{pw, fast_bias_off(8), hoff, hr, window(kSaveHr), mask_rec(8), lane};
+        stream_layer_bf<16, 2, 4, TERMS>(pw, fast_fwd_off(8), act, vencp, ep);
+    }
+    // ---- colour layer 1: 128 -> 3, sigmoid
+    {
+        unsigned unused[2][8];
+        FastFwdEpilogue<1, false, 2> ep{pw, fast_bias_off(9), hoff, unused, RowWindow{nullptr, 0, 0}, nullptr, lane};
+        stream_layer_bf<8, 0, 1, TERMS>(pw, fast_fwd_off(9), hr, none, ep);
+        if (h == 0 && valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-ep.head[c]));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t niw_mlp_fast_image_bytes(void) { return kFastImageBytes; }
+
+extern "C" int niw_mlp_pack_weights_fast(const float* params, void* image, niw_stream_t stream) {
+    NIW_REQUIRE(params && image, "niw_mlp_pack_weights_fast: null pointer");
+    pack_fast_kernel<<<(kFastImageBytes / 4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, reinterpret_cast<unsigned*>(image));
+    NIW_LAUNCH_CHECK("niw_mlp_pack_weights_fast");
+    return NIW_OK;
+}
+
+int niw_launch_mlp_fwd_fast(int precision, const void* image, const float* center, const float* ray, const float* depth, const float* noise,
+                            int64_t n_rays, int n_samples, const float* band_w3d, const float* band_wview, const float* band_dev,
+                            int density_activ, float* rgb, float* sigma, float* save, hipStream_t stream) {
+    FastFwdArgs a;
+    a.image = reinterpret_cast<const unsigned char*>(image);
+    a.center = center; a.ray = ray; a.depth = depth; a.noise = noise; a.rgb = rgb; a.sigma = sigma; a.save = save;
+    a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
+    a.S = n_samples; a.act = density_activ;
+    for (int i = 0; i < NIW_L3D; ++i) a.w3d[i] = band_w3d ? band_w3d[i] : 1.f;
+    for (int i = 0; i < NIW_LVIEW; ++i) a.wview[i] = band_wview ? band_wview[i] : 1.f;
+    a.band_dev = band_dev;
+    const int blocks = (int)(a.Mpad / 128);
+    if (precision == NIW_PREC_BF16X3) {
+        if (save) mlp_fwd_fast_kernel<3, true><<<blocks, 256, 0, stream>>>(a);
+        else mlp_fwd_fast_kernel<3, false><<<blocks, 256, 0, stream>>>(a);
+    } else {
+        if (save) mlp_fwd_fast_kernel<1, true><<<blocks, 256, 0, stream>>>(a);
+        else mlp_fwd_fast_kernel<1, false><<<blocks, 256, 0, stream>>>(a);
+    }
+    NIW_LAUNCH_CHECK("niw_mlp_fwd (fast precision)");
+    return NIW_OK;
+}
+
+// (the dX chain of the fast modes: below, once built)
+int niw_launch_mlp_bwd_dx_fast(int precision, const void* image, const float* center, const float* ray, const float* depth, int64_t n_rays,
+                               int n_samples, int density_activ, const float* rgb, const float* d_rgb, const float* d_sigma, const float* save,
+                               float* gradws, float* d_center, float* d_ray, hipStream_t stream) {
+    (void)precision; (void)image; (void)center; (void)ray; (void)depth; (void)n_rays; (void)n_samples; (void)density_activ; (void)rgb; (void)d_rgb;
+    (void)d_sigma; (void)save; (void)gradws; (void)d_center; (void)d_ray; (void)stream;
+    niw_set_error("niw_mlp_bwd_dx: the fast-precision dX chain is not built; use NIW_PREC_FP32 for the backward (the forward's saves are the same)");
+    return NIW_ERR_UNSUPPORTED;
+}

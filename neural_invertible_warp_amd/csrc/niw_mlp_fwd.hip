@@ -14,8 +14,16 @@
 // from L2 (2.1 MB total, resident in every XCD's 4 MiB L2).
 #include "niw_common.h"
 #include "niw_mlp_device.h"
+#include "niw_mlp_encode.h"
 
 using namespace niw;
+
+// fast-precision modes: niw_mlp_fast.hip
+extern "C" int64_t niw_mlp_fast_image_bytes(void);
+extern "C" int niw_mlp_pack_weights_fast(const float* params, void* image, niw_stream_t stream);
+int niw_launch_mlp_fwd_fast(int precision, const void* image, const float* center, const float* ray, const float* depth, const float* noise,
+                            int64_t n_rays, int n_samples, const float* band_w3d, const float* band_wview, const float* band_dev,
+                            int density_activ, float* rgb, float* sigma, float* save, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
 // weight packing
@@ -83,59 +91,7 @@ __global__ void pack_gather_kernel(const float* __restrict__ params, const int4*
 }
 static_assert(kPackedFloats % 4 == 0, "packed image is a whole number of float4");
 
-// ---------------------------------------------------------------------------------------
-// positional encoding in MFMA slot order
-// ---------------------------------------------------------------------------------------
-// band frequency 2^k * fp32(pi)  (reference: 2**arange(L) * np.pi evaluated in fp32)
-
-// sincos_band(): niw_common.h
-
-// One sincos pair (compile-time pair index per lane half, selected by h).  rev[c] = fl32(p_c*pi32)/(2 pi).
-template <int L>
-__device__ __forceinline__ void enc_pair(const double (&rev)[3], const float* __restrict__ w, int h, int pair0, int pair1,
-                                         float& s_out, float& c_out) {
-    // pair index -> (coordinate, band); pairs >= 3L are zero padding
-    const bool valid0 = pair0 < 3 * L, valid1 = pair1 < 3 * L;
-    const int c0 = valid0 ? pair0 / L : 0, k0 = valid0 ? pair0 % L : 0;
-    const int c1 = valid1 ? pair1 / L : 0, k1 = valid1 ? pair1 % L : 0;
-    const double t = h ? rev[c1] : rev[c0];
-    const int k = h ? k1 : k0;
-    const float wk = h ? w[k1] : w[k0];
-    float s, c;
-    sincos_band(t, k, s, c);
-    const bool valid = h ? valid1 : valid0;
-    s_out = valid ? s * wk : 0.f;
-    c_out = valid ? c * wk : 0.f;
-}
-
-// enc[4q+t] = feature of slot 8q+4h+t for this lane's half h
-template <int L, int NQ>
-__device__ __forceinline__ void encode_slots(const float (&p)[3], const float* __restrict__ w, int h, float (&enc)[4 * NQ]) {
-    double rev[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rev[c] = (double)mul_rn(p[c], 3.14159274101257324f) * 0.15915494309189533577;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        // combo g = 2q + h; g == 0: raw coordinates; else pairs 2(g-1), 2(g-1)+1
-        const int pa0 = 2 * (2 * q - 1), pa1 = 2 * (2 * q);      // first pair for h = 0 / h = 1
-        float s0, c0, s1, c1;
-        if (q == 0) {
-            enc_pair<L>(rev, w, 1, 0, 0, s0, c0);                   // only h = 1 lanes use these
-            enc_pair<L>(rev, w, 1, 1, 1, s1, c1);
-            enc[0] = h ? s0 : p[0];
-            enc[1] = h ? c0 : p[1];
-            enc[2] = h ? s1 : p[2];
-            enc[3] = h ? c1 : 0.f;
-        } else {
-            enc_pair<L>(rev, w, h, pa0, pa1, s0, c0);
-            enc_pair<L>(rev, w, h, pa0 + 1, pa1 + 1, s1, c1);
-            enc[4 * q + 0] = s0;
-            enc[4 * q + 1] = c0;
-            enc[4 * q + 2] = s1;
-            enc[4 * q + 3] = c1;
-        }
-    }
-}
+// positional encoding in MFMA slot order: niw_mlp_encode.h (shared with the fast-precision forward)
 
 // Epilogue policy of one forward layer for stream_layer(): bias add, ReLU, hand the value to the next
 // layer's operand registers and (training) store it feature-major [row][Mpad].  Row of (nb, r, h) =
@@ -376,6 +332,18 @@ extern "C" int64_t niw_mlp_padded_rows(int64_t n_rays, int n_samples) {
 
 extern "C" int64_t niw_mlp_packed_floats(void) { return kPackedFloats; }
 
+extern "C" int niw_mlp_pack_weights(const float* params, float* packed, niw_stream_t stream);
+
+extern "C" int64_t niw_mlp_packed_bytes(int precision) {
+    return precision == NIW_PREC_FP32 ? 4ll * kPackedFloats : niw_mlp_fast_image_bytes();
+}
+
+extern "C" int niw_mlp_pack_weights_prec(const float* params, int precision, void* packed, niw_stream_t stream) {
+    if (precision == NIW_PREC_FP32) return niw_mlp_pack_weights(params, reinterpret_cast<float*>(packed), stream);
+    NIW_REQUIRE(precision == NIW_PREC_BF16X3 || precision == NIW_PREC_BF16, "niw_mlp_pack_weights_prec: unknown precision %d", precision);
+    return niw_mlp_pack_weights_fast(params, packed, stream);
+}
+
 extern "C" int niw_mlp_pack_weights(const float* params, float* packed, niw_stream_t stream) {
     NIW_REQUIRE(params && packed, "niw_mlp_pack_weights: null pointer");
     const int threads = 256, blocks = (kPackedFloats + threads - 1) / threads;
@@ -401,12 +369,16 @@ extern "C" int niw_mlp_pack_weights_indexed(const float* params, const int32_t* 
 
 extern "C" int niw_mlp_fwd(const float* packed, const float* center, const float* ray,
                            const float* depth, const float* noise, int64_t n_rays, int n_samples,
-                           const float* band_w3d, const float* band_wview, const float* band_dev, int density_activ,
+                           const float* band_w3d, const float* band_wview, const float* band_dev, int density_activ, int precision,
                            float* rgb, float* sigma, float* save, niw_stream_t stream) {
     NIW_REQUIRE(packed && center && ray && depth && rgb && sigma, "niw_mlp_fwd: null pointer");
+    NIW_REQUIRE(precision == NIW_PREC_FP32 || precision == NIW_PREC_BF16X3 || precision == NIW_PREC_BF16, "niw_mlp_fwd: unknown precision %d", precision);
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_mlp_fwd: n_rays=%lld n_samples=%d must be positive", (long long)n_rays, n_samples);
     NIW_REQUIRE(niw_mlp_padded_rows(n_rays, n_samples) < (1ll << 24), "niw_mlp_fwd: too many samples per call (%lld)", (long long)(n_rays * n_samples));
     NIW_REQUIRE(density_activ == NIW_ACT_RELU || density_activ == NIW_ACT_SOFTPLUS, "niw_mlp_fwd: unknown density activation %d", density_activ);
+    if (precision != NIW_PREC_FP32)
+        return niw_launch_mlp_fwd_fast(precision, packed, center, ray, depth, noise, n_rays, n_samples, band_w3d, band_wview, band_dev, density_activ,
+                                       rgb, sigma, save, (hipStream_t)stream);
     MlpFwdArgs a;
     a.packed = packed; a.center = center; a.ray = ray; a.depth = depth; a.noise = noise;
     a.rgb = rgb; a.sigma = sigma; a.save = save;

@@ -30,7 +30,7 @@ int field(const niw_render_desc* d, bool fine, const float* packed, const float*
     for (long long a = 0; a < n_rays; a += max_rays) {
         const long long n = n_rays - a < max_rays ? n_rays - a : max_rays;
         const int rc = niw_mlp_fwd(packed, center + 3 * a, ray + 3 * a, depth + a * S, nullptr, n, S, fine ? d->band_w3d_fine : d->band_w3d,
-                                   fine ? d->band_wview_fine : d->band_wview, fine ? d->band_dev_fine : d->band_dev, d->density_activ, rgb_s + 3 * a * S, sigma_s + a * S, nullptr, stream);
+                                   fine ? d->band_wview_fine : d->band_wview, fine ? d->band_dev_fine : d->band_dev, d->density_activ, d->precision, rgb_s + 3 * a * S, sigma_s + a * S, nullptr, stream);
         if (rc != NIW_OK) return rc;
     }
     return NIW_OK;

@@ -6,14 +6,15 @@
 namespace {
 
 // ---------------------------------------------------------------- S1: Graph.sample_depth (nerf.py:334-344)
-__global__ void sample_stratified_kernel(const float* __restrict__ u, long long n, int S, float dmin, float dmax, int inverse,
+// `span` = fl32(depth_max - depth_min) with the difference formed in double by the host entry point (include/niw.h)
+__global__ void sample_stratified_kernel(const float* __restrict__ u, long long n, int S, float dmin, float span, int inverse,
                                          float* __restrict__ depth) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s = (int)(i % S);
     const float r = (u ? u[i] : 0.5f) + (float)s;
     // rand_samples / S * (max - min) + min, each op rounded on its own
-    float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)S), dmax - dmin), dmin);
+    float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)S), span), dmin);
     if (inverse) d = __fdiv_rn(1.f, niw::add_rn(d, 1e-8f));
     depth[i] = d;
 }
@@ -34,7 +35,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
 }
 
 __global__ void sample_stratified_rng_kernel(unsigned long long seed, unsigned long long draw, const unsigned long long* __restrict__ draw_dev,
-                                             long long n, int S, float dmin, float dmax, int inverse, float* __restrict__ depth,
+                                             long long n, int S, float dmin, float span, int inverse, float* __restrict__ depth,
                                              float* __restrict__ u_out) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // group of four consecutive samples
     if (4 * g >= n) return;
@@ -47,7 +48,7 @@ __global__ void sample_stratified_rng_kernel(unsigned long long seed, unsigned l
         if (i >= n) break;
         const float u = (float)(c[t] >> 8) * 5.9604644775390625e-08f;           // 2^-24
         const float r = u + (float)(int)(i % S);
-        float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)S), dmax - dmin), dmin);
+        float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)S), span), dmin);
         if (inverse) d = __fdiv_rn(1.f, niw::add_rn(d, 1e-8f));
         depth[i] = d;
         if (u_out) u_out[i] = u;
@@ -264,23 +265,23 @@ __global__ void draw_ray_idx_kernel(long long n_pixels, long long n, unsigned lo
 
 }  // namespace
 
-extern "C" int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, float depth_min, float depth_max,
+extern "C" int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, double depth_min, double depth_max,
                                      int inverse, float* depth, niw_stream_t stream) {
     NIW_REQUIRE(depth, "niw_sample_stratified: null output");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_sample_stratified: empty input");
     const long long n = n_rays * (long long)n_samples;
-    sample_stratified_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, n, n_samples, depth_min, depth_max, inverse, depth);
+    sample_stratified_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, n, n_samples, (float)depth_min, (float)(depth_max - depth_min), inverse, depth);
     NIW_LAUNCH_CHECK("niw_sample_stratified");
     return NIW_OK;
 }
 
 extern "C" int niw_sample_stratified_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n_rays, int n_samples,
-                                         float depth_min, float depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream) {
+                                         double depth_min, double depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream) {
     NIW_REQUIRE(depth, "niw_sample_stratified_rng: null output");
     NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_sample_stratified_rng: empty input");
     const long long n = n_rays * (long long)n_samples, groups = (n + 3) / 4;
     sample_stratified_rng_kernel<<<(int)((groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        seed, draw, reinterpret_cast<const unsigned long long*>(draw_dev), n, n_samples, depth_min, depth_max, inverse, depth, u_out);
+        seed, draw, reinterpret_cast<const unsigned long long*>(draw_dev), n, n_samples, (float)depth_min, (float)(depth_max - depth_min), inverse, depth, u_out);
     NIW_LAUNCH_CHECK("niw_sample_stratified_rng");
     return NIW_OK;
 }

@@ -132,6 +132,7 @@ class INNTrainer:
             if opt.nerf.ray_sampler != "feistel":
                 raise NiwError("hip_graph=True needs ray_sampler='feistel' (torch.randperm cannot be replayed with a fresh draw)")
             self.consts = StepConstants(dev, len(self.bucket.groups))
+        self._bind_constants(False)                      # outside a train iteration the modules read host state (see _bind_constants)
         if world > 1 or parallel.FORCE_COLLECTIVES:      # (a forced one-rank group shards 1-way: same arithmetic, collectives issued)
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)

@@ -98,7 +98,9 @@ class NeRF(torch.nn.Module):
             stacks[stack].append(layer)
         assert cursor == ops.NERF_PARAM_FLOATS
         self.total_param = sum(l.weight.numel() for l in self.field_layers())
-        self._state = ops.FieldState(flat)
+        # arithmetic of the field MLP: "fp32" (exact, default) or one of the opt-in fast modes of include/niw.h, chosen by
+        # `opt.arch.precision` (not a reference key) or set_precision()
+        self._state = ops.FieldState(flat, precision=opt.arch.get("precision") or "fp32")
         self.progress_host = None
         self.band_dev = None            # device tensor [14] of c2f band weights read by the kernel at run time (engine.StepConstants)
         self.grad_sink = None           # flat buffer that receives this network's parameter gradients instead of .grad (ops.field_mlp)
@@ -143,7 +145,12 @@ class NeRF(torch.nn.Module):
         for p in ps:
             p.data = new[off:off + p.numel()].view(p.shape)
             off += p.numel()
-        self._state = ops.FieldState(new)
+        self._state = ops.FieldState(new, precision=self._state.precision)
+
+    def set_precision(self, precision):
+        """"fp32" | "bf16x3" | "bf16" (ops.PREC): the arithmetic of this network's forward (and, where built, backward) kernels"""
+        self._state.set_precision(precision)
+        return self
 
     # ------------------------------------------------------------------ encoding weights
     def band_weights(self, opt, L):
@@ -194,7 +201,7 @@ class NeRF(torch.nn.Module):
         bg = opt.data.bgcolor if opt.nerf.setbg_opaque else None
         rgb, depth, opacity, prob = ops.composite(ray.reshape(-1, 3), rgb_samples.reshape(B * R, S, 3),
                                                   density_samples.reshape(B * R, S), depth_samples.reshape(B * R, S), bg)
-        return rgb.view(B, R, 3), depth.view(B, R, 1), opacity.view(B, R, 1), prob.view(B, R, S, 1)
+        return rgb.view(B, R, 3), depth.view(B, R, 1), opacity.view(B, R, 1), prob.view(B, R, prob.shape[1], 1)
 
 
 class Graph(_BaseGraph):
@@ -321,7 +328,8 @@ class Graph(_BaseGraph):
                     self.nerf.band_weights(opt, ops.LVIEW), opt.arch.density_activ, u=u, ndc_near=1.0 if opt.camera.ndc else None, n_fine=Sf,
                     packed_fine=None if fine is None else fine._state.packed(), pdf_range=opt.nerf.depth.range,
                     bg=opt.data.bgcolor if opt.nerf.setbg_opaque else None, band_dev=self.nerf.band_dev,
-                    bands_fine=None if fine is None else (fine.band_weights(opt, ops.L3D), fine.band_weights(opt, ops.LVIEW), fine.band_dev))
+                    bands_fine=None if fine is None else (fine.band_weights(opt, ops.L3D), fine.band_weights(opt, ops.LVIEW), fine.band_dev),
+                    precision=self.nerf._state.precision)
                 if count == total:
                     return edict(part)
                 if image is None:

@@ -16,6 +16,8 @@ GRAD_ROWS = 2336
 L3D, LVIEW = 10, 4
 TRAIN_LAUNCH_SAMPLES = (1 << 31) // (288 * 4)          # samples per differentiable field_mlp launch (see field_mlp)
 ACT = {"relu": 0, "softplus": 1}
+PREC = {"fp32": 0, "bf16x3": 1, "bf16": 2}         # enum niw_precision (include/niw.h); "fp32" = exact, the default everywhere
+BWD_PRECISIONS = {"fp32"}                            # precisions whose backward kernels exist (others: exact-fp32 backward)
 
 
 def _p(t):
@@ -172,7 +174,7 @@ def sample_pdf_merge(pdf, depth_coarse, Sf, depth_range):
 
 
 def render_fwd(intr, pose, H, W, pixel_range, n_samples, depth_range, inverse_depth, packed, band3d, bandview, activ, u=None, ndc_near=None,
-               n_fine=0, packed_fine=None, pdf_range=None, bg=None, band_dev=None, bands_fine=None):
+               n_fine=0, packed_fine=None, pdf_range=None, bg=None, band_dev=None, bands_fine=None, precision="fp32"):
     """Gradient-free render of the pixels `pixel_range` = (first, count) of every view as ONE library call (niw_render_fwd): rays,
     NDC (when `ndc_near` is given), stratified depths from `u` [B*count, S] (None: mid-points), field MLP, compositing and, when
     n_fine > 0, the inverse-CDF / merge / fine-network pass.  `packed` / `packed_fine`: FieldState.packed() images; `bands_fine` = (band3d, bandview, band_dev) of the fine
@@ -188,7 +190,7 @@ def render_fwd(intr, pose, H, W, pixel_range, n_samples, depth_range, inverse_de
     d = _lib.RenderDesc(intr=intr.data_ptr(), pose=pose.data_ptr(), n_views=B, H=H, W=W, ndc=0 if ndc_near is None else 1, first_pixel=first,
                         n_pixels=count, ndc_near=0.0 if ndc_near is None else float(ndc_near), depth_min=float(depth_range[0]),
                         depth_max=float(depth_range[1]), inverse_depth=1 if inverse_depth else 0, n_samples=n_samples, n_fine=n_fine,
-                        density_activ=ACT[activ], has_bg=0 if bg is None else 1, bg=0.0 if bg is None else float(bg),
+                        density_activ=ACT[activ], precision=PREC[precision], has_bg=0 if bg is None else 1, bg=0.0 if bg is None else float(bg),
                         u=None if u is None else u.data_ptr(), packed=packed.data_ptr(), band_dev=None if band_dev is None else band_dev.data_ptr())
     b3, bv = _farr(band3d, L3D), _farr(bandview, LVIEW)
     d.band_w3d, d.band_wview = ctypes.cast(b3, ctypes.POINTER(ctypes.c_float)), ctypes.cast(bv, ctypes.POINTER(ctypes.c_float))
@@ -225,11 +227,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999
 # ------------------------------------------------------------------------------------------
 
 class FieldState:
-    """Flat parameter storage of one NeRF MLP + the packed-weight cache."""
+    """Flat parameter storage of one NeRF MLP + the packed-weight cache.  `precision` selects the arithmetic of the field MLP
+    (PREC: "fp32" exact -- the default --, "bf16x3" / "bf16" the opt-in fast modes of include/niw.h)."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, precision="fp32"):
         assert flat.numel() == NERF_PARAM_FLOATS
         self.flat = flat
+        self._held = None
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        if precision not in PREC:
+            raise _lib.NiwError(f"field MLP precision {precision!r}: choose from {sorted(PREC)}")
+        self.precision = precision
         self._held = None
 
     @contextlib.contextmanager
@@ -242,15 +252,18 @@ class FieldState:
             self._held = None
 
     def packed(self):
-        """Re-pack on every call (outside hold()): the parameters are views of `flat` updated in place by any
-        optimizer, which no version counter of `flat` observes; packing 2.4 M floats costs ~50 us next to a
-        multi-millisecond MLP launch.  A fresh buffer is returned so that a pending backward keeps the weights its
+        """The weight image of the state's precision class.  Re-packed on every call (outside hold()): the parameters are views of
+        `flat` updated in place by any optimizer, which no version counter of `flat` observes; packing 2.4 M floats costs ~50 us
+        next to a multi-millisecond MLP launch.  A fresh buffer is returned so that a pending backward keeps the weights its
         forward used."""
         return self._held if self._held is not None else self._pack()
 
     _index = {}          # device -> gather table of the packed layout (architecture constant, built once)
 
     def _pack(self):
+        return self.packed_fp32() if self.precision == "fp32" else self._pack_fast()
+
+    def packed_fp32(self):
         n = _lib.load().niw_mlp_packed_floats()
         key = str(self.flat.device)
         if key not in FieldState._index:
@@ -260,6 +273,13 @@ class FieldState:
         packed = torch.empty(n, device=self.flat.device, dtype=torch.float32)
         _lib.call("niw_mlp_pack_weights_indexed", _p(self.flat), _p(FieldState._index[key]), _p(packed), _stream())
         return packed
+
+    def _pack_fast(self):
+        """split-bf16 image (hi / mid planes in MFMA fragment order, niw_mlp_pack_weights_prec); one image serves bf16x3 and bf16"""
+        n = _lib.load().niw_mlp_packed_bytes(PREC[self.precision])
+        image = torch.empty(n // 4, device=self.flat.device, dtype=torch.float32)
+        _lib.call("niw_mlp_pack_weights_prec", _p(self.flat), PREC[self.precision], _p(image), _stream())
+        return image
 
     def _pack_decode(self):
         n = _lib.load().niw_mlp_packed_floats()
@@ -291,9 +311,13 @@ class _FieldMLP(torch.autograd.Function):
             noise = _f32(noise, "noise")
         with timed("mlp_fwd_train" if need else "mlp_fwd", n_rays * S):
             _lib.call("niw_mlp_fwd", _p(packed), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
-                      b3, bv, _p(band_dev), ACT[activ], _p(rgb), _p(sigma), _p(save), _stream())
+                      b3, bv, _p(band_dev), ACT[activ], PREC[state.precision], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
-        ctx.save_ws, ctx.packed, ctx.grad_sink = save, packed, grad_sink
+        # the backward of the fast modes that has no kernel of its own yet runs on the exact-fp32 kernels (the forward's saves are the
+        # same fp32 workspace in every mode) and needs the fp32 image of the same weights
+        ctx.bwd_precision = state.precision if state.precision in BWD_PRECISIONS else "fp32"
+        ctx.save_ws, ctx.grad_sink = save, grad_sink
+        ctx.packed = packed if (not need or ctx.bwd_precision == state.precision) else state.packed_fp32()
         ctx.set_materialize_grads(False)
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(center, ray, depth, rgb)
@@ -315,15 +339,15 @@ class _FieldMLP(torch.autograd.Function):
         sink = ctx.grad_sink
         d_params = sink if sink is not None else torch.empty(NERF_PARAM_FLOATS, device=dev, dtype=torch.float32)
         ray_grad = ctx.needs_input_grad[8] or ctx.needs_input_grad[9]
-        d_both = torch.zeros(2, n_rays, 3, device=dev, dtype=torch.float32) if ray_grad else None     # accumulated by atomics: one fill for both
+        d_both = torch.empty(2, n_rays, 3, device=dev, dtype=torch.float32) if ray_grad else None      # overwritten (fixed-order per-ray sums)
         d_center, d_ray = (d_both[0], d_both[1]) if ray_grad else (None, None)
         with timed("mlp_bwd_dx", n_rays * S):
-            _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], _p(rgb),
+            _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], PREC[ctx.bwd_precision], _p(rgb),
                       _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(d_center), _p(d_ray), _stream())
         # (running this group on a second stream beside the rest of the backward was tried: once the seven 256 x 256
         # pieces became one 511-workgroup launch it fills the chip by itself and the overlap cost 40 %)
         with timed("mlp_bwd_dw", n_rays * S):
-            _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, _p(partial), _p(d_params), _stream())
+            _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, PREC[ctx.bwd_precision], _p(partial), _p(d_params), _stream())
         ctx.save_ws = None
         grads, off = [], 0
         for shp in ctx.param_shapes:
@@ -379,7 +403,7 @@ class _Composite(torch.autograd.Function):
         rgb = torch.empty(N, 3, device=dev)
         depth = torch.empty(N, device=dev)
         opacity = torch.empty(N, device=dev)
-        prob = torch.empty(N, S, device=dev)
+        prob = torch.empty(N, S if S > 1 else 0, device=dev)      # S = 1: the reference's weights are EMPTY (nerf.py:461-462, see niw.h)
         with timed("composite_fwd", N * S):
             _lib.call("niw_composite_fwd", _p(ray), _p(rgb_s), _p(sigma_s), _p(depth_s), N, S, 0 if bg is None else 1,
                       0.0 if bg is None else float(bg), _p(rgb), _p(depth), _p(opacity), _p(prob), _stream())

@@ -76,9 +76,11 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
     # null pointers
     cases = {
         "niw_mlp_pack_weights": (None, None, None),
-        "niw_mlp_fwd": (None,) * 5 + (4, 8, None, None, None, 1, None, None, None, None),
-        "niw_mlp_bwd_dx": (None,) * 4 + (4, 8, 1) + (None,) * 8,
-        "niw_mlp_bwd_dw": (None, None, 4, 8, None, None, None),
+        "niw_mlp_fwd": (None,) * 5 + (4, 8, None, None, None, 1, 0, None, None, None, None),
+        "niw_mlp_bwd_dx": (None,) * 4 + (4, 8, 1, 0) + (None,) * 8,
+        "niw_mlp_bwd_dw": (None, None, 4, 8, 0, None, None, None),
+        "niw_mlp_pack_weights_prec": (None, 1, None, None),
+        "niw_sample_stratified_rng": (1, 1, None, 4, 8, 0.0, 1.0, 0, None, None, None),
         "niw_composite_bwd": (None,) * 4 + (4, 8, 0, 0.0) + (None,) * 8,
         "niw_sample_stratified": (None, 4, 8, 0.0, 1.0, 0, None, None),
         "niw_raygen": (None, None, None, 0, 2, 4, 8, 8, 0, None, None, None),
@@ -98,9 +100,15 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
         rc = getattr(lib, name)(*args)
         assert rc == -1 and err(), (name, rc, err())
     # sizes / enums (pointers non-null)
-    assert lib.niw_mlp_fwd(p, p, p, p, None, 0, 8, None, None, None, 1, p, p, None, None) == -1 and "positive" in err()
-    assert lib.niw_mlp_fwd(p, p, p, p, None, 4, 8, None, None, None, 7, p, p, None, None) == -1 and "activation" in err()
-    assert lib.niw_mlp_fwd(p, p, p, p, None, 1 << 20, 64, None, None, None, 1, p, p, None, None) == -1 and "too many samples" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 0, 8, None, None, None, 1, 0, p, p, None, None) == -1 and "positive" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 4, 8, None, None, None, 7, 0, p, p, None, None) == -1 and "activation" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 4, 8, None, None, None, 1, 5, p, p, None, None) == -1 and "precision" in err()
+    assert lib.niw_mlp_fwd(p, p, p, p, None, 1 << 20, 64, None, None, None, 1, 0, p, p, None, None) == -1 and "too many samples" in err()
+    assert lib.niw_mlp_pack_weights_prec(p, 9, p, None) == -1 and "precision" in err()
+    # the images of the precision classes: fp32 = the packed floats; the split-bf16 image holds two bf16 planes of the forward and
+    # of the transposed (dX) fragments, i.e. about as many bytes
+    assert lib.niw_mlp_packed_bytes(0) == 4 * lib.niw_mlp_packed_floats()
+    assert lib.niw_mlp_packed_bytes(1) == lib.niw_mlp_packed_bytes(2) > 4 * 527872
     assert lib.niw_warp_prep_fwd(p, p, 65, p, p, p, p, None) == -1 and "views" in err()
     assert lib.niw_warp_prep_fwd(p, p, 0, p, p, p, p, None) == -1
     # the one-call render: null descriptor, incomplete descriptor, pixel range outside the image, fine pass without its tables

@@ -59,15 +59,22 @@ def test_mlp_inverse_depth_extremes_stay_finite_and_match():
     close(rgb[:, :2], rgb_ref[0][:, :2]); close(sig[:, :2], sig_ref[0][:, :2], atol=5e-5, rtol=2e-4)
 
 
-def test_composite_single_sample_is_rejected():
-    """reference nerf.py:461-462: the closing 1e10 interval is empty_like(intervals[..., :1]); with S = 1 that slice is
-    empty, so the reference returns all-zero outputs and an EMPTY prob.  The boundary refuses S = 1 instead."""
+@pytest.mark.parametrize("bg", [None, 0.75])
+def test_composite_single_sample_degenerates_like_the_reference(bg):
+    """reference nerf.py:461-462: the closing 1e10 interval is empty_like(intervals[..., :1]); with S = 1 that slice is empty, the
+    sample gets no interval, the weights are an EMPTY tensor and rgb / depth / opacity are sums over nothing (rgb = the background
+    colour under setbg_opaque).  Rounds 1-2 refused S = 1; now the boundary returns what the reference returns, gradients included."""
     from neural_invertible_warp_amd import ops
-    from neural_invertible_warp_amd._lib import NiwError
-    ref = O.composite(torch.randn(1, 2, 3), torch.rand(1, 2, 1, 3), torch.rand(1, 2, 1), torch.rand(1, 2, 1, 1))
+    ray, rgb_s, sig, dep = torch.randn(1, 2, 3), torch.rand(1, 2, 1, 3), torch.rand(1, 2, 1), torch.rand(1, 2, 1, 1)
+    ref = O.composite(ray, rgb_s, sig, dep)
     assert ref[3].numel() == 0 and float(ref[0].abs().max()) == 0.0
-    with pytest.raises(NiwError, match="at least 2 samples"):
-        ops.composite(torch.randn(2, 3, device=DEV), torch.rand(2, 1, 3, device=DEV), torch.rand(2, 1, device=DEV), torch.rand(2, 1, device=DEV))
+    a, b, c = g(ray[0]).requires_grad_(True), g(rgb_s[0]).requires_grad_(True), g(sig[0]).requires_grad_(True)
+    rgb, depth, opacity, prob = ops.composite(a, b, c, g(dep[0, :, :, 0]), bg)
+    assert prob.shape == (2, 0)
+    assert torch.equal(rgb.cpu(), ref[0][0] + (bg or 0.0)) and torch.equal(depth.cpu(), ref[1][0, :, 0]) and torch.equal(opacity.cpu(), ref[2][0, :, 0])
+    (rgb.sum() + depth.sum() + opacity.sum()).backward()
+    for x in (a, b, c):
+        assert x.grad is not None and float(x.grad.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("S", [2, 3, 65])

@@ -1,0 +1,129 @@
+"""The opt-in fast-precision modes of the field MLP (include/niw.h enum niw_precision; csrc/niw_mlp_fast.hip): their own parity row.
+
+    bf16x3   two bf16 planes per operand, hi*hi + hi*mid + mid*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+    bf16     the leading plane only
+
+Neither is ever the default and neither carries a claim at the reference's fp32 tolerance.  Measured against the oracle (the
+reference's fp32 arithmetic, CPU) on the same inputs, NEXT TO the exact mode's error on those inputs, with the tolerance each mode is
+held to written here:
+
+    mode      rgb / opacity-class outputs            raw density                   gradients (of max)
+    fp32      atol 2e-5 rtol 1e-4 (the exact bar)    5e-5 / 2e-4                   5e-3
+    bf16x3    atol 5e-5 (measured 0.9e-5 .. 1.8e-5:   1e-4 relative                 2e-2
+              inside the exact bar on these inputs)
+    bf16      atol 2e-2 (SURVEY 8(c)'s bf16 class)    --                            PSNR-level checks only
+
+Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import niw_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _state(seed, precision):
+    from neural_invertible_warp_amd import ops
+    p = O.make_nerf_params(seed)
+    flat = torch.cat([p[f"{n}.{k}"].reshape(-1) for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]).to(DEV)
+    return p, ops.FieldState(flat, precision=precision)
+
+
+def _rays(N, S, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    center = torch.from_numpy((rng.standard_normal((N, 3)) * 0.1).astype(np.float32))
+    ray = torch.from_numpy((rng.standard_normal((N, 3)) * spread).astype(np.float32))
+    depth = torch.from_numpy(np.sort(rng.uniform(0.5, 4.0, (N, S)), axis=1).astype(np.float32))
+    return center, ray, depth
+
+
+def _oracle(p, center, ray, depth, w3, wv):
+    rgb, sig = O.forward_samples(p, center[None], ray[None], depth[None, :, :, None], density_activ="softplus",
+                                 w3d=torch.tensor(w3), wview=torch.tensor(wv))
+    return rgb[0].double(), sig[0].double()
+
+
+@pytest.mark.parametrize("N,S", [(7, 5), (64, 32), (333, 64)])
+def test_forward_error_of_every_precision_mode_against_the_oracle(N, S):
+    from neural_invertible_warp_amd import ops
+    w3 = [1.0] * 6 + [0.7, 0.2, 0.0, 0.0]              # a c2f state: upper bands partly masked, as in training
+    wv = [1.0, 1.0, 0.5, 0.0]
+    center, ray, depth = _rays(N, S, 3 * N + S)
+    errs = {}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        p, st = _state(5, prec)
+        with torch.no_grad():
+            rgb, sig = ops.field_mlp(st, [], center.to(DEV), ray.to(DEV), depth.to(DEV), w3, wv, "softplus")
+        rgb64, sig64 = _oracle(p, center, ray, depth, w3, wv)
+        assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(sig).all())
+        errs[prec] = (float((rgb.cpu().double() - rgb64).abs().max()), float(((sig.cpu().double() - sig64).abs() / (1 + sig64.abs())).max()))
+    print(f"{N} x {S}: max |rgb - oracle| / relative sigma error: " + ", ".join(f"{k} {a:.2e} / {b:.2e}" for k, (a, b) in errs.items()))
+    assert errs["fp32"][0] < 2e-5 and errs["fp32"][1] < 2e-4
+    assert errs["bf16x3"][0] < 5e-5 and errs["bf16x3"][1] < 1e-4
+    assert errs["bf16"][0] < 2e-2
+    assert errs["fp32"][0] <= errs["bf16x3"][0] <= errs["bf16"][0] + 1e-9           # the modes are ordered
+
+
+def test_fast_image_is_the_split_of_the_parameters():
+    """Known answer for the image builder: with integer-valued weights below 2^8 the hi plane is exact and the mid plane zero; a
+    one-hot weight lands in exactly one fragment element (checked through the forward: the network then routes one input slot)."""
+    from neural_invertible_warp_amd import _lib, ops
+    lib = _lib.load()
+    n = lib.niw_mlp_packed_bytes(1)
+    flat = torch.zeros(ops.NERF_PARAM_FLOATS, device=DEV)
+    flat[:1000] = torch.arange(1000, device=DEV).float() % 200                 # exactly representable in bf16
+    image = torch.empty(n // 4, device=DEV, dtype=torch.float32)
+    _lib.call("niw_mlp_pack_weights_prec", ops._p(flat), 1, ops._p(image), ops._stream())
+    words = image.view(torch.int32).cpu().numpy().view(np.uint32)
+    hi_vals = set()
+    # every 2 KiB fragment = plane 0 (hi) then plane 1 (mid), 1 KiB each; the bias section at the end is fp32
+    frag_bytes = n - 4 * (8 * 9 + 9 + 4 + 1) * 32
+    frags = words[:frag_bytes // 4].reshape(-1, 2, 256)
+    assert not frags[:, 1].any()                                              # mid planes all zero
+    for w in np.unique(frags[:, 0]):
+        for half in (w & 0xffff, w >> 16):
+            hi_vals.add(float(np.array([half << 16], dtype=np.uint32).view(np.float32)[0]))
+    assert hi_vals <= set(float(x) for x in range(200)) and len(hi_vals) > 100
+
+
+def test_training_step_with_a_fast_forward_trains_like_the_exact_one():
+    """Fast forward + (until the fast backward exists) exact backward on the same saved activations: 20 steps of the INN engine in
+    bf16x3 follow the exact engine's loss curve to 2 % and reduce the loss."""
+    from neural_invertible_warp_amd import configs, engine
+
+    def run(precision):
+        opt = configs.cfg3_barf_inn_llff(device=DEV)
+        opt.arch.precision = precision
+        opt.H, opt.W = 24, 32
+        opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = 5 * 64, 64, 200
+        var0 = engine.synthetic_scene(opt, 5)
+        tr = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=3)
+        return [float(tr.train_iteration(type(var0)(var0)).render.detach()) for _ in range(20)]
+
+    exact, fast = run("fp32"), run("bf16x3")
+    assert fast[-1] < fast[0]
+    for a, b in zip(exact, fast):
+        assert abs(a - b) <= 2e-2 * a, (a, b)
+
+
+def test_full_image_render_in_bf16x3_matches_the_exact_render_at_psnr_level():
+    from neural_invertible_warp_amd import configs
+    from neural_invertible_warp_amd.model import nerf
+    imgs = {}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        opt = configs.cfg2_nerf_inn_llff_hier(device=DEV)
+        opt.H, opt.W = 60, 80
+        opt.nerf.sample_stratified = False
+        torch.manual_seed(0)
+        g = nerf.Graph(opt).to(DEV)
+        g.nerf.set_precision(prec)
+        g.nerf_fine.set_precision(prec)
+        with torch.no_grad():
+            intr = torch.tensor([[64.0, 0, 40], [0, 64.0, 30], [0, 0, 1]], device=DEV)[None]
+            imgs[prec] = g.render_by_slices(opt, torch.eye(3, 4, device=DEV)[None], intr=intr, mode="eval")
+    for prec, tol in (("bf16x3", 2e-4), ("bf16", 3e-2)):
+        for k in ("rgb", "rgb_fine", "opacity_fine"):
+            e = float((imgs[prec][k] - imgs["fp32"][k]).abs().max())
+            assert e < tol, (prec, k, e)

@@ -9,6 +9,7 @@ FLOP = 2 * 527872
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--sizes", default="252x128,504x128,1008x128,2034x128,4086x64,4086x192")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="arithmetic of the field MLP (include/niw.h enum niw_precision)")
     args = ap.parse_args()
     import torch
     from neural_invertible_warp_amd import _lib, ops
@@ -16,7 +17,9 @@ def main():
     dev = "cuda:0"; P = ops._p; lib = _lib.load()
     p = O.make_nerf_params(1)
     flat = torch.cat([p[f"{n}.{k}"].reshape(-1) for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]).to(dev)
-    st8 = ops.FieldState(flat); packed = st8.packed()
+    st8 = ops.FieldState(flat, precision=args.precision); packed = st8.packed()
+    prec = ops.PREC[args.precision]; bprec = prec if args.precision in ops.BWD_PRECISIONS else 0
+    bpacked = packed if bprec == prec else st8.packed_fp32()       # backward kernels that do not exist in a fast mode run exact
     for spec in args.sizes.split(","):
         N, S = (int(x) for x in spec.split("x"))
         M = N * S; mpad = lib.niw_mlp_padded_rows(N, S)
@@ -29,11 +32,11 @@ def main():
         dc = torch.zeros(N, 3, device=dev); dr = torch.zeros(N, 3, device=dev)
         b3 = ops._farr([1.0] * 10, 10); bv = ops._farr([1.0] * 4, 4); st = ops._stream()
         fns = dict(
-            fwd_eval=lambda: _lib.call("niw_mlp_fwd", P(packed), P(center), P(ray), P(depth), None, N, S, b3, bv, None, 1, P(rgb), P(sigma), None, st),
-            fwd_train=lambda: _lib.call("niw_mlp_fwd", P(packed), P(center), P(ray), P(depth), None, N, S, b3, bv, None, 1, P(rgb), P(sigma), P(save), st),
-            bwd_dx=lambda: _lib.call("niw_mlp_bwd_dx", P(packed), P(center), P(ray), P(depth), N, S, 1, P(rgb), P(d_rgb), P(d_sigma), P(save), P(gradws), P(dc), P(dr), st),
-            bwd_dw=lambda: _lib.call("niw_mlp_bwd_dw", P(save), P(gradws), N, S, P(partial), P(d_params), st))
-        line = dict(rays=N, samples=S, mlp_evals=M, workgroups=int(mpad // 128), lib=os.environ.get("NIW_LIB_PATH", "product"))
+            fwd_eval=lambda: _lib.call("niw_mlp_fwd", P(packed), P(center), P(ray), P(depth), None, N, S, b3, bv, None, 1, prec, P(rgb), P(sigma), None, st),
+            fwd_train=lambda: _lib.call("niw_mlp_fwd", P(packed), P(center), P(ray), P(depth), None, N, S, b3, bv, None, 1, prec, P(rgb), P(sigma), P(save), st),
+            bwd_dx=lambda: _lib.call("niw_mlp_bwd_dx", P(bpacked), P(center), P(ray), P(depth), N, S, 1, bprec, P(rgb), P(d_rgb), P(d_sigma), P(save), P(gradws), P(dc), P(dr), st),
+            bwd_dw=lambda: _lib.call("niw_mlp_bwd_dw", P(save), P(gradws), N, S, bprec, P(partial), P(d_params), st))
+        line = dict(precision=args.precision, backward_precision="fp32" if bprec == 0 else args.precision, rays=N, samples=S, mlp_evals=M, workgroups=int(mpad // 128), lib=os.environ.get("NIW_LIB_PATH", "product"))
         for name, fn in fns.items():
             fn(); fn()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
