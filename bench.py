@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_FWD = 2 * 527872           # algorithmic GEMM FLOPs per MLP evaluation
 PEAK_FP32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA = 2500.0         # TFLOP/s dense (the guide's ~2.5 PF; never the 2:1-sparsity figure)
 PEAK_HBM = 8000.0               # GB/s spec (6290 GB/s measured streaming copy)
 
 
@@ -188,13 +189,14 @@ def composite_scan(dev, iters=20):
                 traffic_source="profiles/r2_composite_traffic.json (rocprofv3 FETCH_SIZE x2 / WRITE_SIZE of the same launches)")
 
 
-def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True):
+def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, precision="fp32"):
     """-> (list of (trainer, var0, B, R_local, S, Sf), description, rays of the global batch per scene)"""
     from neural_invertible_warp_amd import configs, engine
     eff_world, eff_rank = (shard_of, 0) if shard_of else (world, rank)
     out, desc = [], None
 
     def mk(opt, B, rays, warp_perturb=0.02, dtu=False):
+        opt.arch.precision = precision                                              # arithmetic of the field MLP (include/niw.h enum niw_precision)
         opt.nerf.rand_rays = rays * (eff_world if scaling == "weak" else 1)        # global draw; each rank keeps idx[rank::world]
         if dtu:
             var0, init = engine.synthetic_dtu_scene(opt, B)
@@ -278,6 +280,10 @@ def main():
                          "default avoids capturing next to a live RCCL communicator)")
     ap.add_argument("--no-hip-graph", action="store_true", help="same as --hip-graph off")
     ap.add_argument("--kernel-steps", type=int, default=3, help="extra eager steps after the timed region for the per-kernel device-event table (0: skip)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
+                    help="arithmetic of the field MLP.  fp32 (default, the headline): exact fp32 MFMA.  bf16x3 / bf16: the opt-in fast modes "
+                         "(split-bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- a SEPARATE line with its own parity row "
+                         "(tests/test_gpu_fast_precision.py), never comparable with the reference's fp32 tolerance")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the torch.distributed process group even for ONE rank, so that the gradient all-reduce really goes through RCCL "
                          "(hardware evidence of the N > 1 code path on a 1-GPU box)")
@@ -313,7 +319,9 @@ def main():
     scaling = "strong" if args.shard_of else args.scaling
 
     use_graph = False if args.no_hip_graph else ((world == 1 and not args.force_dist) if args.hip_graph == "auto" else args.hip_graph == "on")
-    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph)
+    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph, precision=args.precision)
+    exact = args.precision == "fp32"
+    peak_mfma = PEAK_FP32_MFMA if exact else PEAK_BF16_MFMA
     evals_local = sum(B * R * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
 
     # the batch tensors stay resident at fixed addresses (the captured graph reads them in place)
@@ -400,7 +408,8 @@ def main():
         kernels[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in entry.items()}
     # roofline: the dominant SINGLE kernel (mlp_bwd_dw is a group of GEMM + reduce launches and is listed
     # under `kernels` only), so that its average can be checked against one row of the rocprofv3 summary
-    rocprof_name = {"mlp_fwd_train": "mlp_fwd_kernel<true>", "mlp_fwd": "mlp_fwd_kernel<false>", "mlp_bwd_dx": "mlp_bwd_dx_kernel"}
+    rocprof_name = {"mlp_fwd_train": "mlp_fwd_kernel<true>", "mlp_fwd": "mlp_fwd_kernel<false>", "mlp_bwd_dx": "mlp_bwd_dx_kernel"} if exact else \
+        {"mlp_fwd_train": "mlp_fwd_fast_kernel", "mlp_fwd": "mlp_fwd_fast_kernel", "mlp_bwd_dx": "mlp_bwd_dx_fast_kernel"}
     mlp = {k: v for k, v in kernels.items() if k in rocprof_name}
     dom = max(mlp, key=lambda k: mlp[k]["avg_ms"] * mlp[k]["launches"]) if mlp else None
     roofline = None
@@ -419,25 +428,29 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 pass
-        roofline = dict(bound="mfma", kernel=rocprof_name[dom], achieved=a, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=round(a / PEAK_FP32_MFMA, 4), traffic=traffic,
+        roofline = dict(bound="mfma", kernel=rocprof_name[dom], achieved=a, peak=peak_mfma, unit="TFLOP/s", frac=round(a / peak_mfma, 4), traffic=traffic,
                         avg_ms=kernels[dom]["avg_ms"], samples_per_launch=kernels[dom]["samples_per_launch"], flop_per_sample=FLOP_FWD,
                         rocprof=rocprof_row(args.config, rocprof_name[dom]))
     elif kernel_check is not None:
         # no trustworthy per-kernel table: the whole step against the train roofline (3 x forward FLOPs per sample) is all that can be claimed
         a = evals_total / world * args.steps / dt * 3 * FLOP_FWD / 1e12
-        roofline = dict(bound="mfma", kernel="whole train step (per-kernel table rejected)", achieved=round(a, 4), peak=PEAK_FP32_MFMA, unit="TFLOP/s",
-                        frac=round(a / PEAK_FP32_MFMA, 4), traffic=None)
+        roofline = dict(bound="mfma", kernel="whole train step (per-kernel table rejected)", achieved=round(a, 4), peak=peak_mfma, unit="TFLOP/s",
+                        frac=round(a / peak_mfma, 4), traffic=None)
 
     ms_step = dt / args.steps * 1e3
     value = evals_total * args.steps / dt
     par = f"ray-shard dp{world}" + (f" ({scaling} scaling)" if world > 1 else "") + (f"; 1/{args.shard_of} shard of the global batch" if args.shard_of else "")
     out = dict(metric="ray-samples/sec (warp+MLP+composite) on LLFF-fern, 1/2/4/8 GPUs + PSNR parity",
                value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
+               ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32" if exact else args.precision, data="synthetic",
                config=dict(workload=desc, name=args.config, rays_per_gpu=sum(B * R for _, _, B, R, _, _ in loads),
                            samples_per_ray="+".join(str(x) for x in ((loads[0][4], loads[0][4] + loads[0][5]) if loads[0][5] else (loads[0][4],))),
-                           mlp_evals_per_step_per_gpu=evals_local, parallelism=par, precision="exact fp32 MFMA"),
-               frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4),
+                           mlp_evals_per_step_per_gpu=evals_local, parallelism=par,
+                           precision="exact fp32 MFMA" if exact else
+                           f"{args.precision}: OPT-IN fast mode, split-bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation ("
+                           + ("hi*hi + hi*mid + mid*hi, 16 significand bits per operand" if args.precision == "bf16x3" else "leading plane only, 8 bits") +
+                           "); not the headline, own parity row in tests/test_gpu_fast_precision.py"),
+               frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4),
                loss=loss_value, hip_graph=graphed, ranks_seen=ranks_seen, backend=dist_backend, roofline=roofline, kernel_check=kernel_check, kernels=kernels)
     g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]
     S, Sf = loads[0][4], loads[0][5]
@@ -463,7 +476,7 @@ def main():
             t_img = time_image(lambda: g.render_by_slices(opt, pose1, intr=intr1, mode="eval", **kw))
             t_sweep = time_image(lambda: g._sweep_image(opt, lambda first, count: g._render_pixels(opt, pose1, intr1, "eval", pixel_range=(first, count), **kw)))
         n_eval = opt.H * opt.W * (S + (S + Sf if Sf else 0))
-        frac = lambda t: round(n_eval / t * FLOP_FWD / 1e12 / PEAK_FP32_MFMA, 4)
+        frac = lambda t: round(n_eval / t * FLOP_FWD / 1e12 / peak_mfma, 4)
         out["forward_only"] = dict(value=n_eval / t_img, unit="ray-samples/s", ms_per_image=round(t_img * 1e3, 2),
                                    workload=f"one {opt.H}x{opt.W} image, {S} coarse" + (f" + {S + Sf} fine" if Sf else "") + " samples per ray, "
                                             "one niw_render_fwd call",
@@ -473,7 +486,7 @@ def main():
     if world == 1 and not args.no_psnr_parity:
         # the "+ PSNR parity" half of the metric, bounded: 10 identical optimisation steps on the HIP path and on the CPU oracle
         from oracle import parity
-        pg, pc = parity.psnr_trajectories(dev, steps=10)
+        pg, pc = parity.psnr_trajectories(dev, steps=10, precision=args.precision)
         out["psnr_parity"] = dict(steps=len(pg), max_abs_diff_db=round(max(abs(a - b) for a, b in zip(pg, pc)), 5),
                                   final_psnr_hip=round(pg[-1], 4), final_psnr_oracle=round(pc[-1], 4),
                                   sample="barf_inn_llff, 3 views x 16 rays x 32 samples on 12x16 images, identical weights / pixel draws / stratified draws, "

@@ -11,6 +11,7 @@
 // scatters the result into the state-dict layout of d_params.
 #include "niw_common.h"
 #include "niw_mlp_device.h"
+#include "niw_bf16.h"
 #include <type_traits>
 
 using namespace niw;
@@ -215,6 +216,174 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
     if (tid < 256) out[TN * TK + tid] = bsum;
 }
 
+// The same product in the fast-precision modes (include/niw.h NIW_PREC_BF16X3 / NIW_PREC_BF16): the fp32 operands (quad-row images
+// only) are split into bf16 planes (hi, mid) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+// TERMS = 3: hi*hi + hi*mid + mid*hi, TERMS = 1: hi*hi.  Same split-M decomposition, same partial-tile format, same reduction kernel.
+//   * a 16-byte load is four rows of ONE sample; a bf16 dword needs TWO samples of one row, so neighbouring lanes (samples m, m ^ 1)
+//     swap two values each: the even lane then owns rows 0, 1 of the quad for both samples, the odd lane rows 2, 3;
+//   * LDS image of a 32-sample slice: [plane][row][64 B]; the four 16-byte chunks of a row (8 samples each = one MFMA operand
+//     fragment of a lane) are XOR-swizzled with (row >> 2) & 3, which makes the ds_read_b128 of 16 consecutive rows conflict free
+//     without padding (2 planes x 512 rows x 64 B x 2 buffers = 128 KiB for the wide tile);
+//   * bias sums are accumulated in fp32 from the staged registers (exact, like the fp32 path), not from the planes;
+//   * with a sixteenth / three sixteenths of the matrix time the kernel is bound by its HBM reads (the fp32 workspaces).
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, int TERMS>
+__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_fast_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
+                                                                    float* __restrict__ partial) {
+    const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
+    const int bias_side = batch.bias_side[blockIdx.y];
+    constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
+    constexpr int ROWS = TN + TK;
+    constexpr int LOADS = ROWS * 8 / NT, GROUP = NT / 8;
+    constexpr int PL = TERMS >= 3 ? 2 : 1;                  // planes kept in LDS
+    constexpr int PLANE_BYTES = ROWS * 64, BUF_BYTES = PL * PLANE_BYTES;
+    static_assert(ROWS * 8 % NT == 0 && TN % GROUP == 0, "tile must divide over the threads, each load entirely A or B");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int i = lane & 31, h = lane >> 5;
+    const int step0 = blockIdx.x * steps_per_wg;
+    bool live[NBW][KBW];
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y) live[x][y] = !SKIP || ((wn * NBW + x) * 32 < opA.rows && (wk * KBW + y) * 32 < opB.rows);
+    const int nsteps = min(steps_per_wg, steps_total - step0);
+    const int strideA4 = (int)opA.row_stride * 4, strideB4 = (int)opB.row_stride * 4;
+    const int cutA = (min(opA.rows, TN) + 3) / 4 * 4, cutB = (min(opB.rows, TK) + 3) / 4 * 4;
+    const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, cutA * strideA4, 0x00020000);
+    const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, cutB * strideB4, 0x00020000);
+    const int voffA = (tid >> 5) * 4 * strideA4 + (tid & 31) * 16, voffB = (tid >> 5) * 4 * strideB4 + (tid & 31) * 16;
+    constexpr int STEP_BYTES = 512;
+
+    f32x16 acc[NBW][KBW];
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    constexpr int SIDE_LOADS = LOADS / 2 > 0 ? LOADS : LOADS;   // (bias sums are kept per load slot; only one operand side is ever used)
+    float bsum[SIDE_LOADS][4];
+#pragma unroll
+    for (int k = 0; k < SIDE_LOADS; ++k)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bsum[k][jj] = 0.f;
+
+    f32x4 stage[PF][LOADS];
+    auto gload = [&](int step, int slot) {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const bool isA = k * GROUP < TN;
+            const int g = isA ? k * GROUP : k * GROUP - TN;
+            stage[slot][k] = isA ? buf_load4(rsA, voffA, step * STEP_BYTES + g * strideA4) : buf_load4(rsB, voffB, step * STEP_BYTES + g * strideB4);
+        }
+    };
+    // byte offset of dword w (two samples) of `row` inside a plane
+    auto lds_off = [&](int row, int w) { return row * 64 + ((((w >> 2) ^ (row >> 2)) & 3) << 4) + ((w & 3) << 2); };
+    auto lstore = [&](int buf, int slot) {
+        const int m = tid & 31, odd = m & 1, w = m >> 1;
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const f32x4 v = stage[slot][k];
+            const bool isA = k * GROUP < TN;
+            if ((bias_side == 1 && isA) || (bias_side == 2 && !isA)) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bsum[k][jj] += v[jj];
+            }
+            // the even lane keeps rows 0, 1 and receives them for sample m + 1; the odd lane keeps rows 2, 3 and receives them for m - 1
+            const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+            const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+            const float a0 = odd ? r0 : v[0], b0 = odd ? v[2] : r0;      // row (0 | 2): samples (m & ~1, m | 1)
+            const float a1 = odd ? r1 : v[1], b1 = odd ? v[3] : r1;      // row (1 | 3)
+            unsigned hi0, mid0, hi1, mid1;
+            split_pair(a0, b0, hi0, mid0);
+            split_pair(a1, b1, hi1, mid1);
+            const int row = k * GROUP + (tid >> 5) * 4 + 2 * odd;
+            char* base = ldsb + buf * BUF_BYTES;
+            *reinterpret_cast<unsigned*>(base + lds_off(row, w)) = hi0;
+            *reinterpret_cast<unsigned*>(base + lds_off(row + 1, w)) = hi1;
+            if (PL == 2) {
+                *reinterpret_cast<unsigned*>(base + PLANE_BYTES + lds_off(row, w)) = mid0;
+                *reinterpret_cast<unsigned*>(base + PLANE_BYTES + lds_off(row + 1, w)) = mid1;
+            }
+        }
+    };
+    auto step_body = [&](int s, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int buf = s & 1;
+        if (s + PF < nsteps) gload(step0 + s + PF, slot);
+        const char* base = ldsb + buf * BUF_BYTES;
+        // fragment of a lane: 8 consecutive samples (16 bytes) of its row: chunk 2 ks + h of the row
+        auto frag = [&](int plane, int row, int ks) {
+            return *reinterpret_cast<const u32x4_t*>(base + plane * PLANE_BYTES + row * 64 + ((((2 * ks + h) ^ (row >> 2)) & 3) << 4));
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4_t af[PL][NBW];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int x = 0; x < NBW; ++x) af[pl][x] = frag(pl, (wn * NBW + x) * 32 + i, ks);
+#pragma unroll
+            for (int y = 0; y < KBW; ++y) {
+                u32x4_t bf[PL];
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) bf[pl] = frag(pl, TN + (wk * KBW + y) * 32 + i, ks);
+#pragma unroll
+                for (int x = 0; x < NBW; ++x)
+                    if (live[x][y]) {
+                        if (TERMS >= 3) {
+                            acc[x][y] = mfma_bf16(af[0][x], bf[PL - 1], acc[x][y]);
+                            acc[x][y] = mfma_bf16(af[PL - 1][x], bf[0], acc[x][y]);
+                        }
+                        acc[x][y] = mfma_bf16(af[0][x], bf[0], acc[x][y]);
+                    }
+            }
+            if (ks == 0 && s + 1 < nsteps) lstore(buf ^ 1, (slot + 1) % PF);
+        }
+        __syncthreads();
+    };
+
+    if (nsteps > 0) {
+        gload(step0, 0);
+        lstore(0, 0);
+    }
+    if (PF == 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += PF) {
+        step_body(s, std::integral_constant<int, 0>{});
+        if (PF == 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+    }
+    float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[((wn * NBW + x) * 32 + acc_row(r, h)) * TK + (wk * KBW + y) * 32 + i] = acc[x][y][r];
+    // bias sums: reduce the 32 samples of a wave half (fixed xor tree), one write per row
+    if (tid < 256) out[TN * TK + tid] = 0.f;
+    __syncthreads();
+    if (bias_side) {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const bool isA = k * GROUP < TN;
+            if ((bias_side == 1 && isA) || (bias_side == 2 && !isA)) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float v = bsum[k][jj];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    const int row = (isA ? k * GROUP : k * GROUP - TN) + (tid >> 5) * 4 + jj;
+                    if ((tid & 31) == 0 && row < 256) out[TN * TK + row] = v;
+                }
+            }
+        }
+    }
+}
+
 // Deterministic reduction of the partial tiles + scatter into the flat parameter gradient: ONE launch for all pieces of a
 // network (blockIdx.y = piece).
 struct ReduceArgs {
@@ -275,7 +444,13 @@ struct Piece {
     int n_off, k_off, transposed, bias, wide;   // wide: 256x256 tile, else 256x64
 };
 
-template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD>
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD, int TERMS>
+constexpr auto fast_or_exact() {
+    if constexpr (TERMS == 0) return dw_gemm_kernel<WN, WK, NBW, KBW, SKIP, PF, QUAD>;
+    else return dw_gemm_fast_kernel<WN, WK, NBW, KBW, SKIP, PF, TERMS>;
+}
+
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD, int TERMS = 0>
 int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32;
     const int steps_total = (int)(mpad / 32);
@@ -293,8 +468,9 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     nsplit = nsplit < 1 ? 1 : (nsplit > cap ? cap : nsplit);
     const int per = (steps_total + nsplit - 1) / nsplit;
     nsplit = (steps_total + per - 1) / per;
-    const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
-    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW, SKIP, PF, QUAD>;
+    static_assert(TERMS == 0 || QUAD, "the fast-precision loader reads quad-row images");
+    const size_t lds = TERMS == 0 ? 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float) : 2 * (size_t)(TERMS >= 3 ? 2 : 1) * (TN + TK) * 64;
+    auto kern = fast_or_exact<WN, WK, NBW, KBW, SKIP, PF, QUAD, TERMS>();
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM")) return rc;
     for (int b = 0; b < batches; ++b) {
@@ -313,16 +489,16 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     return NIW_OK;
 }
 
-template <bool QUAD>
+template <bool QUAD, int TERMS = 0>
 int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, float* partial, int* nsplit_out, hipStream_t st) {
     // tile shapes: 0 = 256 x 64, 1 = 256 x 256, 2 = 128 x 288 (the colour layer: 128 outputs x [256 features + 32 view slots])
 #ifndef NIW_DW_COLOUR_288
-    if (wide == 2) return launch_gemm<4, 2, 1, 5, true, NIW_DW_PF_COLOUR, QUAD>(batch, mpad, batches, partial, nsplit_out, st);
+    if (wide == 2) return launch_gemm<4, 2, 1, 5, true, NIW_DW_PF_COLOUR, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st);
 #else
-    if (wide == 2) return launch_gemm<4, 1, 1, 9, false, NIW_DW_PF_COLOUR, QUAD>(batch, mpad, batches, partial, nsplit_out, st);
+    if (wide == 2) return launch_gemm<4, 1, 1, 9, false, NIW_DW_PF_COLOUR, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st);
 #endif
-    return wide ? launch_gemm<4, 2, 2, 4, false, 1, QUAD>(batch, mpad, batches, partial, nsplit_out, st)
-                : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY, QUAD>(batch, mpad, batches, partial, nsplit_out, st);
+    return wide ? launch_gemm<4, 2, 2, 4, false, 1, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st)
+                : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st);
 }
 
 }  // namespace
@@ -408,7 +584,9 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
             gb.bias_side[b] = p.bias ? (p.transposed ? 2 : 1) : 0;
         }
         int nsplit = 0;
-        int rc = launch_shape<true>(g.wide, gb, mpad, g.n, partial + off, &nsplit, st);
+        int rc = precision == NIW_PREC_FP32   ? launch_shape<true>(g.wide, gb, mpad, g.n, partial + off, &nsplit, st)
+                 : precision == NIW_PREC_BF16X3 ? launch_shape<true, 3>(g.wide, gb, mpad, g.n, partial + off, &nsplit, st)
+                                                : launch_shape<true, 1>(g.wide, gb, mpad, g.n, partial + off, &nsplit, st);
         if (rc != NIW_OK) return rc;
         const long long tile = (long long)g.TN * g.TK + 256;
         for (int b = 0; b < g.n; ++b) {

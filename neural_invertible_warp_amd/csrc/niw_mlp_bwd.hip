@@ -8,6 +8,7 @@
 // of SURVEY section 8a; route (iii), the ray length, is niw_composite_bwd's).
 #include "niw_common.h"
 #include "niw_mlp_device.h"
+#include "niw_mlp_encode.h"
 
 using namespace niw;
 
@@ -84,41 +85,7 @@ struct AddStashEpilogue {
     __device__ __forceinline__ void epi(int nb, int r, float a, float p) { out[nb * 16 + r] = a + p; }
 };
 
-// d(point)/d(unit dir) from the gradient of the encoding slots and the saved encoding values:
-// d/dx [w sin(f x)] = f * (w cos(f x)),  d/dx [w cos(f x)] = -f * (w sin(f x)).
-template <int L, int NQ>
-__device__ __forceinline__ void enc_backward(const float (&de)[4 * NQ], const float* __restrict__ enc_row0, long long mpad,
-                                             unsigned qoff, int h, float (&dp)[3]) {
-    dp[0] = dp[1] = dp[2] = 0.f;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        // rows 8q + 4h + {0..3} of this sample: one quad of the saved encoding (qoff = h*Mpad + m)
-        const f32x4 e = reinterpret_cast<const f32x4*>(enc_row0 + (long long)(8 * q) * mpad)[qoff];
-        if (q == 0) {
-            // half 0: raw coordinates; half 1: pairs 0 and 1
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dp[c] += h ? 0.f : de[c];
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int pair = pr;
-                if (pair < 3 * L) {
-                    const float v = band_freq(pair % L) * (de[2 * pr] * e[2 * pr + 1] - de[2 * pr + 1] * e[2 * pr]);
-                    dp[pair / L] += h ? v : 0.f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int pair0 = 2 * (2 * q - 1) + pr, pair1 = 4 * q + pr;   // half 0 / half 1
-                const float core = de[4 * q + 2 * pr] * e[2 * pr + 1] - de[4 * q + 2 * pr + 1] * e[2 * pr];
-                if (pair0 < 3 * L) dp[pair0 / L] += h ? 0.f : band_freq(pair0 % L) * core;
-                if (pair1 < 3 * L) dp[pair1 / L] += h ? band_freq(pair1 % L) * core : 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);
-}
+// enc_backward(): niw_mlp_encode.h (shared with the fast-precision dX chain)
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -287,6 +254,13 @@ __global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __res
     }
 }
 
+// per-ray sums of the ray gradients the dX chain (either precision) parked in the first stash rows of `gradws`
+int niw_launch_ray_grad_reduce(const float* gradws, long long mpad, int64_t n_rays, int n_samples, float* d_center, float* d_ray, hipStream_t stream) {
+    ray_grad_reduce_kernel<<<(int)((n_rays + 3) / 4), 256, 0, stream>>>(gradws + (long long)kGradStashEnc * mpad, mpad, n_rays, n_samples, d_center, d_ray);
+    NIW_LAUNCH_CHECK("niw_mlp_bwd (ray-gradient reduction)");
+    return NIW_OK;
+}
+
 int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
                           int64_t n_rays, int n_samples, int density_activ, const float* rgb, const float* d_rgb,
                           const float* d_sigma, const float* save, float* gradws, float* d_center, float* d_ray,
@@ -298,10 +272,6 @@ int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float*
     a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
     mlp_bwd_dx_kernel<<<(int)(a.Mpad / 128), 256, 0, stream>>>(a);
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dX chain)");
-    if (a.ray_grad) {
-        ray_grad_reduce_kernel<<<(int)((n_rays + 3) / 4), 256, 0, stream>>>(gradws + (long long)kGradStashEnc * a.Mpad, a.Mpad, n_rays, n_samples,
-                                                                           d_center, d_ray);
-        NIW_LAUNCH_CHECK("niw_mlp_bwd (ray-gradient reduction)");
-    }
+    if (a.ray_grad) return niw_launch_ray_grad_reduce(gradws, a.Mpad, n_rays, n_samples, d_center, d_ray, stream);
     return NIW_OK;
 }

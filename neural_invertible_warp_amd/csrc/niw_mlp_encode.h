@@ -3,6 +3,7 @@
 // Reference: NeRF.positional_encoding, model/nerf.py:476-483 (+ the c2f band mask, model/barf_inn_llff.py:427-442).
 #pragma once
 #include "niw_common.h"
+#include "niw_mlp_device.h"
 
 namespace niw {
 
@@ -53,5 +54,41 @@ __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* _
     }
 }
 
+
+// d(point)/d(unit dir) from the gradient of the encoding slots and the saved encoding values:
+// d/dx [w sin(f x)] = f * (w cos(f x)),  d/dx [w cos(f x)] = -f * (w sin(f x)).
+template <int L, int NQ>
+__device__ __forceinline__ void enc_backward(const float (&de)[4 * NQ], const float* __restrict__ enc_row0, long long mpad,
+                                             unsigned qoff, int h, float (&dp)[3]) {
+    dp[0] = dp[1] = dp[2] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        // rows 8q + 4h + {0..3} of this sample: one quad of the saved encoding (qoff = h*Mpad + m)
+        const f32x4 e = reinterpret_cast<const f32x4*>(enc_row0 + (long long)(8 * q) * mpad)[qoff];
+        if (q == 0) {
+            // half 0: raw coordinates; half 1: pairs 0 and 1
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dp[c] += h ? 0.f : de[c];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int pair = pr;
+                if (pair < 3 * L) {
+                    const float v = band_freq(pair % L) * (de[2 * pr] * e[2 * pr + 1] - de[2 * pr + 1] * e[2 * pr]);
+                    dp[pair / L] += h ? v : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int pair0 = 2 * (2 * q - 1) + pr, pair1 = 4 * q + pr;   // half 0 / half 1
+                const float core = de[4 * q + 2 * pr] * e[2 * pr + 1] - de[4 * q + 2 * pr + 1] * e[2 * pr];
+                if (pair0 < 3 * L) dp[pair0 / L] += h ? 0.f : band_freq(pair0 % L) * core;
+                if (pair1 < 3 * L) dp[pair1 / L] += h ? band_freq(pair1 % L) * core : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);
+}
 
 }  // namespace niw

@@ -10,28 +10,14 @@
 #include "niw_mlp_device.h"
 #include "niw_mlp_encode.h"
 #include "niw_mlp_fast.h"
+#include "niw_bf16.h"
 
 using namespace niw;
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
 namespace {
 
-// two fp32 values -> one dword of two bf16 (round to nearest even, NaN kept: v_cvt_pk_bf16_f32); element 0 in the low half
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-// (hi, mid) planes of a pair: hi = bf16(x), mid = bf16(x - hi); x - hi is exact in fp32 (hi keeps the leading 8 significand bits)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid) {
-    hi = pack_bf16(a, b);
-    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
-    mid = pack_bf16(a - ha, b - hb);
-}
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const unsigned (&b)[4], f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, u32x4_t{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
+    return niw::mfma_bf16(a, u32x4_t{b[0], b[1], b[2], b[3]}, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -355,12 +341,229 @@ int niw_launch_mlp_fwd_fast(int precision, const void* image, const float* cente
     return NIW_OK;
 }
 
-// (the dX chain of the fast modes: below, once built)
+// ---------------------------------------------------------------------------------------------------------------------------
+// dX chain in the fast modes: dX[k][m] = sum_n W[n][k] dY[n][m] with the transposed fragments of the image (backward section), the
+// ReLU masks the forward recorded, every dY stored in fp32 for the dW pass -- the same workspace contents as the exact chain
+// (niw_mlp_bwd.hip), formed on split-bf16 operands.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float relu_keep(const u32x4_t& mk, int nb, int r, float a) {
+    const int keep = (int)(mk[nb >> 1] << (16 * (nb & 1) + r)) >> 31;       // sign bit record of the forward -> all ones / zero
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
+}
+// mask, planes for the next product, fp32 store of dY for the dW pass
+template <int NBOUT>
+struct FastMaskEpilogue {
+    u32x4_t mk;
+    unsigned (&out)[2][8 * NBOUT];
+    RowWindow grad;
+    float keep[2] = {0.f, 0.f};
+    __device__ __forceinline__ void acc_init(int, f32x16& c) const {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    }
+    __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
+        const float g0 = relu_keep(mk, nb, 2 * rp, a0), g1 = relu_keep(mk, nb, 2 * rp + 1, a1);
+        split_pair(g0, g1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
+        if (rp & 1) buf_store4(keep[0], keep[1], g0, g1, grad.rsrc(nb * 32), grad.voff4, 8 * (rp >> 1) * grad.pitch4);
+        else { keep[0] = g0; keep[1] = g1; }
+    }
+};
+// park a result in the stash rows (d encoding slots of the skip connection, d view-encoding slots)
+struct FastStashEpilogue {
+    RowWindow win;
+    float keep[2] = {0.f, 0.f};
+    __device__ __forceinline__ void acc_init(int, f32x16& c) const {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    }
+    __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
+        if (rp & 1) buf_store4(keep[0], keep[1], a0, a1, win.rsrc(nb * 32), win.voff4, 8 * (rp >> 1) * win.pitch4);
+        else { keep[0] = a0; keep[1] = a1; }
+    }
+};
+// the parked part is the value the accumulation STARTS from; the sum stays in registers
+template <int NBOUT>
+struct FastAddStashEpilogue {
+    RowWindow win;
+    float (&out)[16 * NBOUT];
+    __device__ __forceinline__ void acc_init(int nb, f32x16& c) const {
+        const rsrc_t r0 = win.rsrc(nb * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = buf_load4(r0, win.voff4, 8 * q * win.pitch4);
+            c[4 * q] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+        }
+    }
+    __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) { out[nb * 16 + 2 * rp] = a0; out[nb * 16 + 2 * rp + 1] = a1; }
+};
+
+struct FastBwdArgs {
+    const unsigned char* image;
+    const float* center;
+    const float* ray;
+    const float* depth;
+    const float* rgb;
+    const float* d_rgb;
+    const float* d_sigma;
+    const float* save;
+    float* grad;
+    long long M, Mpad;
+    int S, act, ray_grad;
+};
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool valid = m < a.M;
+    const long long mc = valid ? m : a.M - 1;
+    const unsigned qoff = (unsigned)((long long)h * a.Mpad + m);
+    const long long P = a.Mpad;
+    const PackedWeights pw{make_rsrc(a.image), reinterpret_cast<const float*>(a.image), lane * 16};
+    const int pitch4 = (int)(P * 4), voff4 = (int)(((long long)h * P + m) * 16);
+    auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };
+    const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    const char* mbase = reinterpret_cast<const char*>(a.save + (long long)kSaveMask * P) + wave_id * kMaskRecords * kMaskRecBytes;
+    auto mask_rec = [&](int i) {
+        const u32x4_t v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(mbase), lane * 16, i * kMaskRecBytes, 0));
+        return valid ? v : u32x4_t{0u, 0u, 0u, 0u};
+    };
+    u32x4_t mk_cur = mask_rec(8), mk_nxt = mask_rec(7);
+    const unsigned none[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    unsigned dy[2][64], nxt[2][64];
+    auto advance = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) dy[pl][i] = nxt[pl][i];
+    };
+    // ---- colour head: sigmoid' ; rows 0..2 of the reduction step = elements 0..2 of lane half 0
+    unsigned dy9p[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    {
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (h == 0 && valid) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float o = a.rgb[mc * 3 + t];
+                g[t] = a.d_rgb[mc * 3 + t] * o * (1.f - o);
+            }
+        }
+        reinterpret_cast<f32x4*>(a.grad + (long long)kGradRgb1 * P)[qoff] = f32x4{g[0], g[1], g[2], g[3]};
+        split_pair(g[0], g[1], dy9p[0][0], dy9p[1][0]);
+        split_pair(g[2], g[3], dy9p[0][1], dy9p[1][1]);
+    }
+    unsigned dyr[2][32];
+    {
+        FastMaskEpilogue<4> ep{mk_cur, dyr, gwin(kGradRgb0)};
+        stream_layer_bf<1, 0, 4, TERMS>(pw, fast_bwd_off(9), dy9p, none, ep);
+    }
+    // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = slot block 8 of 9)
+    if (a.ray_grad) {
+        FastStashEpilogue ep{gwin(kGradStashVenc)};
+        stream_layer_bf<8, 0, 1, TERMS>(pw, fast_bwd_off(8) + 8 * fast_rs(8) * kFragBytes, dyr, none, ep);
+    }
+    {
+        mk_cur = mk_nxt; mk_nxt = mask_rec(6);
+        FastMaskEpilogue<8> ep{mk_cur, dy, gwin(kGradY7)};
+        stream_layer_bf<8, 0, 8, TERMS>(pw, fast_bwd_off(8), dyr, none, ep);
+    }
+    // ---- density head: d sigma_raw = reduction row 256 of layer 7 = element 0 of lane half 0 of the 17th step
+    unsigned dsigp[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    {
+        float g = 0.f;
+        if (h == 0 && valid) {
+            const float raw = (a.save + (long long)kSaveSigma * P)[m];
+            const float dact = a.act == NIW_ACT_RELU ? (raw > 0.f ? 1.f : 0.f) : (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
+            g = a.d_sigma[mc] * dact;
+        }
+        reinterpret_cast<f32x4*>(a.grad + (long long)(kGradY7 + 256) * P)[qoff] = f32x4{g, 0.f, 0.f, 0.f};
+        split_pair(g, 0.f, dsigp[0][0], dsigp[1][0]);
+    }
+    // ---- layer 7 transposed (257 -> 256), mask with h7
+    {
+        mk_cur = mk_nxt; mk_nxt = mask_rec(5);
+        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin(6 * 256)};
+        stream_layer_bf<16, 1, 8, TERMS>(pw, fast_bwd_off(7), dy, dsigp, ep);
+        advance();
+    }
+    // ---- layers 6, 5 transposed
+#pragma unroll 1
+    for (int l = 6; l >= 5; --l) {
+        mk_cur = mk_nxt; mk_nxt = mask_rec(l - 2);
+        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
+        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_bwd_off(5) + (l - 5) * (8 * 16 * kFragBytes), dy, none, ep);
+        advance();
+    }
+    // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots = slot blocks 8, 9 of 10)
+    if (a.ray_grad) {
+        FastStashEpilogue ep{gwin(kGradStashEnc)};
+        stream_layer_bf<16, 0, 2, TERMS>(pw, fast_bwd_off(4) + 8 * fast_rs(4) * kFragBytes, dy, none, ep);
+    }
+    {
+        mk_cur = mk_nxt; mk_nxt = mask_rec(2);
+        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin(3 * 256)};
+        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_bwd_off(4), dy, none, ep);
+        advance();
+    }
+    // ---- layers 3, 2, 1 transposed
+#pragma unroll 1
+    for (int l = 3; l >= 1; --l) {
+        mk_cur = mk_nxt; mk_nxt = mask_rec(l >= 2 ? l - 2 : 0);
+        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
+        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_bwd_off(1) + (l - 1) * (8 * 16 * kFragBytes), dy, none, ep);
+        advance();
+    }
+    if (!a.ray_grad) return;
+    // ---- layer 0 transposed: 256 -> 64 encoding slots, starting from the parked skip-connection part
+    float denc[32], dvenc[16];
+    {
+        FastAddStashEpilogue<2> ep{gwin(kGradStashEnc), denc};
+        stream_layer_bf<16, 0, 2, TERMS>(pw, fast_bwd_off(0), dy, none, ep);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(a.grad + (long long)(kGradStashVenc + 8 * q) * P)[qoff];
+            dvenc[4 * q] = v[0]; dvenc[4 * q + 1] = v[1]; dvenc[4 * q + 2] = v[2]; dvenc[4 * q + 3] = v[3];
+        }
+    }
+    // ---- encodings -> point / direction -> per-sample ray gradients (fp32, as in the exact chain), parked for the per-ray reduction
+    float dp[3], du[3];
+    enc_backward<NIW_L3D, 8>(denc, a.save + (long long)kSaveEnc * P, P, qoff, h, dp);
+    enc_backward<NIW_LVIEW, 4>(dvenc, a.save + (long long)kSaveVenc * P, P, qoff, h, du);
+    const long long ri = mc / a.S;
+    const float d = a.depth[mc];
+    const float rx = a.ray[ri * 3], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];
+    const float nrm = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+    const float ux = rx / nrm, uy = ry / nrm, uz = rz / nrm;
+    const float dot = ux * du[0] + uy * du[1] + uz * du[2];
+    float gc[3] = {dp[0], dp[1], dp[2]};
+    float gr[3] = {dp[0] * d + (du[0] - ux * dot) / nrm, dp[1] * d + (du[1] - uy * dot) / nrm, dp[2] * d + (du[2] - uz * dot) / nrm};
+    if (!valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gc[c] = gr[c] = 0.f;
+    }
+    reinterpret_cast<f32x4*>(a.grad + (long long)kGradStashEnc * P)[qoff] =
+        h == 0 ? f32x4{gc[0], gc[1], gc[2], gr[0]} : f32x4{gr[1], gr[2], 0.f, 0.f};
+}
+
+}  // namespace
+
+int niw_launch_ray_grad_reduce(const float* gradws, long long mpad, int64_t n_rays, int n_samples, float* d_center, float* d_ray, hipStream_t stream);
+
 int niw_launch_mlp_bwd_dx_fast(int precision, const void* image, const float* center, const float* ray, const float* depth, int64_t n_rays,
                                int n_samples, int density_activ, const float* rgb, const float* d_rgb, const float* d_sigma, const float* save,
                                float* gradws, float* d_center, float* d_ray, hipStream_t stream) {
-    (void)precision; (void)image; (void)center; (void)ray; (void)depth; (void)n_rays; (void)n_samples; (void)density_activ; (void)rgb; (void)d_rgb;
-    (void)d_sigma; (void)save; (void)gradws; (void)d_center; (void)d_ray; (void)stream;
-    niw_set_error("niw_mlp_bwd_dx: the fast-precision dX chain is not built; use NIW_PREC_FP32 for the backward (the forward's saves are the same)");
-    return NIW_ERR_UNSUPPORTED;
+    FastBwdArgs a;
+    a.image = reinterpret_cast<const unsigned char*>(image);
+    a.center = center; a.ray = ray; a.depth = depth; a.rgb = rgb; a.d_rgb = d_rgb; a.d_sigma = d_sigma; a.save = save; a.grad = gradws;
+    a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
+    a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
+    const int blocks = (int)(a.Mpad / 128);
+    if (precision == NIW_PREC_BF16X3) mlp_bwd_dx_fast_kernel<3><<<blocks, 256, 0, stream>>>(a);
+    else mlp_bwd_dx_fast_kernel<1><<<blocks, 256, 0, stream>>>(a);
+    NIW_LAUNCH_CHECK("niw_mlp_bwd (dX chain, fast precision)");
+    if (a.ray_grad) return niw_launch_ray_grad_reduce(gradws, a.Mpad, n_rays, n_samples, d_center, d_ray, stream);
+    return NIW_OK;
 }

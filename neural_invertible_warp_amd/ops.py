@@ -17,7 +17,8 @@ L3D, LVIEW = 10, 4
 TRAIN_LAUNCH_SAMPLES = (1 << 31) // (288 * 4)          # samples per differentiable field_mlp launch (see field_mlp)
 ACT = {"relu": 0, "softplus": 1}
 PREC = {"fp32": 0, "bf16x3": 1, "bf16": 2}         # enum niw_precision (include/niw.h); "fp32" = exact, the default everywhere
-BWD_PRECISIONS = {"fp32"}                            # precisions whose backward kernels exist (others: exact-fp32 backward)
+DX_PRECISIONS = {"fp32", "bf16x3", "bf16"}           # precisions whose dX chain / dW GEMMs exist; a missing one falls back to the
+DW_PRECISIONS = {"fp32", "bf16x3", "bf16"}           # exact-fp32 kernel on the same (fp32) workspaces
 
 
 def _p(t):
@@ -315,9 +316,10 @@ class _FieldMLP(torch.autograd.Function):
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
         # the backward of the fast modes that has no kernel of its own yet runs on the exact-fp32 kernels (the forward's saves are the
         # same fp32 workspace in every mode) and needs the fp32 image of the same weights
-        ctx.bwd_precision = state.precision if state.precision in BWD_PRECISIONS else "fp32"
+        ctx.dx_precision = state.precision if state.precision in DX_PRECISIONS else "fp32"
+        ctx.dw_precision = state.precision if state.precision in DW_PRECISIONS else "fp32"
         ctx.save_ws, ctx.grad_sink = save, grad_sink
-        ctx.packed = packed if (not need or ctx.bwd_precision == state.precision) else state.packed_fp32()
+        ctx.packed = packed if (not need or ctx.dx_precision == state.precision) else state.packed_fp32()
         ctx.set_materialize_grads(False)
         ctx.param_shapes = [p.shape for p in params]
         ctx.save_for_backward(center, ray, depth, rgb)
@@ -342,12 +344,12 @@ class _FieldMLP(torch.autograd.Function):
         d_both = torch.empty(2, n_rays, 3, device=dev, dtype=torch.float32) if ray_grad else None      # overwritten (fixed-order per-ray sums)
         d_center, d_ray = (d_both[0], d_both[1]) if ray_grad else (None, None)
         with timed("mlp_bwd_dx", n_rays * S):
-            _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], PREC[ctx.bwd_precision], _p(rgb),
+            _lib.call("niw_mlp_bwd_dx", _p(ctx.packed), _p(center), _p(ray), _p(depth), n_rays, S, ACT[ctx.activ], PREC[ctx.dx_precision], _p(rgb),
                       _p(d_rgb), _p(d_sigma), _p(ctx.save_ws), _p(gradws), _p(d_center), _p(d_ray), _stream())
         # (running this group on a second stream beside the rest of the backward was tried: once the seven 256 x 256
         # pieces became one 511-workgroup launch it fills the chip by itself and the overlap cost 40 %)
         with timed("mlp_bwd_dw", n_rays * S):
-            _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, PREC[ctx.bwd_precision], _p(partial), _p(d_params), _stream())
+            _lib.call("niw_mlp_bwd_dw", _p(ctx.save_ws), _p(gradws), n_rays, S, PREC[ctx.dw_precision], _p(partial), _p(d_params), _stream())
         ctx.save_ws = None
         grads, off = [], 0
         for shp in ctx.param_shapes:

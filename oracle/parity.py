@@ -14,13 +14,14 @@ def psnr(mse):
     return -10.0 * math.log10(mse)
 
 
-def psnr_trajectories(dev, steps=25, B=3, H=12, W=16, R=16, S=32, seed=7):
+def psnr_trajectories(dev, steps=25, B=3, H=12, W=16, R=16, S=32, seed=7, precision="fp32"):
     """-> (psnr_hip[steps], psnr_oracle[steps]) of the photometric loss of a barf_inn_llff run (c2f encoding, annealed warp
     embedding, both Adam groups under ExponentialLR; no alignment term: its Kabsch solver is parity-unpinned)."""
     from neural_invertible_warp_amd import configs, engine
     from neural_invertible_warp_amd.util import edict
     opt = configs.cfg3_barf_inn_llff(device=dev, global_alignment=None)
     opt.H, opt.W = H, W
+    opt.arch.precision = precision                 # arithmetic of the HIP engine's field MLP; the oracle is always the reference's fp32
     opt.nerf.sample_intvs, opt.nerf.rand_rays = S, R * B
     tr = engine.INNTrainer(opt, B, warp_perturb=0.0, ray_sampler="randperm")     # the harness injects the pixel draw through torch.randperm
     pc, wp, lat = O.make_nerf_params(71), O.make_warp_params(72, 0.02), O.make_latent(73, B)

@@ -8,10 +8,10 @@ reference's fp32 arithmetic, CPU) on the same inputs, NEXT TO the exact mode's e
 held to written here:
 
     mode      rgb / opacity-class outputs            raw density                   gradients (of max)
-    fp32      atol 2e-5 rtol 1e-4 (the exact bar)    5e-5 / 2e-4                   5e-3
-    bf16x3    atol 5e-5 (measured 0.9e-5 .. 1.8e-5:   1e-4 relative                 2e-2
+    fp32      atol 2e-5 rtol 1e-4 (the exact bar)    2e-4 relative                 relative L2 3e-3  (measured 1.6e-3)
+    bf16x3    atol 5e-5 (measured 0.9e-5 .. 1.8e-5:   1e-4 relative                 relative L2 2e-2  (measured 8.0e-3)
               inside the exact bar on these inputs)
-    bf16      atol 2e-2 (SURVEY 8(c)'s bf16 class)    --                            PSNR-level checks only
+    bf16      atol 2e-2 (SURVEY 8(c)'s bf16 class)    --                            relative L2 0.2   (measured 0.13)
 
 Needs a GPU."""
 import numpy as np
@@ -89,8 +89,8 @@ def test_fast_image_is_the_split_of_the_parameters():
 
 
 def test_training_step_with_a_fast_forward_trains_like_the_exact_one():
-    """Fast forward + (until the fast backward exists) exact backward on the same saved activations: 20 steps of the INN engine in
-    bf16x3 follow the exact engine's loss curve to 2 % and reduce the loss."""
+    """forward, dX chain and dW GEMMs all in bf16x3: 20 steps of the INN engine follow the exact engine's loss curve to 2 % and reduce
+    the loss"""
     from neural_invertible_warp_amd import configs, engine
 
     def run(precision):
@@ -127,3 +127,37 @@ def test_full_image_render_in_bf16x3_matches_the_exact_render_at_psnr_level():
         for k in ("rgb", "rgb_fine", "opacity_fine"):
             e = float((imgs[prec][k] - imgs["fp32"][k]).abs().max())
             assert e < tol, (prec, k, e)
+
+
+@pytest.mark.parametrize("prec,tol_l2,tol_max", [("fp32", 3e-3, 2e-2), ("bf16x3", 2e-2, 5e-2), ("bf16", 0.2, 0.5)])
+def test_backward_of_every_precision_mode_against_the_oracle(prec, tol_l2, tol_max):
+    """All gradients of the field MLP (parameters, ray origins, ray directions) of one evaluation, per mode, against autograd through
+    the oracle.  Two measures per tensor: the relative L2 error, and the max error relative to the tensor's max.  The second is
+    dominated, in EVERY mode, by the handful of ReLU units whose pre-activation lies within the forward's rounding error of zero (a
+    flipped unit changes a per-ray gradient discretely), which is why the exact mode itself sits at 1e-2 there on random incoming
+    gradients; the L2 measure separates the modes.  Measured (L2 / max): fp32 1.6e-3 / 9.4e-3, bf16x3 8.0e-3 / 2.4e-2, bf16 0.13 / 0.14."""
+    from neural_invertible_warp_amd import ops
+    N, S = 256, 64
+    w3, wv = [1.0] * 6 + [0.7, 0.2, 0.0, 0.0], [1.0, 1.0, 0.5, 0.0]
+    center, ray, depth = _rays(N, S, 77)
+    p, st = _state(9, prec)
+    names = [f"{n}.{k}" for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]
+    params, off = [], 0
+    for k in names:
+        n = p[k].numel()
+        params.append(st.flat[off:off + n].view(p[k].shape).requires_grad_(True))
+        off += n
+    c, r = center.to(DEV).requires_grad_(True), ray.to(DEV).requires_grad_(True)
+    rgb, sig = ops.field_mlp(st, params, c, r, depth.to(DEV), w3, wv, "softplus")
+    gen = torch.Generator().manual_seed(1)
+    g_rgb, g_sig = torch.randn(N, S, 3, generator=gen), torch.randn(N, S, generator=gen)
+    ((rgb * g_rgb.to(DEV)).sum() + (sig * g_sig.to(DEV)).sum()).backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    cr, rr = center.clone().requires_grad_(True), ray.clone().requires_grad_(True)
+    rgb_o, sig_o = O.forward_samples(pr, cr[None], rr[None], depth[None, :, :, None], density_activ="softplus", w3d=torch.tensor(w3), wview=torch.tensor(wv))
+    ((rgb_o[0] * g_rgb).sum() + (sig_o[0] * g_sig).sum()).backward()
+    pairs = [(k, prm.grad.cpu(), pr[k].grad) for k, prm in zip(names, params)] + [("d_center", c.grad.cpu(), cr.grad), ("d_ray", r.grad.cpu(), rr.grad)]
+    l2 = max(((k, float((a - b).norm() / b.norm().clamp_min(1e-30))) for k, a, b in pairs), key=lambda t: t[1])
+    mx = max(((k, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))) for k, a, b in pairs), key=lambda t: t[1])
+    print(f"{prec}: worst relative L2 gradient error {l2[1]:.2e} ({l2[0]}), worst max error {mx[1]:.2e} of max ({mx[0]})")
+    assert l2[1] < tol_l2 and mx[1] < tol_max, (l2, mx)

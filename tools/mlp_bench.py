@@ -18,7 +18,8 @@ def main():
     p = O.make_nerf_params(1)
     flat = torch.cat([p[f"{n}.{k}"].reshape(-1) for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]).to(dev)
     st8 = ops.FieldState(flat, precision=args.precision); packed = st8.packed()
-    prec = ops.PREC[args.precision]; bprec = prec if args.precision in ops.BWD_PRECISIONS else 0
+    prec = ops.PREC[args.precision]
+    bprec = prec if args.precision in ops.DX_PRECISIONS else 0; wprec = prec if args.precision in ops.DW_PRECISIONS else 0
     bpacked = packed if bprec == prec else st8.packed_fp32()       # backward kernels that do not exist in a fast mode run exact
     for spec in args.sizes.split(","):
         N, S = (int(x) for x in spec.split("x"))
@@ -35,8 +36,8 @@ def main():
             fwd_eval=lambda: _lib.call("niw_mlp_fwd", P(packed), P(center), P(ray), P(depth), None, N, S, b3, bv, None, 1, prec, P(rgb), P(sigma), None, st),
             fwd_train=lambda: _lib.call("niw_mlp_fwd", P(packed), P(center), P(ray), P(depth), None, N, S, b3, bv, None, 1, prec, P(rgb), P(sigma), P(save), st),
             bwd_dx=lambda: _lib.call("niw_mlp_bwd_dx", P(bpacked), P(center), P(ray), P(depth), N, S, 1, bprec, P(rgb), P(d_rgb), P(d_sigma), P(save), P(gradws), P(dc), P(dr), st),
-            bwd_dw=lambda: _lib.call("niw_mlp_bwd_dw", P(save), P(gradws), N, S, bprec, P(partial), P(d_params), st))
-        line = dict(precision=args.precision, backward_precision="fp32" if bprec == 0 else args.precision, rays=N, samples=S, mlp_evals=M, workgroups=int(mpad // 128), lib=os.environ.get("NIW_LIB_PATH", "product"))
+            bwd_dw=lambda: _lib.call("niw_mlp_bwd_dw", P(save), P(gradws), N, S, wprec, P(partial), P(d_params), st))
+        line = dict(precision=args.precision, dx_precision="fp32" if bprec == 0 else args.precision, dw_precision="fp32" if wprec == 0 else args.precision, rays=N, samples=S, mlp_evals=M, workgroups=int(mpad // 128), lib=os.environ.get("NIW_LIB_PATH", "product"))
         for name, fn in fns.items():
             fn(); fn()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
