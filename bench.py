@@ -18,8 +18,8 @@ Synthetic images, reference initialisation (+ N(0, 0.02) on the warp's zero-init
 Exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32); nothing is skipped or cached.
 
 ray-samples = MLP evaluations per step (coarse and fine both counted).  Scaling: `weak` (default) keeps the
-per-GPU ray count fixed (rank r renders pixels idx[r::N] of a global draw N times larger); `strong` keeps the reference's GLOBAL
-batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
+per-GPU ray count fixed (the global draw is N times larger; every rank warps all of it and renders a contiguous 1/N share of the
+B x R rays); `strong` keeps the reference's GLOBAL batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
 on one GPU: a proxy of what one rank of a K-GPU strong-scaled job executes (no collective).  Prints ONE JSON line on rank 0.
 
 At N = 1 the timed iterations replay ONE captured HIP graph each (engine.INNTrainer(hip_graph=True): forward, backward, gradient
@@ -204,10 +204,11 @@ def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, p
         else:
             var0 = engine.synthetic_scene(opt, B)
             tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, hip_graph=hip_graph)
-        R = (opt.nerf.rand_rays // B + eff_world - 1 - eff_rank) // eff_world       # rays per view on this rank
+        from neural_invertible_warp_amd import parallel
+        lo, hi = parallel.flat_share(B * (opt.nerf.rand_rays // B), eff_rank, eff_world)   # this rank's contiguous share of the B x R rays
         S = opt.nerf.sample_intvs
         Sf = opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0
-        out.append((tr, var0, B, R, S, Sf))
+        out.append((tr, var0, B, (hi - lo) / B, S, Sf))                              # (rays per view: fractional for a share)
         return opt
 
     if name == "cfg2":
@@ -322,7 +323,7 @@ def main():
     loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph, precision=args.precision)
     exact = args.precision == "fp32"
     peak_mfma = PEAK_FP32_MFMA if exact else PEAK_BF16_MFMA
-    evals_local = sum(B * R * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
+    evals_local = sum(int(round(B * R)) * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
 
     # the batch tensors stay resident at fixed addresses (the captured graph reads them in place)
     def step(replay=True):
@@ -372,8 +373,11 @@ def main():
             kern = ops.TIMING.summary()
             kernel_sum_ms = sum(n * ms for n, ms, _ in kern.values()) / args.kernel_steps
             ms_timed = dt / args.steps * 1e3
+            # (launch by launch the host can be the limit -- ~50 launches per iteration against a 1.2 ms shard step -- so the eager
+            # iteration may take longer than a replayed one; what must hold is that the kernels fit inside both)
             kernel_check = dict(kernel_sum_ms=round(kernel_sum_ms, 4), eager_ms_per_step=round(eager_ms, 4), timed_ms_per_step=round(ms_timed, 4),
-                                consistent=bool(kernel_sum_ms <= eager_ms and kernel_sum_ms <= 1.01 * ms_timed and eager_ms <= 1.05 * ms_timed))
+                                eager_host_bound=bool(eager_ms > 1.05 * ms_timed),
+                                consistent=bool(kernel_sum_ms <= eager_ms and kernel_sum_ms <= 1.01 * ms_timed))
             if kernel_check["consistent"]:
                 break
         if not kernel_check["consistent"]:
@@ -443,7 +447,7 @@ def main():
     out = dict(metric="ray-samples/sec (warp+MLP+composite) on LLFF-fern, 1/2/4/8 GPUs + PSNR parity",
                value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32" if exact else args.precision, data="synthetic",
-               config=dict(workload=desc, name=args.config, rays_per_gpu=sum(B * R for _, _, B, R, _, _ in loads),
+               config=dict(workload=desc, name=args.config, rays_per_gpu=sum(int(round(B * R)) for _, _, B, R, _, _ in loads),
                            samples_per_ray="+".join(str(x) for x in ((loads[0][4], loads[0][4] + loads[0][5]) if loads[0][5] else (loads[0][4],))),
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=par,
                            precision="exact fp32 MFMA" if exact else
@@ -495,7 +499,7 @@ def main():
     if world == 1 and not args.no_torch_baseline and not args.shard_of:
         rng_kw = dict(depth_range=(1.2, 5.2), param="metric") if args.config == "cfg5" else {}
         try:
-            out["torch_rocm_baseline"] = torch_rocm_baseline(dev, loads[0][2], loads[0][3], S, Sf, opt.H, opt.W, ga_weight=ga, **rng_kw)
+            out["torch_rocm_baseline"] = torch_rocm_baseline(dev, loads[0][2], int(round(loads[0][3])), S, Sf, opt.H, opt.W, ga_weight=ga, **rng_kw)
             out["torch_rocm_baseline"]["speedup_of_this_build"] = round(value / out["torch_rocm_baseline"]["value"], 2)
         except torch.cuda.OutOfMemoryError as e:          # a reported side figure must not cost the line
             out["torch_rocm_baseline"] = dict(error=f"out of memory: {e}"[:200])

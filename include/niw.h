@@ -310,9 +310,11 @@ int niw_align_loss(const float* target, const float* source, const float* poses,
  * model/base.py:209-211): gathers image[b,:,ray_idx] ([B,3,H*W] layout), writes
  * loss[0] = mean((rgb - image)^2) * 1 and d_rgb = scale * 2 (rgb - image) / (3*B*R_norm).
  * n_norm: element count used for the mean (= 3*B*R of the GLOBAL batch under ray sharding).
+ * first_ray, n_rays: rgb / d_rgb hold the rays [first_ray, first_ray + n_rays) of the flattened (view-major) [B][R] ray list -- one
+ * rank's contiguous share under ray sharding; n_rays <= 0 = the whole batch ([B,R,3]).
  * loss[0] is OVERWRITTEN (one workgroup, fixed-order reduction: bit-reproducible, no float atomics, no zero-fill). */
 int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx, int n_views,
-                    int64_t n_rays_per_view, int64_t hw, double n_norm, float grad_scale,
+                    int64_t n_rays_per_view, int64_t hw, int64_t first_ray, int64_t n_rays, double n_norm, float grad_scale,
                     float* loss, float* d_rgb, niw_stream_t stream);
 
 /* torch.optim.Adam step (model/nerf.py:34-38 uses it with default betas/eps) on a flat buffer.

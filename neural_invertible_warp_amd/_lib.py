@@ -61,7 +61,7 @@ SIGNATURES = {
     "niw_align_moments": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "niw_align_solve": (_i, [_vp, _i, _vp, _vp]),
     "niw_align_loss": (_i, [_vp, _vp, _vp, _i, _i64, _d, _vp, _vp, _vp]),
-    "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _d, _f, _vp, _vp, _vp]),
+    "niw_mse_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _d, _f, _vp, _vp, _vp]),
     "niw_render_fwd_workspace_floats": (_i64, [_i, _i64, _i, _i]),
     "niw_render_fwd": (_i, [ctypes.POINTER(RenderDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp, _vp]),

@@ -172,9 +172,13 @@ __global__ void ndc_kernel(const float* __restrict__ center, const float* __rest
 // one workgroup of 1024 threads over all B*R*3 elements: fixed-order reduction, loss[0] overwritten
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ image,
                                                    const int64_t* __restrict__ ray_idx, int B, long long R, long long hw,
+                                                   long long first_ray, long long n_rays,
                                                    double n_norm, float grad_scale, float* __restrict__ loss, float* __restrict__ d_rgb) {
+    // rgb / d_rgb hold the rays first_ray .. first_ray + n_rays - 1 of the flattened (view-major) [B][R] ray list: the whole batch, or one
+    // rank's contiguous share of it under ray sharding
     __shared__ double red[16];
-    const long long total = (long long)B * R * 3;
+    const long long total = n_rays * 3;
+    const unsigned first32 = (unsigned)first_ray;
     const double slope = (double)grad_scale * 2.0 / n_norm;        // d mean / d rgb = 2 diff / n (one fp64 divide per launch, not per element)
     double acc = 0.0;
     // Eight elements per thread per round, every load of the round issued before the first use: the pixel index and the image
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
             idx[k] = base + threadIdx.x + 1024ll * k;
             ok[k] = idx[k] < total;
             const unsigned i = ok[k] ? (unsigned)idx[k] : 0u;             // host guarantees total < 2^32
-            const unsigned br = i / 3u, c = i - br * 3u, b = br / R32, r = br - b * R32;
+            const unsigned lr = i / 3u, c = i - lr * 3u, br = first32 + lr, b = br / R32, r = br - b * R32;
             const long long pix = ray_idx ? ray_idx[r] : (long long)r;
             pred[k] = rgb[i];
             img[k] = image[((long long)b * 3 + c) * hw + pix];
@@ -323,12 +327,15 @@ extern "C" int niw_convert_ndc(const float* center, const float* ray, const floa
 }
 
 extern "C" int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx, int n_views,
-                               int64_t n_rays_per_view, int64_t hw, double n_norm, float grad_scale,
+                               int64_t n_rays_per_view, int64_t hw, int64_t first_ray, int64_t n_rays, double n_norm, float grad_scale,
                                float* loss, float* d_rgb, niw_stream_t stream) {
     NIW_REQUIRE(rgb && image && loss, "niw_mse_fwd_bwd: null pointer");
     NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && hw > 0 && n_norm > 0, "niw_mse_fwd_bwd: empty input");
     NIW_REQUIRE((long long)n_views * n_rays_per_view * 3 < (1ll << 32), "niw_mse_fwd_bwd: at most 2^32 colour values per call");
-    mse_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rgb, image, ray_idx, n_views, n_rays_per_view, hw, n_norm, grad_scale, loss, d_rgb);
+    if (n_rays <= 0) { first_ray = 0; n_rays = (int64_t)n_views * n_rays_per_view; }      // the whole batch
+    NIW_REQUIRE(first_ray >= 0 && first_ray + n_rays <= (int64_t)n_views * n_rays_per_view,
+                "niw_mse_fwd_bwd: rays [%lld, %lld) leave the %d x %lld batch", (long long)first_ray, (long long)(first_ray + n_rays), n_views, (long long)n_rays_per_view);
+    mse_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rgb, image, ray_idx, n_views, n_rays_per_view, hw, first_ray, n_rays, n_norm, grad_scale, loss, d_rgb);
     NIW_LAUNCH_CHECK("niw_mse_fwd_bwd");
     return NIW_OK;
 }

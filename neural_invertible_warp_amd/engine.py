@@ -302,18 +302,12 @@ class INNTrainer:
     def _capture(self, var, it):
         """Capture iteration `it` (it also executes on replay, below).  One graph for a single rank; under ray sharding two graphs
         (forward + backward + gather | Adam) with the RCCL all-reduce of the flat gradient bucket issued eagerly in between, so that
-        no collective is captured -- which also rules capture out while the alignment term all-reduces its Kabsch moments in the
-        middle of the forward: that case is recognised up front and stays eager (-> False).  A capture that fails while recording
-        is an error (NiwError)."""
+        no collective is captured.  A capture that fails while recording is an error (NiwError)."""
         import sys
         import torch.distributed as dist
         live_group = parallel._collectives_live()
-        if live_group and self.opt.loss_weight.get("global_alignment") is not None:
-            return self._give_up_capture("the sharded alignment loss all-reduces its moments inside the forward")
-        if live_group and self.family == "dtu":
-            # INNPoseParams registers the warped onto the initial points in EVERY train forward (pose_models/inn.py:96-102), with or
-            # without the alignment term, and under ray sharding that registration all-reduces its Kabsch moments
-            return self._give_up_capture("the DTU pose network's sharded rigid registration all-reduces its moments inside the forward")
+        # (round 3: no collective sits inside the forward any more -- the warp and the alignment term are replicated, ..parallel --
+        # so a sharded iteration is captured like any other: forward + backward + gather | all-reduce, eager | Adam)
         self._static_inputs = {k: v for k, v in var.items() if isinstance(v, torch.Tensor)}      # must stay alive and in place
         torch.cuda.synchronize()
         try:

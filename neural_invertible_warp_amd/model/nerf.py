@@ -233,11 +233,12 @@ class Graph(_BaseGraph):
         loss = edict()
         ray_idx = var.ray_idx if (opt.nerf.rand_rays and mode in ["train", "test-optim"]) else None
         n_norm = getattr(opt, "loss_norm_elements", None)
+        share = var.get("ray_share") if ray_idx is not None else None          # a rank's contiguous share of the B x R rays (..parallel)
         if opt.loss_weight.render is not None:
-            loss.render = ops.mse_gather(var.rgb, var.image, ray_idx, n_norm)
+            loss.render = ops.mse_gather(var.rgb, var.image, ray_idx, n_norm, share=share)
         if opt.loss_weight.render_fine is not None:
             assert opt.nerf.fine_sampling
-            loss.render_fine = ops.mse_gather(var.rgb_fine, var.image, ray_idx, n_norm)
+            loss.render_fine = ops.mse_gather(var.rgb_fine, var.image, ray_idx, n_norm, share=share)
         return loss
 
     def get_pose(self, opt, var, mode=None):

@@ -28,7 +28,7 @@ class Graph(nerf_inn_llff.Graph):
         if opt.nerf.rand_rays and mode == "train":
             var.ray_idx = self.draw_ray_idx(opt, batch_size, draw=iter)
             ray, center, grid_3d = self.get_pose(opt, var, mode=mode, iter=iter)
-            ret = self.render_local(opt, ray, center, intr=var.intr, mode=mode, depth_range=depth_range)
+            ret = self.render_share(opt, var, ray, center, mode=mode, depth_range=depth_range)
             ret.update(grid_local=grid_3d, center_local=center, grid_init=self.pose_net.grid_init, center_init=self.pose_net.center_init)
         elif opt.nerf.rand_rays and mode == "test-optim":
             # test-time pose refinement: random rays of the back-aligned (and refined) test pose.  The reference's DTU forward
@@ -66,10 +66,9 @@ class Graph(nerf_inn_llff.Graph):
         else:
             warped = torch.cat([var.grid_local, var.center_local], dim=1)
             initial = torch.cat([var.grid_init, var.center_init], dim=1)
-        views = warped.shape[0]
-        sharded = getattr(opt, "ray_shard", None) is not None
-        elements = 3 * views * (2 * (opt.nerf.rand_rays // views) if sharded else warped.shape[1])
-        loss.global_alignment = (nerf_inn_llff.ALIGN_BACKEND or ops).alignment_residual(warped, initial, self.pose_net.get_w2c_poses(), n_norm=elements)
+        world = (getattr(opt, "ray_shard", None) or (0, 1))[1]          # replicated term, weight 1 / world per rank (..parallel)
+        loss.global_alignment = (nerf_inn_llff.ALIGN_BACKEND or ops).alignment_residual(warped, initial, self.pose_net.get_w2c_poses(),
+                                                                                        n_norm=warped.numel() * world)
         return loss
 
     def render(self, opt, pose, intr=None, ray_idx=None, mode=None, depth_range=None):

@@ -52,7 +52,7 @@ class Graph(nerf.Graph):
                                                                           pose_init=None if opt.data.dataset != "blender" else pose_init)
                 var.center_cam, var.grid_cam = center_cam, grid_cam
                 ray, center, grid_3D, alpha_ratio = self.get_pose(opt, var, mode=mode, iter=iter)
-                ret = self.render_local(opt, ray, center, intr=var.intr, mode=mode)
+                ret = self.render_share(opt, var, ray, center, mode=mode)
                 ret.update(grid_3D=grid_3D, center=center, grid_cam=grid_cam, center_cam=center_cam, inn_posenc_alpha=alpha_ratio)
             else:
                 pose = self.get_pose(opt, var, mode=mode)
@@ -64,6 +64,22 @@ class Graph(nerf.Graph):
         var.update(ret)
         return var
 
+    def render_share(self, opt, var, ray, center, mode=None, depth_range=None):
+        """render_local on what this rank renders of the warped rays [B,R,3]: all of them, or -- under ray sharding (..parallel) -- its
+        contiguous share of the flattened view-major ray list as ONE [1, n, 3] batch (`var.ray_share` = (lo, hi) tells the loss which
+        rays those are).  The warp ran on the whole batch on every rank; autograd routes the share's gradient back into it."""
+        shard = getattr(opt, "ray_shard", None)
+        if shard is None:
+            var.ray_share = None
+            return self.render_local(opt, ray, center, intr=var.intr, mode=mode, depth_range=depth_range)
+        from .. import parallel
+        if opt.camera.ndc:                       # per-view intrinsics: reparametrise while the rays still have their [B,R] shape
+            center, ray = camera.convert_NDC(opt, center, ray, intr=var.intr)
+        n = ray.shape[0] * ray.shape[1]
+        lo, hi = parallel.flat_share(n, *shard)
+        var.ray_share = (lo, hi)
+        return self._render_rays(opt, center.reshape(1, n, 3)[:, lo:hi], ray.reshape(1, n, 3)[:, lo:hi], mode=mode, depth_range=depth_range)
+
     def draw_ray_idx(self, opt, batch_size, draw=None):
         """The pixel subset of a training step (reference :510): `nerf.rand_rays // batch_size` distinct pixels, the SAME set for
         every view.  Two samplers, equal in distribution (a uniformly random subset in random order):
@@ -71,24 +87,22 @@ class Graph(nerf.Graph):
           * "feistel" (`opt.nerf.ray_sampler`, what the engine selects): niw_draw_ray_idx, one sort-free launch keyed by
             (opt.seed, `draw` = the training iteration -- a resumed run continues the same sequence; a running count of the
             calls when no iteration is given), also replayable from a captured HIP graph (`self.draw_dev`).
-        Under ray sharding (..parallel) every rank must see the same permutation and keep its share idx[rank::world]: "feistel"
-        has that by construction; "randperm" then draws from a generator of its own, seeded alike on all ranks, because the
-        ranks' default generators drift apart as soon as their stratified draws differ in size."""
+        Under ray sharding (..parallel) every rank draws the SAME n pixels (it warps all of them and renders a contiguous share of
+        the B x n rays, render_share): "feistel" has that by construction; "randperm" then draws from a generator of its own, seeded
+        alike on all ranks, because the ranks' default generators drift apart as soon as their stratified draws differ in size."""
         n = opt.nerf.rand_rays // batch_size
-        rank, world = getattr(opt, "ray_shard", None) or (0, 1)
         self._ray_draws = getattr(self, "_ray_draws", 0) + 1
         number = self._ray_draws if draw is None else int(draw) + 1
         self._depth_draw = number                  # the in-kernel stratified draw of this forward uses the same number (nerf.Graph.sample_depth)
         if opt.nerf.get("ray_sampler", "randperm") == "feistel":
-            return ops.draw_ray_idx(opt.H * opt.W, len(range(rank, n, world)), int(getattr(opt, "seed", 0) or 0), number, opt.device,
-                                    first=rank, stride=world, draw_dev=getattr(self, "draw_dev", None))
-        if world == 1:
+            return ops.draw_ray_idx(opt.H * opt.W, n, int(getattr(opt, "seed", 0) or 0), number, opt.device, draw_dev=getattr(self, "draw_dev", None))
+        if getattr(opt, "ray_shard", None) is None:
             return torch.randperm(opt.H * opt.W, device=opt.device)[:n]
         gen = getattr(self, "_ray_idx_gen", None)
         if gen is None:
             gen = self._ray_idx_gen = torch.Generator(device=opt.device)
             gen.manual_seed(1234567 + int(getattr(opt, "seed", 0) or 0))
-        return torch.randperm(opt.H * opt.W, device=opt.device, generator=gen)[:n][rank::world]
+        return torch.randperm(opt.H * opt.W, device=opt.device, generator=gen)[:n]
 
     def get_pose_init(self, opt, var, mode=None, ind=None, iter=None):
         return None
@@ -103,7 +117,6 @@ class Graph(nerf.Graph):
         loss = super().compute_loss(opt, var, mode=mode)
         if opt.loss_weight.global_alignment is None or mode != "train":
             return loss
-        from .. import parallel
         backend = ALIGN_BACKEND or ops
         from .nvp import nvp_ndr
         stack = nvp_ndr.stacked_points(var.grid_3D, var.center)
@@ -112,14 +125,13 @@ class Graph(nerf.Graph):
         else:
             unwarped = torch.cat([var.grid_cam, var.center_cam], dim=1)
             warped = torch.cat([var.grid_3D, var.center], dim=1)
-        sharded = getattr(opt, "ray_shard", None) is not None
-        poses = backend.rigid_registration(warped, unwarped, reduce_moments=parallel.all_reduce_sum_ if sharded else None)
+        poses = backend.rigid_registration(warped, unwarped)                          # the whole point set, on every rank: no collective
         if hasattr(self, "global_rigid"):
             self.global_rigid.weight.data = poses.reshape(-1, 12)                  # what pose evaluation reads (:570); `poses` is a fresh tensor
-        views, local_points = warped.shape[0], warped.shape[1]
-        # mean over the GLOBAL batch: under sharding every rank contributes its share and the gradient all-reduce sums them
-        elements = 3 * views * (2 * (opt.nerf.rand_rays // views) if sharded else local_points)
-        loss.global_alignment = backend.alignment_residual(warped, unwarped, poses, n_norm=elements)
+        # under ray sharding every rank holds the WHOLE alignment term (the warp is replicated, ..parallel): it enters with weight
+        # 1 / world, so that the per-rank losses -- like the per-rank photometric shares -- and their gradients sum to the global ones
+        world = (getattr(opt, "ray_shard", None) or (0, 1))[1]
+        loss.global_alignment = backend.alignment_residual(warped, unwarped, poses, n_norm=warped.numel() * world)
         return loss
 
     def get_pose(self, opt, var, mode=None):

@@ -50,8 +50,8 @@ class INNPoseParams(torch.nn.Module):
 
     def solve_for_global_transformation(self, grid_pred, center_pred):
         """Kabsch registration of the warped onto the initial points, kept detached in pose_global (reference :96-102).  Under ray
-        sharding the registration is that of the GLOBAL point set (moments summed over ranks): identical on every rank."""
+        sharding every rank warps the whole point set (..parallel), so this is the global registration without a collective."""
         stack = nvp_ndr.stacked_points(grid_pred, center_pred)
         warped, initial = stack if stack is not None else (torch.cat([grid_pred, center_pred], dim=1), torch.cat([self.grid_init, self.center_init], dim=1))
-        R, t = rigid_points_registration(warped, initial, sharded=getattr(self.opt, "ray_shard", None) is not None)
+        R, t = rigid_points_registration(warped, initial)
         self.pose_global.weight.data = torch.cat([R, t.unsqueeze(-1)], dim=-1).reshape(self.num_poses, 12).clone()

@@ -611,26 +611,31 @@ def alignment_residual(target, source, poses, n_norm=None):
 
 class _MSE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb, image, ray_idx, n_norm):
+    def forward(ctx, rgb, image, ray_idx, n_norm, share):
         rgb, image = _f32(rgb, "rgb"), _f32(image, "image")
-        B, R = rgb.shape[0], rgb.shape[1]
+        B = image.shape[0]
         hw = image.shape[-1] * image.shape[-2] if image.dim() == 4 else image.shape[-1]
         if ray_idx is not None:
             ray_idx = ray_idx.to(device=rgb.device, dtype=torch.int64).contiguous()
+        R = ray_idx.numel() if ray_idx is not None else hw
+        first, count = (0, 0) if share is None else (int(share[0]), int(share[1]) - int(share[0]))
+        if rgb.numel() != 3 * (count if share is not None else B * R):
+            raise _lib.NiwError(f"mse_gather: rgb {tuple(rgb.shape)} does not hold " + (f"the {count} rays of the share {tuple(share)}" if share is not None else f"{B} x {R} rays"))
         loss = torch.empty(1, device=rgb.device)
         d_rgb = torch.empty_like(rgb)
         n = float(n_norm if n_norm is not None else rgb.numel())
-        _lib.call("niw_mse_fwd_bwd", _p(rgb), _p(image), _p(ray_idx), B, R, hw, n, 1.0, _p(loss), _p(d_rgb), _stream())
+        _lib.call("niw_mse_fwd_bwd", _p(rgb), _p(image), _p(ray_idx), B, R, hw, first, count, n, 1.0, _p(loss), _p(d_rgb), _stream())
         ctx.save_for_backward(d_rgb)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (d_rgb,) = ctx.saved_tensors
-        return d_rgb * g, None, None, None
+        return d_rgb * g, None, None, None, None
 
 
-def mse_gather(rgb, image, ray_idx=None, n_norm=None):
-    """mean((rgb - image[:, :, ray_idx])^2) with image [B,3,H,W]; n_norm overrides the element count
-    of the mean (global batch under ray sharding)."""
-    return _MSE.apply(rgb, image, ray_idx, n_norm)
+def mse_gather(rgb, image, ray_idx=None, n_norm=None, share=None):
+    """mean((rgb - image[:, :, ray_idx])^2) with image [B,3,H,W]; n_norm overrides the element count of the mean (global batch
+    under ray sharding).  share = (lo, hi): rgb holds the rays lo .. hi-1 of the flattened view-major [B][R] ray list (one rank's
+    contiguous share, ..parallel.flat_share), any leading shape; None: the whole batch [B,R,3]."""
+    return _MSE.apply(rgb, image, ray_idx, n_norm, share)

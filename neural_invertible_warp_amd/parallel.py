@@ -3,13 +3,21 @@
 The reference is single-GPU (options.py:103 asserts it); this is new work.  Rays are
 independent units, so the only exchange is the gradient all-reduce:
   * every rank holds all B views and the full parameter set;
-  * one global pixel permutation is drawn with a shared seed, rank r keeps idx[r::world]
-    ("same pixels for every view", reference nerf_inn_llff.py:510, stays true per rank);
+  * one global pixel set is drawn per iteration, identical on every rank ("same pixels for every view",
+    reference nerf_inn_llff.py:510, holds for the global batch exactly as in the reference);
+  * REPLICATED: ray generation, the NVP warp of all B x 2R points and the alignment term -- 0.4 % of the step's FLOPs.  Every rank
+    computes them on the whole batch, so the warp sees the points at the indices the reference gives them (its embedder window acts on
+    point INDICES, SURVEY W2: a sharded run is the same function as the unsharded one), the Kabsch registration needs no collective,
+    and the alignment gradient enters with weight 1 / world (the all-reduce sums it back to 1);
+  * SHARDED: everything per (ray, sample) -- depth sampling, the field MLPs, compositing, the photometric loss -- on the rank's
+    CONTIGUOUS share of the flattened view-major [B][R] ray list (flat_share: equal shares to within one ray).  Round 2 gave rank r
+    the pixels idx[r::world] of every view; at 113 rays per view and 8 ranks that is 15 rays on rank 0 = 34,560 samples, 1,792 more
+    than one 32,768-sample round of the register-chained MLP kernels, i.e. two rounds where 255 rays (32,640 samples) take one;
   * every rank normalises its photometric loss by the GLOBAL element count, so that the SUM of
     the per-rank gradients is the gradient of the global-batch mean (reference base.py:209-211);
   * ONE flat fp32 bucket (NeRF + fine NeRF + warp + latents, ~4.9 MB) is all-reduced per step:
     at this size a ring over xGMI is latency-bound, so a single in-place call beats buckets.
-No collective sits on the per-sample data path.
+No collective sits on the per-sample data path, and none inside the forward.
 """
 import os
 
@@ -45,8 +53,13 @@ def init_from_env(backend=None, force=False):
 
 
 def shard_ray_idx(ray_idx, rank, world):
-    """Disjoint, exhaustive split of a shared pixel permutation."""
+    """Disjoint, exhaustive strided split of a shared pixel permutation (round 1-2 partition; kept as a helper)."""
     return ray_idx[rank::world]
+
+
+def flat_share(n_rays, rank, world):
+    """-> (lo, hi): rank's contiguous share of a list of n_rays rays; shares are disjoint, exhaustive and equal to within one ray."""
+    return (n_rays * rank) // world, (n_rays * (rank + 1)) // world
 
 
 def all_reduce_sum_(t):

@@ -89,7 +89,7 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
         "niw_warp_fwd": (None,) * 4 + (2, 4, None, None, None, 0, None, None, 0, None, None, None),
         "niw_warp_prep_fwd": (None, None, 2, None, None, None, None, None),
         "niw_warp_prep_bwd": (None, None, 2) + (None,) * 7,
-        "niw_mse_fwd_bwd": (None, None, None, 2, 4, 64, 1.0, 1.0, None, None, None),
+        "niw_mse_fwd_bwd": (None, None, None, 2, 4, 64, 0, 0, 1.0, 1.0, None, None, None),
         "niw_adam_step": (None,) * 4 + (8, 1e-3, 0.9, 0.999, 1e-8, 1, None, None),
         "niw_align_moments": (None, None, 2, 8, None, None),
         "niw_align_solve": (None, 2, None, None),
@@ -109,6 +109,7 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
     # of the transposed (dX) fragments, i.e. about as many bytes
     assert lib.niw_mlp_packed_bytes(0) == 4 * lib.niw_mlp_packed_floats()
     assert lib.niw_mlp_packed_bytes(1) == lib.niw_mlp_packed_bytes(2) > 4 * 527872
+    assert lib.niw_mse_fwd_bwd(p, p, None, 2, 4, 64, 6, 4, 1.0, 1.0, p, p, None) == -1 and "leave" in err()      # rays [6, 10) of a 2 x 4 batch
     assert lib.niw_warp_prep_fwd(p, p, 65, p, p, p, p, None) == -1 and "views" in err()
     assert lib.niw_warp_prep_fwd(p, p, 0, p, p, p, p, None) == -1
     # the one-call render: null descriptor, incomplete descriptor, pixel range outside the image, fine pass without its tables

@@ -1,0 +1,69 @@
+"""Ray sharding on the HIP path (parallel.py: replicated warp + alignment term, contiguous shares of the B x R rays for everything per
+sample): the ranks' losses and gradients must SUM to those of the unsharded step.  The ranks are run one after the other in this
+process (no process group: the all-reduce is the sum formed here), each as the engine builds it for (rank, world).  Needs a GPU."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _step(cfg, rank, world, B, rays, S):
+    from neural_invertible_warp_amd import configs, engine
+    if cfg == "dtu":
+        opt = configs.cfg5_barf_inn_dtu(device=DEV)
+        var0, init = engine.synthetic_dtu_scene(opt, B)
+    else:
+        opt = getattr(configs, cfg)(device=DEV)
+        var0, init = engine.synthetic_scene(opt, B), None
+    opt.nerf.sample_stratified = False                  # mid-point samples: the shares of a sharded run see the unsharded run's depths
+    opt.nerf.rand_rays, opt.nerf.sample_intvs = rays, S
+    if opt.nerf.fine_sampling:
+        opt.nerf.sample_intvs_fine = S
+    tr = engine.INNTrainer(opt, B, rank=rank, world=world, warp_perturb=0.02, seed=4, initial_poses_w2c=init)
+    tr.it = 30000                                        # inside the embedder's annealing window: the reference's index quirk is live
+    for n in tr.nets:
+        n.set_progress(0.3)
+    loss = tr._forward_backward(type(var0)(var0), tr.it)
+    return {k: float(v.detach()) for k, v in loss.items()}, tr.bucket.flat.clone(), tr
+
+
+@pytest.mark.parametrize("cfg,B,rays,S,world", [("cfg3_barf_inn_llff", 18, 2048, 16, 8), ("cfg2_nerf_inn_llff_hier", 5, 5 * 37, 16, 3), ("dtu", 3, 3 * 41, 16, 4)])
+def test_sharded_ranks_sum_to_the_unsharded_step(cfg, B, rays, S, world):
+    ref_loss, ref_grad, ref = _step(cfg, 0, 1, B, rays, S)
+    total_loss, total_grad, sizes = None, None, []
+    for r in range(world):
+        loss, grad, tr = _step(cfg, r, world, B, rays, S)
+        total_loss = loss if total_loss is None else {k: total_loss[k] + v for k, v in loss.items()}
+        total_grad = grad if total_grad is None else total_grad + grad
+        lo, hi = tr.opt.ray_shard and __import__("neural_invertible_warp_amd.parallel", fromlist=["x"]).flat_share(B * (rays // B), r, world)
+        sizes.append(hi - lo)
+    assert sum(sizes) == B * (rays // B) and max(sizes) - min(sizes) <= 1
+    for k in ref_loss:
+        assert abs(total_loss[k] - ref_loss[k]) <= 1e-5 * max(abs(ref_loss[k]), 1e-6), (k, total_loss[k], ref_loss[k])
+    # every optimizer group: NeRF(s), warp network, latent table.  The embedder's index window is live (alpha = 0.3) and the sums still
+    # agree: the warp runs on the whole batch on every rank, so its points keep the indices the reference gives them.
+    for i in range(len(ref.bucket.groups)):
+        a, b = total_grad[ref.bucket.offsets[i]:ref.bucket.offsets[i + 1]], ref.bucket.segment(i)
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), (cfg, i, float((a - b).abs().max() / b.abs().max()))
+
+
+def test_photometric_share_kernel_equals_the_slice_of_the_whole_batch():
+    """niw_mse_fwd_bwd on the rays [lo, hi) of the flattened view-major list == the corresponding slice of the whole-batch call"""
+    from neural_invertible_warp_amd import ops
+    B, R, H, W = 5, 37, 12, 16
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    image = torch.rand(B, 3, H, W, device=DEV, generator=gen)
+    rgb = torch.rand(B, R, 3, device=DEV, generator=gen).requires_grad_(True)
+    idx = torch.randperm(H * W, device=DEV, generator=gen)[:R]
+    n = 3 * B * R
+    whole = ops.mse_gather(rgb, image, idx, n)
+    whole.backward()
+    parts, lo = 0.0, 0
+    for hi in (61, 62, 150, B * R):
+        piece = rgb.detach().reshape(1, B * R, 3)[:, lo:hi].clone().requires_grad_(True)
+        l = ops.mse_gather(piece, image, idx, n, share=(lo, hi))
+        l.backward()
+        assert torch.allclose(piece.grad[0], rgb.grad.reshape(B * R, 3)[lo:hi], rtol=0, atol=1e-9)
+        parts, lo = parts + float(l.detach()), hi
+    assert abs(parts - float(whole.detach())) < 1e-6

@@ -1,5 +1,5 @@
-"""world_size-2 gloo test (CPU) of the ray-shard data-parallel path: shard_ray_idx, the global
-loss normalisation and the flat GradBucket all-reduce.  The per-rank compute is the CPU oracle
+"""world_size-2 gloo tests (CPU) of the ray-shard data-parallel path: the partition of the rays, the global
+loss normalisation, the replicated alignment term and the flat GradBucket all-reduce.  The per-rank compute is the CPU oracle
 (the HIP path needs a GPU); what is under test is the host logic of
 neural_invertible_warp_amd.parallel, which is device agnostic: the summed bucket of two ranks,
 each rendering its slice of the pixel permutation with the GLOBAL mean normaliser, must equal
@@ -122,18 +122,16 @@ def _ga_worker(rank, world, port, q):
     torch.set_num_threads(2)
     parallel.init_from_env(backend="gloo")
     src, tgt = _ga_points()
-    sel = torch.arange(2 * R)[rank::world]
     g = nerf_inn_llff.Graph.__new__(nerf_inn_llff.Graph)
     torch.nn.Module.__init__(g)
     opt = edict(loss_weight=edict(render=None, render_fine=None, global_alignment=2), nerf=edict(rand_rays=R * B, fine_sampling=False),
                 ray_shard=(rank, world))
-    n = len(sel) // 2
-    var = edict(grid_cam=src[:, sel[:n]], center_cam=src[:, sel[n:]], grid_3D=tgt[:, sel[:n]], center=tgt[:, sel[n:]], idx=torch.arange(B),
-                ray_idx=torch.arange(n))
+    # round 3: the warp and the alignment term are REPLICATED -- every rank holds all points and the whole term, weighted 1 / world
+    var = edict(grid_cam=src[:, :R], center_cam=src[:, R:], grid_3D=tgt[:, :R], center=tgt[:, R:], idx=torch.arange(B), ray_idx=torch.arange(R))
     loss = g.compute_loss(opt, var, mode="train").global_alignment
     loss.backward()
     grad = tgt.grad.clone()
-    dist.all_reduce(grad)
+    dist.all_reduce(grad)                              # what the gradient all-reduce of the engine does
     lsum = loss.detach().clone()
     dist.all_reduce(lsum)
     if rank == 0:
@@ -141,7 +139,9 @@ def _ga_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_kabsch_alignment_loss_matches_single_process():
+def test_replicated_kabsch_alignment_loss_sums_to_the_single_process_one():
+    """per-rank alignment losses and gradients (each the whole term / world, no collective inside) SUM to the reference's
+    formulation, autograd THROUGH the SVD of the registration"""
     from oracle import niw_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -154,7 +154,6 @@ def test_sharded_kabsch_alignment_loss_matches_single_process():
         p.join(timeout=300)
         assert p.exitcode == 0
     src, tgt = _ga_points()
-    # single process, the reference's formulation: autograd THROUGH the SVD of the registration (oracle)
     Rg, tg = O.rigid_registration(tgt, src)
     loss = ((tgt - O.cam2world(src, torch.cat([Rg, tg[..., None]], -1))) ** 2).mean()
     loss.backward()
@@ -171,23 +170,24 @@ def _idx_worker(rank, world, port, q):
     torch.manual_seed(0)
     g = nerf_inn_llff.Graph.__new__(nerf_inn_llff.Graph)
     torch.nn.Module.__init__(g)
-    opt = edict(H=12, W=16, device="cpu", seed=0, nerf=edict(rand_rays=3 * 37), ray_shard=(rank, world))     # 37 rays per view: 19 + 18
+    opt = edict(H=12, W=16, device="cpu", seed=0, nerf=edict(rand_rays=3 * 37), ray_shard=(rank, world))     # 3 views x 37 rays
     out = []
     for _ in range(4):
         idx = g.draw_ray_idx(opt, 3)
         torch.rand(len(idx), 5 + rank)                 # rank-dependent consumption of the default generator (stratified draws)
-        pad = torch.full((19,), -1, dtype=torch.int64)
-        pad[:len(idx)] = idx
-        both = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(both, pad)
+        both = [torch.empty_like(idx) for _ in range(world)]
+        dist.all_gather(both, idx)
         out.append(torch.stack(both).numpy())
     if rank == 0:
         q.put(out)
     dist.destroy_process_group()
 
 
-def test_sharded_ray_indices_stay_a_partition_when_ranks_hold_different_ray_counts():
+def test_every_rank_draws_the_same_pixels_and_the_shares_partition_the_rays():
+    """Round 3 partition: all ranks draw the SAME pixel set each step (although their default generators drift apart) and render
+    contiguous shares of the flattened B x R ray list; the shares are disjoint, exhaustive and equal to within one ray."""
     import numpy as np
+    from neural_invertible_warp_amd import parallel
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -200,9 +200,13 @@ def test_sharded_ray_indices_stay_a_partition_when_ranks_hold_different_ray_coun
         assert p.exitcode == 0
     seen = []
     for both in steps:
-        a, b = both[0][both[0] >= 0], both[1][both[1] >= 0]
-        assert len(a) == 19 and len(b) == 18
-        merged = np.concatenate([a, b])
-        assert len(set(merged.tolist())) == 37                      # disjoint, together the 37 pixels of ONE permutation prefix
-        seen.append(tuple(sorted(merged.tolist())))
-    assert len(set(seen)) == len(seen)                              # and a fresh draw every step
+        assert np.array_equal(both[0], both[1]) and len(both[0]) == 37 and len(set(both[0].tolist())) == 37
+        seen.append(tuple(both[0].tolist()))
+    assert len(set(seen)) == len(seen)                              # a fresh draw every step
+    for n, w in ((3 * 37, 2), (18 * 113, 8), (18 * 227, 8), (3 * 682, 8), (5, 8), (56 * 36, 8)):
+        shares = [parallel.flat_share(n, r, w) for r in range(w)]
+        assert shares[0][0] == 0 and shares[-1][1] == n and all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
+        sizes = [hi - lo for lo, hi in shares]
+        assert max(sizes) - min(sizes) <= 1
+    # the case that motivated it: 18 views x 113 rays x 128 samples over 8 ranks fits ONE 32,768-sample round of the MLP kernels
+    assert max(hi - lo for lo, hi in (parallel.flat_share(18 * 113, r, 8) for r in range(8))) * 128 <= 32768

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Refresh the rocprofv3 evidence under profiles/ in one go (run on the GPU box from the repo root):
-#   bash tools/collect_profiles.sh r2        -> gpurun_out/profiles_r2/*  (copy what should be judged into profiles/)
+#   bash tools/collect_profiles.sh r3        -> gpurun_out/profiles_r3/*  (copy what should be judged into profiles/)
 # Kernel-trace statistics per config, the three PMC passes over the MLP kernels (separate runs, --kernel-trace only beside --pmc),
 # the two composite traffic passes, and the un-profiled microbenchmarks.  The profiled program itself follows `--`.
 set -u
-tag=${1:-r2}
+tag=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$tag
 mkdir -p $OUT
@@ -12,7 +12,9 @@ cd /tmp && export TMPDIR=/tmp
 W=/tmp/niw_prof_$$; rm -rf $W; mkdir -p $W
 stats() {   # name, bench flags...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $W/$name -- python3 $ROOT/bench.py --steps 5 --warmup 3 --lean --kernel-steps 0 "$@" > $W/$name.log 2>&1
+  # the driver's flags (--gpus 1 --steps 20 --warmup 5) with --lean --kernel-steps 0: the side measurements of the full line (eval render,
+  # PSNR-parity run at toy sizes, torch baseline) launch the same kernels at other sizes and would pollute the per-kernel averages
+  rocprofv3 --kernel-trace --stats --output-format csv -d $W/$name -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --lean --kernel-steps 0 "$@" > $W/$name.log 2>&1
   local f=$(find $W/$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" > $OUT/${tag}_kernel_stats_$name.csv <<'PY'
 import csv, sys
@@ -28,7 +30,9 @@ PY
 stats cfg2 --config cfg2
 stats cfg3 --config cfg3
 stats cfg5 --config cfg5
-stats cfg3_shard8 --config cfg3 --shard-of 8 --steps 10
+stats cfg3_shard8 --config cfg3 --shard-of 8
+stats cfg2_bf16x3 --config cfg2 --precision bf16x3
+stats cfg2_bf16 --config cfg2 --precision bf16
 for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=${c%%:*}; ctr=${c#*:}
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $W/pmc/$d -o pm -- python3 $ROOT/tools/mlp_bench.py --iters 2 --sizes 4086x192 > $W/pmc_$d.log 2>&1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 PMC passes of tools/mlp_bench.py (csv output) into profiles/r2_traffic.json and profiles/r2_mfma_util.json.
+"""Summarise the rocprofv3 PMC passes of tools/mlp_bench.py (csv output) into profiles/<tag>_traffic.json and profiles/<tag>_mfma_util.json.
 
     cd /tmp && export TMPDIR=/tmp
     for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -23,8 +23,11 @@ NAMES = {"mlp_fwd_kernel<true>": "mlp_fwd_train", "mlp_fwd_kernel<false>": "mlp_
 ALGO = {  # algorithmic bytes per sample: reads / writes of the workspaces, fp32
     "mlp_fwd_train": dict(read=16.0, write=9384.0), "mlp_fwd": dict(read=16.0, write=16.0),
     # dX reads: 288 B sign masks + 384 B parked skip / view gradients (written and read back) + 384 B saved encodings (for d point,
-    # d direction) + d_rgb 12 + d_sigma 4 + rgb 12 + raw density 4 + depth 4
-    "mlp_bwd_dx": dict(read=1092.0, write=9344.0 + 384.0), "mlp_bwd_dw_wide_batch": dict(read=7 * 2 * 256 * 4.0, write=0.0),
+    # d direction) + d_rgb 12 + d_sigma 4 + rgb 12 + raw density 4 + depth 4.
+    # dX writes (round 3: counted by rows actually written, not by the padded row count of the workspace, which over-stated them by
+    # 592 B and hid a read excess behind a "combined ratio 1.0"): dY0..dY6 7*256 rows + dY7 256 rows + 1 quad (d sigma_raw) + dYrgb0 128
+    # rows + dYrgb1 2 quads + stash 96 rows = 2284 rows * 4 B = 9136 B, + 32 B of parked per-sample ray gradients.
+    "mlp_bwd_dx": dict(read=1092.0, write=9136.0 + 32.0), "mlp_bwd_dw_wide_batch": dict(read=7 * 2 * 256 * 4.0, write=0.0),
     "mlp_bwd_dw_skinny_batch": dict(read=(320 + 320 + 257 + 131) * 4.0, write=0.0), "mlp_bwd_dw_colour": dict(read=(128 + 288) * 4.0, write=0.0)}
 
 
@@ -46,10 +49,18 @@ def main(out, prefix):
             continue
         fr, wr = f[k]["FETCH_SIZE"] * 1024 / SAMPLES, w[k]["WRITE_SIZE"] * 1024 / SAMPLES
         traffic[k] = dict(fetch_raw=round(fr, 1), fetch_corrected=round(2 * fr, 1), write=round(wr, 1), algorithmic_read=ALGO[k]["read"],
-                          algorithmic_write=ALGO[k]["write"], traffic_over_algorithmic=round((2 * fr + wr) / (ALGO[k]["read"] + ALGO[k]["write"]), 3))
+                          algorithmic_write=ALGO[k]["write"], traffic_over_algorithmic=round((2 * fr + wr) / (ALGO[k]["read"] + ALGO[k]["write"]), 3),
+                          # the two directions separately: a combined ratio can hide a read excess behind an over-stated write figure
+                          read_over_algorithmic=round(2 * fr / ALGO[k]["read"], 3),
+                          write_over_algorithmic=round(wr / ALGO[k]["write"], 3) if ALGO[k]["write"] else None,
+                          read_excess_bytes_per_sample=round(2 * fr - ALGO[k]["read"], 1))
     doc = dict(source="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192; "
                       "MI355X; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream), WRITE_SIZE as reported; KiB = 1024 B",
-               samples_per_launch=SAMPLES, bytes_per_sample=traffic)
+               samples_per_launch=SAMPLES, bytes_per_sample=traffic,
+               note="read excess of the register-chained kernels = weight fragments re-fetched through the fabric: the 2.1 MB transposed / forward "
+                    "image competes for the XCD's 4 MiB L2 with the kernel's own streaming stores (9.4 KB per sample; nt) -- ~13 B/sample without "
+                    "stores (eval forward), a few hundred with them; served by the Infinity Cache (FETCH_SIZE counts fabric requests, cache hits "
+                    "included), 3-6 % of the kernel's traffic and far from any bandwidth limit")
     json.dump(doc, open(prefix + "_traffic.json", "w"), indent=1)
     rows = []
     for k, d in m.items():
