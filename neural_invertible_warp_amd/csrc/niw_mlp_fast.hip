@@ -24,16 +24,26 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const unsigned (&b
 // image builder (once per optimizer step): one thread per dword of the fragment sections / per float of the bias section
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int frag_source(int byte, int j) {
-    // -> index into the flat parameter vector of element j (0..7) of the fragment lane that owns `byte`, or -1 (zero padding)
-    const bool bwd = byte >= fast_bwd_off(0);
-    int l = 0;
-    if (!bwd) { while (l + 1 < kLayers && byte >= fast_fwd_off(l + 1)) ++l; }
-    else      { while (l + 1 < kLayers && byte >= fast_bwd_off(l + 1)) ++l; }
-    const int local = byte - (bwd ? fast_bwd_off(l) : fast_fwd_off(l));
-    const int frag = local / kFragBytes, lane = (local % 1024) / 16;
+    // -> index into the flat parameter vector of element j (0..7) of the chunk lane that owns `byte`, or -1 (zero padding)
+    const int chunk = byte / kChunkBytes, lane = (byte % 1024) / 16;
     const int i = lane & 31, h = lane >> 5;
-    const int steps = bwd ? fast_rs(l) : fast_ks(l);
-    const int blk = frag / steps, q = frag % steps;
+    int l, blk, q;
+    bool bwd = chunk >= kFastFwdChunks;
+    if (!bwd) {
+        l = 0;
+        while (l + 1 < kLayers && chunk >= fast_fwd_chunk(l + 1)) ++l;
+        const int local = chunk - fast_fwd_chunk(l);
+        blk = local / fast_ks(l); q = local % fast_ks(l);
+    } else {
+        const int c = chunk - kFastFwdChunks;
+        int sgm = 0;
+        while (sgm + 1 < kFastBwdSegs && c >= fast_bwd_chunk(sgm + 1)) ++sgm;
+        const FastBwdSeg sg = fast_bwd_seg(sgm);
+        const int local = c - fast_bwd_chunk(sgm);
+        l = sg.layer;
+        if (local >= sg.nob * fast_rs(l)) return -1;               // padding chunks of the segment
+        blk = sg.ob0 + local / fast_rs(l); q = local % fast_rs(l);
+    }
     const int red = 16 * q + fast_perm(h, j);                     // reduction index of this element
     const int row = out_row(l, bwd ? red : blk * 32 + i), col = fwd_slot_col(l, bwd ? blk * 32 + i : red);
     return (row >= 0 && col >= 0) ? weight_off(l) + row * layer_k(l) + col : -1;
@@ -52,7 +62,7 @@ __global__ void pack_fast_kernel(const float* __restrict__ params, unsigned* __r
         image[d] = __builtin_bit_cast(unsigned, row >= 0 ? params[bias_off(l) + row] : 0.f);
         return;
     }
-    const int plane = (byte % kFragBytes) / 1024, jp = (byte % 16) / 4;
+    const int plane = (byte % kChunkBytes) / 1024, jp = (byte % 16) / 4;
     const int s0 = frag_source(byte, 2 * jp), s1 = frag_source(byte, 2 * jp + 1);
     const float w0 = s0 >= 0 ? params[s0] : 0.f, w1 = s1 >= 0 ? params[s1] : 0.f;
     unsigned hi, mid;
@@ -61,25 +71,152 @@ __global__ void pack_fast_kernel(const float* __restrict__ params, unsigned* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Weight stream shared by the four waves of a workgroup.
+// In the exact-fp32 kernel every wave fetches its own copy of every weight fragment (16 B / clk / CU from L1 / L2: far from a limit).
+// At a sixteenth / three sixteenths of the matrix time the same habit asks 85 - 128 B / clk / CU of a path that delivers ~40
+// (measured: the per-wave version of this kernel ran at 46 % / 33 % of its matrix-pipe time).  All four waves walk the SAME chunk
+// stream (niw_mlp_fast.h), so a chunk is brought in ONCE per workgroup: stages of kStageChunks chunks, a ring of kRingStages stages
+// in LDS, filled by LDS-DMA (buffer_load ... lds: no registers, 1 KiB per wave-instruction), wave w fetching chunks 2w, 2w + 1 of a
+// stage kRingStages - 1 stages ahead of its use.  One s_barrier per stage: before the first read of stage t every wave waits for its
+// own part of it (s_waitcnt vmcnt: the DMA of the later stages may still be in flight), the barrier makes the other waves' parts
+// visible and -- because every wave has by then taken its last fragments of stage t - 1 into registers -- frees that stage's slot for
+// the DMA of stage t + kRingStages - 1, issued right behind the barrier.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kRingStages = 4;
+constexpr int kStageBytes = kStageChunks * kChunkBytes;
+constexpr int kFastLdsBytes = kRingStages * kStageBytes;              // 64 KiB
+
+template <int TERMS>
+struct WeightStream {
+    static constexpr int PL = TERMS >= 3 ? 2 : 1;                     // planes this mode multiplies with
+    rsrc_t rsrc;
+    char* lds;
+    int wave, lane16;
+    int base_bytes;                                                    // image offset of the stream's chunk 0
+    int n_stages;                                                      // stages of the stream
+
+    // DMA of this wave's part of global stage t into ring slot `slot`
+    __device__ __forceinline__ void issue(int t, int slot) const {
+        // stage index and wave number are wave-uniform by construction; readfirstlane says so to the compiler (an LDS-DMA's M0 and scalar
+        // offset built from values it holds in VGPRs become readfirstlane / compare / exec-mask "waterfall" loops, one per instruction)
+        const int tu = __builtin_amdgcn_readfirstlane(t), wv = __builtin_amdgcn_readfirstlane(wave);
+        if (tu >= n_stages) return;
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds) + slot * kStageBytes;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+                const int off = (2 * wv + k) * kChunkBytes + p * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(size_t)(dst0 + off), 16, lane16,
+                                                         base_bytes + tu * kStageBytes + off, 0, 0);
+            }
+    }
+    __device__ __forceinline__ void start() const {
+#pragma unroll
+        for (int t = 0; t < kRingStages - 1; ++t) issue(t, t);
+    }
+    // before the first read of global stage t (ring slot `slot`, compile-time)
+    template <int SLOT>
+    __device__ __forceinline__ void boundary(int t) const {
+        // own fragment reads of the previous stage have returned; own DMA of stage t has landed (younger: the 2 * PL * (kRingStages - 2)
+        // DMA instructions of the stages behind it -- and whatever else this wave has issued since, which only makes the wait safer)
+        if (PL == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(t + kRingStages - 1, (SLOT + kRingStages - 1) % kRingStages);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ u32x4_t frag(int plane, int chunk_in_stage) const {
+        return *reinterpret_cast<const u32x4_t*>(lds + SLOT * kStageBytes + chunk_in_stage * kChunkBytes + plane * 1024 + lane16);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // streaming register-chained layer on bf16 planes
-//   out[n][m] = sum_k A[n][k] B[k][m],  A = image fragments (L2 / L1), B = this lane's operand planes b1 then b2
+//   out[n][m] = sum_k A[n][k] B[k][m],  A = the layer's chunks of the weight stream, B = this lane's operand planes b1 then b2
 // Row blocks outer, k-steps inner, one dependent MFMA chain per block (a single chain of v_mfma_f32_32x32x16_bf16 issues back to back);
-// TERMS = 3: hi*hi + hi*mid + mid*hi per k-step, TERMS = 1: hi*hi.  A ring keeps D fragments (TERMS = 3: both planes) in flight; the
-// epilogue of block nb-1 -- ReLU, split into planes, stores -- is spread in PAIRS of accumulator registers over the k-steps of block nb.
+// TERMS = 3: hi*mid + mid*hi + hi*hi per k-step, TERMS = 1: hi*hi.  The fragments of chunk c + 1 are read from LDS before the MFMAs of
+// chunk c; the epilogue of block nb-1 -- ReLU, split into planes, stores -- is spread in PAIRS of accumulator registers over the k-steps
+// of block nb.  `stage0` = global stage of the layer's first chunk (run time: layers of a kind share one body), PHASE = stage0 modulo
+// the ring (compile time: it is the same for every layer that runs a given call site).
 //   pol.acc_init(nb, c)            the 16-register value block nb accumulates from (its bias fragment), fetched one block ahead
 //   pol.epi2(nb, rp, a0, a1)       accumulator registers 2 rp, 2 rp + 1 of block nb
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kFastRing = 8;
+template <int KS1, int KS2, int NB, int TERMS, int PHASE, typename Policy>
+__device__ __forceinline__ void stream_layer_shared(const WeightStream<TERMS>& ws, int stage0, const unsigned (&b1)[2][4 * KS1],
+                                                    const unsigned (&b2)[2][4 * (KS2 > 0 ? KS2 : 1)], Policy& pol) {
+    constexpr int KS = KS1 + KS2, N = NB * KS, PL = TERMS >= 3 ? 2 : 1, G = kStageChunks, R = kRingStages;
+    static_assert(N % G == 0 || true, "");
+    f32x16 cin[2], acc[2];
+    u32x4_t fr[2][PL];                                      // fragments of the current / next chunk
+    pol.acc_init(0, cin[0]);
+    ws.template boundary<PHASE % R>(stage0);
+#pragma unroll
+    for (int p = 0; p < PL; ++p) fr[0][p] = ws.template frag<PHASE % R>(p, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        f32x16& cur = acc[nb & 1];
+        if (nb + 1 < NB) pol.acc_init(nb + 1, cin[(nb + 1) & 1]);
+        cur = cin[nb & 1];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            constexpr int dummy = 0; (void)dummy;
+            const int c = nb * KS + q;                      // compile-time after unrolling
+            // next chunk's fragments (crossing into the next stage: synchronise first)
+            if (c + 1 < N) {
+                if ((c + 1) % G == 0) {
+                    switch (((c + 1) / G + PHASE) % R) {     // compile-time slot of the stage being entered
+                        case 0: ws.template boundary<0>(stage0 + (c + 1) / G); break;
+                        case 1: ws.template boundary<1>(stage0 + (c + 1) / G); break;
+                        case 2: ws.template boundary<2>(stage0 + (c + 1) / G); break;
+                        default: ws.template boundary<3>(stage0 + (c + 1) / G); break;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < PL; ++p) {
+                    switch (((c + 1) / G + PHASE) % R) {
+                        case 0: fr[(c + 1) & 1][p] = ws.template frag<0>(p, (c + 1) % G); break;
+                        case 1: fr[(c + 1) & 1][p] = ws.template frag<1>(p, (c + 1) % G); break;
+                        case 2: fr[(c + 1) & 1][p] = ws.template frag<2>(p, (c + 1) % G); break;
+                        default: fr[(c + 1) & 1][p] = ws.template frag<3>(p, (c + 1) % G); break;
+                    }
+                }
+            }
+            unsigned bh[4], bm[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bh[t] = q < KS1 ? b1[0][4 * (q < KS1 ? q : 0) + t] : b2[0][4 * (q >= KS1 ? q - KS1 : 0) + t];
+                bm[t] = q < KS1 ? b1[1][4 * (q < KS1 ? q : 0) + t] : b2[1][4 * (q >= KS1 ? q - KS1 : 0) + t];
+            }
+            if (TERMS >= 3) {
+                cur = mfma_bf16(fr[c & 1][0], bm, cur);          // the two small terms first, the leading term last
+                cur = mfma_bf16(fr[c & 1][PL - 1], bh, cur);
+            }
+            cur = mfma_bf16(fr[c & 1][0], bh, cur);
+            if (nb > 0) {
+#pragma unroll
+                for (int rp = q * 8 / KS; rp < (q + 1) * 8 / KS; ++rp) pol.epi2(nb - 1, rp, acc[(nb - 1) & 1][2 * rp], acc[(nb - 1) & 1][2 * rp + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) pol.epi2(NB - 1, rp, acc[(NB - 1) & 1][2 * rp], acc[(NB - 1) & 1][2 * rp + 1]);
+}
 
+// The same layer with every wave fetching its own copy of every chunk through a register ring (kFastRing chunks in flight), as the
+// exact-fp32 kernel does.  Which of the two forms a mode uses is decided by measurement (kSharedWeights below).
+constexpr int kFastRing = 8;
 template <int KS1, int KS2, int NB, int TERMS, typename Policy>
-__device__ __forceinline__ void stream_layer_bf(const PackedWeights& pw, int w_base, const unsigned (&b1)[2][4 * KS1],
-                                                const unsigned (&b2)[2][4 * (KS2 > 0 ? KS2 : 1)], Policy& pol) {
+__device__ __forceinline__ void stream_layer_ring(const WeightStream<TERMS>& ws, int stage0, const unsigned (&b1)[2][4 * KS1],
+                                                  const unsigned (&b2)[2][4 * (KS2 > 0 ? KS2 : 1)], Policy& pol) {
     constexpr int KS = KS1 + KS2, N = NB * KS, D = kFastRing, PL = TERMS >= 3 ? 2 : 1;
+    const int w_base = ws.base_bytes + stage0 * kStageBytes;
     u32x4_t ring[D][PL];
     auto fetch = [&](int i, int slot) {
 #pragma unroll
         for (int p = 0; p < PL; ++p)
-            ring[slot][p] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(pw.rsrc, pw.lane16, w_base + i * kFragBytes + p * 1024, 0));
+            ring[slot][p] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.lane16, w_base + i * kChunkBytes + p * 1024, 0));
     };
     f32x16 cin[2], acc[2];
     pol.acc_init(0, cin[0]);
@@ -118,6 +255,22 @@ __device__ __forceinline__ void stream_layer_bf(const PackedWeights& pw, int w_b
     }
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) pol.epi2(NB - 1, rp, acc[(NB - 1) & 1][2 * rp], acc[(NB - 1) & 1][2 * rp + 1]);
+}
+
+// Measured on MI355X, 784,512 samples, us (eval forward / training forward / dX chain):
+//   bf16x3   per-wave ring 2196 / 2634 / 2697     shared through LDS 6875 (spills) / 2889 / 2609
+//   bf16     per-wave ring 1073 / 1617 / 2104     shared through LDS 1198 / 1495 / 1398
+// Sharing removes three quarters of the L2 -> CU weight traffic and pays one barrier per 8 chunks.  With three matrix instructions per
+// chunk the per-wave ring keeps up (and the shared form's barrier, fragment reads and waits cost as much as they save); with one
+// instruction per chunk the ring's 128 B / clk / CU does not, and sharing wins where the kernel also streams stores.
+template <int TERMS>
+constexpr bool kSharedWeights = TERMS == 1;
+
+template <int KS1, int KS2, int NB, int TERMS, int PHASE, typename Policy>
+__device__ __forceinline__ void stream_layer_bf(const WeightStream<TERMS>& ws, int stage0, const unsigned (&b1)[2][4 * KS1],
+                                                const unsigned (&b2)[2][4 * (KS2 > 0 ? KS2 : 1)], Policy& pol) {
+    if constexpr (kSharedWeights<TERMS>) stream_layer_shared<KS1, KS2, NB, TERMS, PHASE>(ws, stage0, b1, b2, pol);
+    else stream_layer_ring<KS1, KS2, NB, TERMS>(ws, stage0, b1, b2, pol);
 }
 
 // planes of an fp32 register array in B-operand order: dword r of a plane = values 2 r, 2 r + 1
@@ -195,6 +348,8 @@ __device__ __forceinline__ float density_act_fast(float x, int kind) {
     return x > 20.f ? x : log1pf(expf(x));      // F.softplus(beta=1, threshold=20)
 }
 
+static_assert((8 * 16 / kStageChunks) % kRingStages == 0, "a 256 -> 256 layer is a whole number of ring turns: the layers of one rolled loop share their ring phase");
+
 template <int TERMS, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -225,6 +380,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
         encode_slots<NIW_LVIEW, 4>(u, wv, h, venc);
     }
     const PackedWeights pw{make_rsrc(a.image), reinterpret_cast<const float*>(a.image), lane * 16};
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const WeightStream<TERMS> ws{pw.rsrc, wlds, __builtin_amdgcn_readfirstlane(wave), lane * 16, 0, kFastFwdChunks / kStageChunks};
+    if (kSharedWeights<TERMS>) ws.start();
+    constexpr int G = kStageChunks;
     const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)(((long long)h * a.Mpad + m) * 16), hoff = h * 64;
     const unsigned mpad32 = (unsigned)a.Mpad;
     auto row_off = [&](int r) { return (long long)((unsigned long long)(unsigned)r * (unsigned long long)mpad32); };
@@ -254,33 +413,33 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     // ---- layer 0: 63 -> 256
     {
         FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(0), hoff, nxt, window(save_h(1)), mask_rec(0), lane};
-        stream_layer_bf<4, 0, 8, TERMS>(pw, fast_fwd_off(0), encp, none, ep);
+        stream_layer_bf<4, 0, 8, TERMS, (fast_fwd_chunk(0) / G) % kRingStages>(ws, fast_fwd_chunk(0) / G, encp, none, ep);
         advance();
     }
     // ---- layers 1..3
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(1) + (l - 1) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
-        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_fwd_off(1) + (l - 1) * (8 * 16 * kFragBytes), act, none, ep);
+        stream_layer_bf<16, 0, 8, TERMS, (fast_fwd_chunk(1) / G) % kRingStages>(ws, fast_fwd_chunk(1) / G + (l - 1) * (8 * 16 / G), act, none, ep);
         advance();
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
         FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(4), hoff, nxt, window(save_h(5)), mask_rec(4), lane};
-        stream_layer_bf<16, 4, 8, TERMS>(pw, fast_fwd_off(4), act, encp, ep);
+        stream_layer_bf<16, 4, 8, TERMS, (fast_fwd_chunk(4) / G) % kRingStages>(ws, fast_fwd_chunk(4) / G, act, encp, ep);
         advance();
     }
     // ---- layers 5, 6
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
         FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(5) + (l - 5) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
-        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_fwd_off(5) + (l - 5) * (8 * 16 * kFragBytes), act, none, ep);
+        stream_layer_bf<16, 0, 8, TERMS, (fast_fwd_chunk(5) / G) % kRingStages>(ws, fast_fwd_chunk(5) / G + (l - 5) * (8 * 16 / G), act, none, ep);
         advance();
     }
     // ---- layer 7: 256 -> 256 features + the density row (row block 8)
     {
         FastFwdEpilogue<8, SAVE, 1> ep{pw, fast_bias_off(7), hoff, nxt, window(kSaveFeat), mask_rec(7), lane};
-        stream_layer_bf<16, 0, 9, TERMS>(pw, fast_fwd_off(7), act, none, ep);
+        stream_layer_bf<16, 0, 9, TERMS, (fast_fwd_chunk(7) / G) % kRingStages>(ws, fast_fwd_chunk(7) / G, act, none, ep);
         advance();
         float sig_raw = ep.head[0];
         if (a.noise != nullptr) sig_raw += a.noise[mc];
@@ -293,13 +452,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     unsigned hr[2][32];
     {
         FastFwdEpilogue<4, SAVE, 0> ep{pw, fast_bias_off(8), hoff, hr, window(kSaveHr), mask_rec(8), lane};
-        stream_layer_bf<16, 2, 4, TERMS>(pw, fast_fwd_off(8), act, vencp, ep);
+        stream_layer_bf<16, 2, 4, TERMS, (fast_fwd_chunk(8) / G) % kRingStages>(ws, fast_fwd_chunk(8) / G, act, vencp, ep);
     }
     // ---- colour layer 1: 128 -> 3, sigmoid
     {
         unsigned unused[2][8];
         FastFwdEpilogue<1, false, 2> ep{pw, fast_bias_off(9), hoff, unused, RowWindow{nullptr, 0, 0}, nullptr, lane};
-        stream_layer_bf<8, 0, 1, TERMS>(pw, fast_fwd_off(9), hr, none, ep);
+        stream_layer_bf<8, 0, 1, TERMS, (fast_fwd_chunk(9) / G) % kRingStages>(ws, fast_fwd_chunk(9) / G, hr, none, ep);
         if (h == 0 && valid) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-ep.head[c]));
@@ -330,13 +489,18 @@ int niw_launch_mlp_fwd_fast(int precision, const void* image, const float* cente
     for (int i = 0; i < NIW_LVIEW; ++i) a.wview[i] = band_wview ? band_wview[i] : 1.f;
     a.band_dev = band_dev;
     const int blocks = (int)(a.Mpad / 128);
+#define NIW_FAST_FWD(T, S)                                                                                                  \
+    do {                                                                                                                    \
+        static std::atomic<unsigned long long> attr{0ull};                                                                  \
+        if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(mlp_fwd_fast_kernel<T, S>), kFastLdsBytes, attr, "niw_mlp_fwd (fast)")) return rc; \
+        mlp_fwd_fast_kernel<T, S><<<blocks, 256, kFastLdsBytes, stream>>>(a);                                               \
+    } while (0)
     if (precision == NIW_PREC_BF16X3) {
-        if (save) mlp_fwd_fast_kernel<3, true><<<blocks, 256, 0, stream>>>(a);
-        else mlp_fwd_fast_kernel<3, false><<<blocks, 256, 0, stream>>>(a);
+        if (save) NIW_FAST_FWD(3, true); else NIW_FAST_FWD(3, false);
     } else {
-        if (save) mlp_fwd_fast_kernel<1, true><<<blocks, 256, 0, stream>>>(a);
-        else mlp_fwd_fast_kernel<1, false><<<blocks, 256, 0, stream>>>(a);
+        if (save) NIW_FAST_FWD(1, true); else NIW_FAST_FWD(1, false);
     }
+#undef NIW_FAST_FWD
     NIW_LAUNCH_CHECK("niw_mlp_fwd (fast precision)");
     return NIW_OK;
 }
@@ -373,13 +537,14 @@ struct FastMaskEpilogue {
 // park a result in the stash rows (d encoding slots of the skip connection, d view-encoding slots)
 struct FastStashEpilogue {
     RowWindow win;
+    bool store;
     float keep[2] = {0.f, 0.f};
     __device__ __forceinline__ void acc_init(int, f32x16& c) const {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
     }
     __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
-        if (rp & 1) buf_store4(keep[0], keep[1], a0, a1, win.rsrc(nb * 32), win.voff4, 8 * (rp >> 1) * win.pitch4);
+        if (rp & 1) { if (store) buf_store4(keep[0], keep[1], a0, a1, win.rsrc(nb * 32), win.voff4, 8 * (rp >> 1) * win.pitch4); }
         else { keep[0] = a0; keep[1] = a1; }
     }
 };
@@ -423,6 +588,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     const unsigned qoff = (unsigned)((long long)h * a.Mpad + m);
     const long long P = a.Mpad;
     const PackedWeights pw{make_rsrc(a.image), reinterpret_cast<const float*>(a.image), lane * 16};
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const WeightStream<TERMS> ws{pw.rsrc, wlds, __builtin_amdgcn_readfirstlane(wave), lane * 16, kFastBwdOffBytes, kFastBwdChunks / kStageChunks};
+    if (kSharedWeights<TERMS>) ws.start();
+    constexpr int G = kStageChunks;
     const int pitch4 = (int)(P * 4), voff4 = (int)(((long long)h * P + m) * 16);
     auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };
     const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
@@ -458,17 +627,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     unsigned dyr[2][32];
     {
         FastMaskEpilogue<4> ep{mk_cur, dyr, gwin(kGradRgb0)};
-        stream_layer_bf<1, 0, 4, TERMS>(pw, fast_bwd_off(9), dy9p, none, ep);
+        stream_layer_bf<1, 0, 4, TERMS, (fast_bwd_chunk(0) / G) % kRingStages>(ws, fast_bwd_chunk(0) / G, dy9p, none, ep);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = slot block 8 of 9)
-    if (a.ray_grad) {
-        FastStashEpilogue ep{gwin(kGradStashVenc)};
-        stream_layer_bf<8, 0, 1, TERMS>(pw, fast_bwd_off(8) + 8 * fast_rs(8) * kFragBytes, dyr, none, ep);
+    {   // (always run: the weight stream is linear; without a ray gradient only its stores are dropped)
+        FastStashEpilogue ep{gwin(kGradStashVenc), a.ray_grad != 0};
+        stream_layer_bf<8, 0, 1, TERMS, (fast_bwd_chunk(1) / G) % kRingStages>(ws, fast_bwd_chunk(1) / G, dyr, none, ep);
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(6);
         FastMaskEpilogue<8> ep{mk_cur, dy, gwin(kGradY7)};
-        stream_layer_bf<8, 0, 8, TERMS>(pw, fast_bwd_off(8), dyr, none, ep);
+        stream_layer_bf<8, 0, 8, TERMS, (fast_bwd_chunk(2) / G) % kRingStages>(ws, fast_bwd_chunk(2) / G, dyr, none, ep);
     }
     // ---- density head: d sigma_raw = reduction row 256 of layer 7 = element 0 of lane half 0 of the 17th step
     unsigned dsigp[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
@@ -486,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(5);
         FastMaskEpilogue<8> ep{mk_cur, nxt, gwin(6 * 256)};
-        stream_layer_bf<16, 1, 8, TERMS>(pw, fast_bwd_off(7), dy, dsigp, ep);
+        stream_layer_bf<16, 1, 8, TERMS, (fast_bwd_chunk(3) / G) % kRingStages>(ws, fast_bwd_chunk(3) / G, dy, dsigp, ep);
         advance();
     }
     // ---- layers 6, 5 transposed
@@ -494,18 +663,18 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     for (int l = 6; l >= 5; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l - 2);
         FastMaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
-        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_bwd_off(5) + (l - 5) * (8 * 16 * kFragBytes), dy, none, ep);
+        stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(4) / G) % kRingStages>(ws, fast_bwd_chunk(4) / G + (6 - l) * (8 * 16 / G), dy, none, ep);
         advance();
     }
     // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots = slot blocks 8, 9 of 10)
-    if (a.ray_grad) {
-        FastStashEpilogue ep{gwin(kGradStashEnc)};
-        stream_layer_bf<16, 0, 2, TERMS>(pw, fast_bwd_off(4) + 8 * fast_rs(4) * kFragBytes, dy, none, ep);
+    {
+        FastStashEpilogue ep{gwin(kGradStashEnc), a.ray_grad != 0};
+        stream_layer_bf<16, 0, 2, TERMS, (fast_bwd_chunk(6) / G) % kRingStages>(ws, fast_bwd_chunk(6) / G, dy, none, ep);
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(2);
         FastMaskEpilogue<8> ep{mk_cur, nxt, gwin(3 * 256)};
-        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_bwd_off(4), dy, none, ep);
+        stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(7) / G) % kRingStages>(ws, fast_bwd_chunk(7) / G, dy, none, ep);
         advance();
     }
     // ---- layers 3, 2, 1 transposed
@@ -513,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     for (int l = 3; l >= 1; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l >= 2 ? l - 2 : 0);
         FastMaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
-        stream_layer_bf<16, 0, 8, TERMS>(pw, fast_bwd_off(1) + (l - 1) * (8 * 16 * kFragBytes), dy, none, ep);
+        stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(8) / G) % kRingStages>(ws, fast_bwd_chunk(8) / G + (3 - l) * (8 * 16 / G), dy, none, ep);
         advance();
     }
     if (!a.ray_grad) return;
@@ -521,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     float denc[32], dvenc[16];
     {
         FastAddStashEpilogue<2> ep{gwin(kGradStashEnc), denc};
-        stream_layer_bf<16, 0, 2, TERMS>(pw, fast_bwd_off(0), dy, none, ep);
+        stream_layer_bf<16, 0, 2, TERMS, (fast_bwd_chunk(11) / G) % kRingStages>(ws, fast_bwd_chunk(11) / G, dy, none, ep);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = reinterpret_cast<const f32x4*>(a.grad + (long long)(kGradStashVenc + 8 * q) * P)[qoff];
@@ -561,8 +730,14 @@ int niw_launch_mlp_bwd_dx_fast(int precision, const void* image, const float* ce
     a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
     a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
     const int blocks = (int)(a.Mpad / 128);
-    if (precision == NIW_PREC_BF16X3) mlp_bwd_dx_fast_kernel<3><<<blocks, 256, 0, stream>>>(a);
-    else mlp_bwd_dx_fast_kernel<1><<<blocks, 256, 0, stream>>>(a);
+#define NIW_FAST_BWD(T)                                                                                                     \
+    do {                                                                                                                    \
+        static std::atomic<unsigned long long> attr{0ull};                                                                  \
+        if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(mlp_bwd_dx_fast_kernel<T>), kFastLdsBytes, attr, "niw_mlp_bwd_dx (fast)")) return rc; \
+        mlp_bwd_dx_fast_kernel<T><<<blocks, 256, kFastLdsBytes, stream>>>(a);                                               \
+    } while (0)
+    if (precision == NIW_PREC_BF16X3) NIW_FAST_BWD(3); else NIW_FAST_BWD(1);
+#undef NIW_FAST_BWD
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dX chain, fast precision)");
     if (a.ray_grad) return niw_launch_ray_grad_reduce(gradws, a.Mpad, n_rays, n_samples, d_center, d_ray, stream);
     return NIW_OK;

@@ -17,6 +17,13 @@ RUNS = {
     "cfg3_shard8": ["--config", "cfg3", "--shard-of", "8", "--lean", "--steps", "100"],
     "cfg3_shard8_eager": ["--config", "cfg3", "--shard-of", "8", "--lean", "--steps", "100", "--hip-graph", "off"],
     "cfg2_shard8": ["--config", "cfg2", "--shard-of", "8", "--lean", "--steps", "50"],
+    # the opt-in fast-precision modes (separate lines, never the headline)
+    "cfg2_bf16x3": ["--config", "cfg2", "--precision", "bf16x3"],
+    "cfg2_bf16": ["--config", "cfg2", "--precision", "bf16"],
+    "cfg3_bf16x3": ["--config", "cfg3", "--lean", "--precision", "bf16x3"],
+    "cfg5_bf16x3": ["--config", "cfg5", "--lean", "--precision", "bf16x3"],
+    # one rank through RCCL (a forced one-rank process group): the collective path on hardware
+    "cfg3_rccl_1rank": ["--config", "cfg3", "--lean", "--force-dist"],
 }
 
 
