@@ -284,8 +284,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--shard-of", type=int, default=0, help="N=1 only: run rank 0's 1/K shard of the global batch (strong-scaling proxy)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak (strong with --shard-of)")
+    ap.add_argument("--shard-of", type=int, default=0, help="N=1 only: run rank 0's 1/K share of the global batch on this GPU: the work of one rank of a "
+                                                            "K-GPU job (strong scaling: the reference's batch split K ways; with --scaling weak: a K times larger batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the full-image eval render (e.g. when profiling the train step)")
     ap.add_argument("--no-composite-scan", action="store_true")
@@ -334,7 +335,7 @@ def main():
             raise SystemExit(f"bench.py: the {dist_backend} all-reduce saw {ranks_seen} ranks, expected {world}")
     assert not (args.shard_of and world > 1), "--shard-of is a single-GPU proxy"
     dev = f"cuda:{local}"
-    scaling = "strong" if args.shard_of else args.scaling
+    scaling = args.scaling or ("strong" if args.shard_of else "weak")
 
     use_graph = False if args.no_hip_graph else ((world == 1 and not args.force_dist) if args.hip_graph == "auto" else args.hip_graph == "on")
     loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph, precision=args.precision)

@@ -348,6 +348,13 @@ class INNTrainer:
         for n in self.nets:
             if hasattr(n, "set_progress"):
                 n.set_progress(self.it / self.opt.max_iter if self.it else float(n.progress_host or 0.0))
+        if self.world > 1:
+            # per-view pose tables: under ray sharding every rank has refreshed the rows of its own views only
+            win = getattr(self.graph, "_last_window", None)
+            if self.family == "dtu":
+                self.pose_net.pose_global.weight.data = parallel.gather_owned_rows(self.pose_net.pose_global.weight.data, win)
+            else:
+                self.graph.gather_global_rigid()
 
 
 def synthetic_scene(opt, n_views, seed=0):

@@ -78,9 +78,12 @@ class Graph(nerf_inn_llff.Graph):
             else:
                 grid_cam = var.grid_cam
             center_cam, grid_cam = center_cam.detach(), grid_cam.detach()
-            # the whole latent table is used, not var.idx rows of it (reference :334)
+            # the whole latent table is used, not var.idx rows of it (reference :334); under ray sharding the rows of this rank's views
+            win = var.get("view_window")
+            latent = self.warp_latent.weight if win is None else self.warp_latent.weight[win.views]
+            self.warp_mlp.code_rows = None if win is None else (win.v0, win.v1)
             alpha_ratio = nvp_ndr.embedding_anneal_ratio(opt, iter)
-            ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.warp_mlp, self.warp_latent.weight, grid_cam, center_cam, alpha_ratio)
+            ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.warp_mlp, latent, grid_cam, center_cam, alpha_ratio)
             return ray, center_3D, grid_3D, alpha_ratio
         if mode in ["val", "eval", "test-optim"]:
             # a held-out view has no learnt pose: its ground-truth pose is brought into the learnt frame with the similarity the
@@ -170,6 +173,7 @@ class Model:
     def validate(self, opt, ep=None):
         """pose errors after the Procrustes pre-alignment + PSNR of the held-out views rendered from their
         aligned ground-truth poses (nerf_inn_llff.py:130-160, barf_inn_llff.py:122-145)"""
+        self.trainer.sync_state()                  # (under ray sharding: collect the per-view poses the ranks hold)
         self.graph.eval()
         ev = self._evaluator(opt)
         pose, pose_GT = ev.get_all_training_poses(opt)

@@ -27,6 +27,7 @@ class Graph(nerf_inn_llff.Graph):
         depth_range = opt.nerf.depth.range if opt.nerf.depth.param == "inverse" else self._host_depth_range(var.depth_range)
         if opt.nerf.rand_rays and mode == "train":
             var.ray_idx = self.draw_ray_idx(opt, batch_size, draw=iter)
+            var.view_window = self._last_window = self.view_window(opt, batch_size, len(var.ray_idx))      # ray sharding (..parallel)
             ray, center, grid_3d = self.get_pose(opt, var, mode=mode, iter=iter)
             ret = self.render_share(opt, var, ray, center, mode=mode, depth_range=depth_range)
             ret.update(grid_local=grid_3d, center_local=center, grid_init=self.pose_net.grid_init, center_init=self.pose_net.center_init)
@@ -66,9 +67,18 @@ class Graph(nerf_inn_llff.Graph):
         else:
             warped = torch.cat([var.grid_local, var.center_local], dim=1)
             initial = torch.cat([var.grid_init, var.center_init], dim=1)
-        world = (getattr(opt, "ray_shard", None) or (0, 1))[1]          # replicated term, weight 1 / world per rank (..parallel)
-        loss.global_alignment = (nerf_inn_llff.ALIGN_BACKEND or ops).alignment_residual(warped, initial, self.pose_net.get_w2c_poses(),
-                                                                                        n_norm=warped.numel() * world)
+        win = var.get("view_window")
+        backend = nerf_inn_llff.ALIGN_BACKEND or ops
+        poses = self.pose_net.get_w2c_poses()
+        if win is None:
+            loss.global_alignment = backend.alignment_residual(warped, initial, poses, n_norm=warped.numel())
+        else:
+            # this rank's window of views: the alignment terms of the views it OWNS, normalised by the global point count (..parallel)
+            own = win.owned_in_window
+            if own.stop > own.start:
+                loss.global_alignment = backend.alignment_residual(warped[own], initial[own], poses[win.own0:win.own1], n_norm=3 * win.B * warped.shape[1])
+            else:
+                loss.global_alignment = warped.sum() * 0.0
         return loss
 
     def render(self, opt, pose, intr=None, ray_idx=None, mode=None, depth_range=None):

@@ -47,9 +47,13 @@ class Graph(nerf.Graph):
             var.ray_idx = self.draw_ray_idx(opt, batch_size, draw=iter)
             if mode == "train":
                 pose_init = self.get_pose_init(opt, var, mode=mode, iter=iter)
+                # under ray sharding (..parallel): this rank's window of whole views; every tensor from here to the renderer is the window's
+                win = self.view_window(opt, batch_size, len(var.ray_idx))
+                var.view_window = self._last_window = win
+                views = slice(None) if win is None else win.views
                 # camera-frame grid / centre kept for the alignment loss (:519); get_pose reuses them
-                center_cam, grid_cam = camera.get_unwarped_center_and_ray(opt, intr=var.intr, ray_idx=var.ray_idx,
-                                                                          pose_init=None if opt.data.dataset != "blender" else pose_init)
+                center_cam, grid_cam = camera.get_unwarped_center_and_ray(opt, intr=var.intr[views], ray_idx=var.ray_idx,
+                                                                          pose_init=None if opt.data.dataset != "blender" else pose_init[views])
                 var.center_cam, var.grid_cam = center_cam, grid_cam
                 ray, center, grid_3D, alpha_ratio = self.get_pose(opt, var, mode=mode, iter=iter)
                 ret = self.render_share(opt, var, ray, center, mode=mode)
@@ -64,21 +68,29 @@ class Graph(nerf.Graph):
         var.update(ret)
         return var
 
-    def render_share(self, opt, var, ray, center, mode=None, depth_range=None):
-        """render_local on what this rank renders of the warped rays [B,R,3]: all of them, or -- under ray sharding (..parallel) -- its
-        contiguous share of the flattened view-major ray list as ONE [1, n, 3] batch (`var.ray_share` = (lo, hi) tells the loss which
-        rays those are).  The warp ran on the whole batch on every rank; autograd routes the share's gradient back into it."""
+    def view_window(self, opt, n_views, n_rays_per_view):
+        """..parallel.ViewWindow of this rank under ray sharding, else None"""
         shard = getattr(opt, "ray_shard", None)
         if shard is None:
+            return None
+        from .. import parallel
+        return parallel.ViewWindow(n_views, n_rays_per_view, *shard)
+
+    def render_share(self, opt, var, ray, center, mode=None, depth_range=None):
+        """render_local on what this rank renders of the warped rays: all of them [B,R,3], or -- under ray sharding (..parallel) -- its
+        contiguous share of the flattened view-major ray list as ONE [1, n, 3] batch, cut out of the window of whole views it has
+        warped (`var.view_window`); `var.ray_share` = (lo, hi) tells the loss which rays of the global batch those are.  Autograd
+        routes the share's gradient back into the window's warp."""
+        win = var.get("view_window")
+        if win is None:
             var.ray_share = None
             return self.render_local(opt, ray, center, intr=var.intr, mode=mode, depth_range=depth_range)
-        from .. import parallel
-        if opt.camera.ndc:                       # per-view intrinsics: reparametrise while the rays still have their [B,R] shape
-            center, ray = camera.convert_NDC(opt, center, ray, intr=var.intr)
+        if opt.camera.ndc:                       # per-view intrinsics: reparametrise while the rays still have their [views, R] shape
+            center, ray = camera.convert_NDC(opt, center, ray, intr=var.intr[win.views])
         n = ray.shape[0] * ray.shape[1]
-        lo, hi = parallel.flat_share(n, *shard)
-        var.ray_share = (lo, hi)
-        return self._render_rays(opt, center.reshape(1, n, 3)[:, lo:hi], ray.reshape(1, n, 3)[:, lo:hi], mode=mode, depth_range=depth_range)
+        a, b = win.local
+        var.ray_share = (win.lo, win.hi)
+        return self._render_rays(opt, center.reshape(1, n, 3)[:, a:b], ray.reshape(1, n, 3)[:, a:b], mode=mode, depth_range=depth_range)
 
     def draw_ray_idx(self, opt, batch_size, draw=None):
         """The pixel subset of a training step (reference :510): `nerf.rand_rays // batch_size` distinct pixels, the SAME set for
@@ -125,14 +137,32 @@ class Graph(nerf.Graph):
         else:
             unwarped = torch.cat([var.grid_cam, var.center_cam], dim=1)
             warped = torch.cat([var.grid_3D, var.center], dim=1)
-        poses = backend.rigid_registration(warped, unwarped)                          # the whole point set, on every rank: no collective
+        poses = backend.rigid_registration(warped, unwarped)                          # whole views: no collective under sharding either
+        win = var.get("view_window")
+        if win is None:
+            if hasattr(self, "global_rigid"):
+                self.global_rigid.weight.data = poses.reshape(-1, 12)              # what pose evaluation reads (:570); `poses` is a fresh tensor
+            loss.global_alignment = backend.alignment_residual(warped, unwarped, poses, n_norm=warped.numel())
+            return loss
+        # under ray sharding the tensors are this rank's window of views: it refreshes their rows of global_rigid (evaluation gathers the
+        # table, `gather_global_rigid`) and counts the alignment term of the views it OWNS, normalised by the global point count, so
+        # that the ranks' losses and gradients sum to the unsharded term
         if hasattr(self, "global_rigid"):
-            self.global_rigid.weight.data = poses.reshape(-1, 12)                  # what pose evaluation reads (:570); `poses` is a fresh tensor
-        # under ray sharding every rank holds the WHOLE alignment term (the warp is replicated, ..parallel): it enters with weight
-        # 1 / world, so that the per-rank losses -- like the per-rank photometric shares -- and their gradients sum to the global ones
-        world = (getattr(opt, "ray_shard", None) or (0, 1))[1]
-        loss.global_alignment = backend.alignment_residual(warped, unwarped, poses, n_norm=warped.numel() * world)
+            self.global_rigid.weight.data[win.views] = poses.reshape(-1, 12)
+        own = win.owned_in_window
+        n_global = 3 * win.B * warped.shape[1]
+        if own.stop > own.start:
+            loss.global_alignment = backend.alignment_residual(warped[own], unwarped[own], poses[own], n_norm=n_global)
+        else:
+            loss.global_alignment = warped.sum() * 0.0                              # (no view starts in this rank's share)
         return loss
+
+    def gather_global_rigid(self, opt=None):
+        """Under ray sharding every rank refreshes only the rows of `global_rigid` of the views it warps; before the table is read as a
+        whole (validation, checkpoints) every view's row is taken from the rank that owns the view (one small all-reduce)."""
+        from .. import parallel
+        if hasattr(self, "global_rigid"):
+            self.global_rigid.weight.data = parallel.gather_owned_rows(self.global_rigid.weight.data, getattr(self, "_last_window", None))
 
     def get_pose(self, opt, var, mode=None):
         return var.pose

@@ -72,6 +72,7 @@ class DeformNetwork(torch.nn.Module):
         self._ea, self._eb = ea, eb
         self.window_dev = None      # device tensor [12] of annealing windows read by the kernels at run time (engine.StepConstants)
         self.grad_sink = None       # (parameter-gradient buffer, code-gradient buffer) written instead of .grad (ops.warp_prepare)
+        self.code_rows = None       # (first, end) rows of the latent table the next forward's `deformation_code` holds; None: all of it
 
     # ------------------------------------------------------------------ operand preparation
     def _ensure_flat(self):
@@ -107,7 +108,15 @@ class DeformNetwork(torch.nn.Module):
         weight norm (nvp_ndr.py:291-292), code projection (:381) and the latent half of the first layers,
         fused in niw_warp_prep_fwd / _bwd."""
         flat = self._ensure_flat()
-        return ops.warp_prepare(flat, list(self.parameters()), code, grad_sink=self.grad_sink)
+        sink, rows = self.grad_sink, self.code_rows
+        if sink is not None and rows is not None and torch.is_grad_enabled():
+            # `code` is rows [rows[0], rows[1]) of the latent table whose gradient buffer the sink holds (a rank's window of views under
+            # ray sharding, ...parallel.ViewWindow): the kernel writes those rows, the other views get no gradient from this rank
+            full, a, b = sink[1], rows[0] * _LAT, rows[1] * _LAT
+            full[:a].zero_()
+            full[b:].zero_()
+            sink = (sink[0], full[a:b])
+        return ops.warp_prepare(flat, list(self.parameters()), code, grad_sink=sink)
 
     def _anneal(self, alpha_ratio):
         """-> (chan_w[6], index_window[6] | None).  reference_exact: the window multiplies whole points

@@ -38,20 +38,29 @@ class INNPoseParams(torch.nn.Module):
         return self.pose_embedding(self.pose_latent.weight, stacked, alpha_ratio=self._alpha(iter))
 
     def get_warped_rays_in_world(self, var, mode=None, iter=None):
-        """-> ray, center_3D, grid_3D, each [B,R,3] (training only)"""
+        """-> ray, center_3D, grid_3D, each [B,R,3] (training only).  Under ray sharding (`var.view_window`, ...parallel.ViewWindow)
+        B is this rank's window of whole views."""
         if mode != "train":
             raise AssertionError("INNPoseParams renders warped rays in training mode only")
-        self.center_init, self.grid_init = camera.get_unwarped_center_and_ray(self.opt, intr=var.intr, ray_idx=var.ray_idx,
-                                                                              pose_init=self.initial_poses_w2c)
-        ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.pose_embedding, self.pose_latent.weight, self.grid_init.detach(),
+        win = var.get("view_window")
+        views = slice(None) if win is None else win.views
+        self.center_init, self.grid_init = camera.get_unwarped_center_and_ray(self.opt, intr=var.intr[views], ray_idx=var.ray_idx,
+                                                                              pose_init=self.initial_poses_w2c[views])
+        self.pose_embedding.code_rows = None if win is None else (win.v0, win.v1)
+        ray, center_3D, grid_3D = nvp_ndr.warp_grid_and_center(self.pose_embedding, self.pose_latent.weight[views], self.grid_init.detach(),
                                                                self.center_init.detach(), self._alpha(iter))
-        self.solve_for_global_transformation(grid_3D, center_3D)
+        self.solve_for_global_transformation(grid_3D, center_3D, views)
         return ray, center_3D, grid_3D
 
-    def solve_for_global_transformation(self, grid_pred, center_pred):
+    def solve_for_global_transformation(self, grid_pred, center_pred, views=slice(None)):
         """Kabsch registration of the warped onto the initial points, kept detached in pose_global (reference :96-102).  Under ray
-        sharding every rank warps the whole point set (..parallel), so this is the global registration without a collective."""
+        sharding a rank warps WHOLE views (...parallel), so the registration of each of them is complete without a collective; the
+        rows of the views it handles are refreshed (every rank that touches a view computes the same row)."""
         stack = nvp_ndr.stacked_points(grid_pred, center_pred)
         warped, initial = stack if stack is not None else (torch.cat([grid_pred, center_pred], dim=1), torch.cat([self.grid_init, self.center_init], dim=1))
         R, t = rigid_points_registration(warped, initial)
-        self.pose_global.weight.data = torch.cat([R, t.unsqueeze(-1)], dim=-1).reshape(self.num_poses, 12).clone()
+        rows = torch.cat([R, t.unsqueeze(-1)], dim=-1).reshape(-1, 12)
+        if views == slice(None):
+            self.pose_global.weight.data = rows.clone()
+        else:
+            self.pose_global.weight.data[views] = rows

@@ -5,10 +5,12 @@ independent units, so the only exchange is the gradient all-reduce:
   * every rank holds all B views and the full parameter set;
   * one global pixel set is drawn per iteration, identical on every rank ("same pixels for every view",
     reference nerf_inn_llff.py:510, holds for the global batch exactly as in the reference);
-  * REPLICATED: ray generation, the NVP warp of all B x 2R points and the alignment term -- 0.4 % of the step's FLOPs.  Every rank
-    computes them on the whole batch, so the warp sees the points at the indices the reference gives them (its embedder window acts on
-    point INDICES, SURVEY W2: a sharded run is the same function as the unsharded one), the Kabsch registration needs no collective,
-    and the alignment gradient enters with weight 1 / world (the all-reduce sums it back to 1);
+  * PER WHOLE VIEW: ray generation, the NVP warp and the alignment term -- 0.4 % of the step's FLOPs.  A rank warps ALL 2R points of
+    every view its share of the rays touches (view_window: B / world + 1 views or fewer), whole views because the warp's embedder window
+    acts on point INDICES inside a view: every point is warped at the index the reference gives it, so a sharded run is the
+    same function as the unsharded one, and the per-view Kabsch registration has all of a view's points at hand -- no collective inside
+    the forward.  A view cut by a share boundary is warped by both neighbours; its alignment term is counted once, by the rank that
+    holds the view's first ray.  (Warping the whole batch on every rank, the first form of this round, cost N x the warp under weak scaling.)
   * SHARDED: everything per (ray, sample) -- depth sampling, the field MLPs, compositing, the photometric loss -- on the rank's
     CONTIGUOUS share of the flattened view-major [B][R] ray list (flat_share: equal shares to within one ray).  Round 2 gave rank r
     the pixels idx[r::world] of every view; at 113 rays per view and 8 ranks that is 15 rays on rank 0 = 34,560 samples, 1,792 more
@@ -62,11 +64,49 @@ def flat_share(n_rays, rank, world):
     return (n_rays * rank) // world, (n_rays * (rank + 1)) // world
 
 
+class ViewWindow:
+    """What one rank handles of a batch of B views x R rays (view-major flat ray list):
+         lo, hi      its contiguous share of the rays (flat_share)
+         v0, v1      the views that share touches, [v0, v1): these it generates rays for and warps WHOLE
+         own0, own1  the views whose first ray lies in its share, [own0, own1): their alignment terms are its to count
+         local       the share as a slice of the window's own flattened rays: [lo - v0 R, hi - v0 R)"""
+
+    def __init__(self, n_views, n_rays_per_view, rank, world):
+        B, R = int(n_views), int(n_rays_per_view)
+        self.B, self.R = B, R
+        self.lo, self.hi = flat_share(B * R, rank, world)
+        if self.hi > self.lo:
+            self.v0, self.v1 = self.lo // R, (self.hi - 1) // R + 1
+            self.own0, self.own1 = -(-self.lo // R), (self.hi - 1) // R + 1
+        else:                                   # more ranks than rays: nothing to do
+            self.v0 = self.v1 = self.own0 = self.own1 = 0
+        self.own1 = max(self.own1, self.own0)
+        self.local = (self.lo - self.v0 * R, self.hi - self.v0 * R)
+
+    @property
+    def views(self):
+        return slice(self.v0, self.v1)
+
+    @property
+    def owned_in_window(self):
+        return slice(self.own0 - self.v0, self.own1 - self.v0)
+
+
 def all_reduce_sum_(t):
     """In-place SUM over ranks (identity without a process group): the [B,16] Kabsch moments of the alignment loss."""
     if _collectives_live():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def gather_owned_rows(table, win):
+    """Per-view table [B, k] of which every rank has refreshed the rows of the views it handles: -> the table with every view's row
+    taken from the rank that OWNS the view (zeros elsewhere, summed over ranks).  Identity without a process group or window."""
+    if win is None or not _collectives_live():
+        return table
+    out = torch.zeros_like(table)
+    out[win.own0:win.own1] = table[win.own0:win.own1]
+    return all_reduce_sum_(out)
 
 
 def global_loss_elements(n_views, n_rays_global):

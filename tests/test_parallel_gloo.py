@@ -126,8 +126,12 @@ def _ga_worker(rank, world, port, q):
     torch.nn.Module.__init__(g)
     opt = edict(loss_weight=edict(render=None, render_fine=None, global_alignment=2), nerf=edict(rand_rays=R * B, fine_sampling=False),
                 ray_shard=(rank, world))
-    # round 3: the warp and the alignment term are REPLICATED -- every rank holds all points and the whole term, weighted 1 / world
-    var = edict(grid_cam=src[:, :R], center_cam=src[:, R:], grid_3D=tgt[:, :R], center=tgt[:, R:], idx=torch.arange(B), ray_idx=torch.arange(R))
+    # round 3: a rank holds the WHOLE views its share of the rays touches (parallel.ViewWindow) and counts the alignment terms of the
+    # views whose first ray is its own; no collective inside
+    win = parallel.ViewWindow(B, R, rank, world)
+    v = win.views
+    var = edict(grid_cam=src[v, :R], center_cam=src[v, R:], grid_3D=tgt[v, :R], center=tgt[v, R:], idx=torch.arange(B), ray_idx=torch.arange(R),
+                view_window=win)
     loss = g.compute_loss(opt, var, mode="train").global_alignment
     loss.backward()
     grad = tgt.grad.clone()
@@ -139,9 +143,9 @@ def _ga_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_replicated_kabsch_alignment_loss_sums_to_the_single_process_one():
-    """per-rank alignment losses and gradients (each the whole term / world, no collective inside) SUM to the reference's
-    formulation, autograd THROUGH the SVD of the registration"""
+def test_per_view_kabsch_alignment_losses_sum_to_the_single_process_one():
+    """per-rank alignment losses and gradients (each rank the views it owns, no collective inside) SUM to the reference's formulation,
+    autograd THROUGH the SVD of the registration"""
     from oracle import niw_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -203,7 +207,15 @@ def test_every_rank_draws_the_same_pixels_and_the_shares_partition_the_rays():
         assert np.array_equal(both[0], both[1]) and len(both[0]) == 37 and len(set(both[0].tolist())) == 37
         seen.append(tuple(both[0].tolist()))
     assert len(set(seen)) == len(seen)                              # a fresh draw every step
-    for n, w in ((3 * 37, 2), (18 * 113, 8), (18 * 227, 8), (3 * 682, 8), (5, 8), (56 * 36, 8)):
+    for Bv, Rv, w in ((3, 37, 2), (18, 113, 8), (18, 227, 8), (3, 682, 8), (5, 1, 8), (56, 36, 8)):
+        n = Bv * Rv
+        wins = [parallel.ViewWindow(Bv, Rv, r, w) for r in range(w)]
+        owned = [b for x in wins for b in range(x.own0, x.own1)]
+        assert owned == list(range(Bv))                                 # every view's alignment term is counted exactly once
+        for x in wins:
+            if x.hi > x.lo:
+                assert x.v0 * Rv <= x.lo and x.hi <= x.v1 * Rv and x.v0 <= x.own0 and x.own1 <= x.v1      # the window holds the share, whole views
+                assert x.local == (x.lo - x.v0 * Rv, x.hi - x.v0 * Rv)
         shares = [parallel.flat_share(n, r, w) for r in range(w)]
         assert shares[0][0] == 0 and shares[-1][1] == n and all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
         sizes = [hi - lo for lo, hi in shares]
