@@ -34,6 +34,8 @@ def analytic_scene(pts):
 
 @torch.no_grad()
 def render_teacher(opt, pose, intr, S=192):
+    if pose.shape[0] > 1 and pose.shape[0] * opt.H * opt.W * S > (1 << 27):    # image-scale scenes: one view at a time (the analytic scene
+        return torch.cat([render_teacher(opt, pose[i:i + 1], intr[i:i + 1], S) for i in range(pose.shape[0])])    # materialises ~60 floats per sample)
     B = pose.shape[0]
     center, ray = camera.get_center_and_ray(opt, pose, intr=intr)          # [B,HW,3]
     depth = torch.linspace(1.0, 7.0, S, device=pose.device)
