@@ -206,7 +206,13 @@ __device__ __forceinline__ void stream_layer_shared(const WeightStream<TERMS>& w
 
 // The same layer with every wave fetching its own copy of every chunk through a register ring (kFastRing chunks in flight), as the
 // exact-fp32 kernel does.  Which of the two forms a mode uses is decided by measurement (kSharedWeights below).
-constexpr int kFastRing = 8;
+#ifndef NIW_FAST_RING
+#define NIW_FAST_RING 8
+#endif
+#ifndef NIW_FAST_SCHED
+#define NIW_FAST_SCHED 1
+#endif
+constexpr int kFastRing = NIW_FAST_RING;
 template <int KS1, int KS2, int NB, int TERMS, typename Policy>
 __device__ __forceinline__ void stream_layer_ring(const WeightStream<TERMS>& ws, int stage0, const unsigned (&b1)[2][4 * KS1],
                                                   const unsigned (&b2)[2][4 * (KS2 > 0 ? KS2 : 1)], Policy& pol) {
@@ -250,7 +256,7 @@ __device__ __forceinline__ void stream_layer_ring(const WeightStream<TERMS>& ws,
 #pragma unroll
                 for (int rp = q * 8 / KS; rp < (q + 1) * 8 / KS; ++rp) pol.epi2(nb - 1, rp, acc[(nb - 1) & 1][2 * rp], acc[(nb - 1) & 1][2 * rp + 1]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (NIW_FAST_SCHED) __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
