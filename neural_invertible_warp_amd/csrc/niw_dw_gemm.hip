@@ -198,11 +198,13 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
         gload(step0, 0);
         lstore(0, 0);
     }
-    if (PF == 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    if (PF >= 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    if (PF >= 3 && nsteps > 2) gload(step0 + 2, 2 % PF);
     __syncthreads();
     for (int s = 0; s < nsteps; s += PF) {
         step_body(s, std::integral_constant<int, 0>{});
-        if (PF == 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF >= 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF >= 3 && s + 2 < nsteps) step_body(s + 2, std::integral_constant<int, 2 % PF>{});
     }
     // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
     float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
@@ -349,11 +351,13 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_fast_kernel(GemmBatch ba
         gload(step0, 0);
         lstore(0, 0);
     }
-    if (PF == 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    if (PF >= 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    if (PF >= 3 && nsteps > 2) gload(step0 + 2, 2 % PF);
     __syncthreads();
     for (int s = 0; s < nsteps; s += PF) {
         step_body(s, std::integral_constant<int, 0>{});
-        if (PF == 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF >= 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF >= 3 && s + 2 < nsteps) step_body(s + 2, std::integral_constant<int, 2 % PF>{});
     }
     float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
 #pragma unroll

@@ -55,7 +55,7 @@ def rotation_gauge_error(pose, gt):
     return float(camera.rotation_distance((Re @ Q).float(), Rg.float()).mean()) * DEG
 
 
-def run(variant, seed, steps, device="cuda:0", size=(48, 64), ga=4):
+def run(variant, seed, steps, device="cuda:0", size=(48, 64), ga=4, hip_graph=False, precision="fp32", log_every=0):
     H, W = size
     views = 16 if variant == "views_16" else 8
     opt = configs.cfg3_barf_inn_llff(device=device, global_alignment=ga)
@@ -64,6 +64,7 @@ def run(variant, seed, steps, device="cuda:0", size=(48, 64), ga=4):
     opt.nerf.rand_rays, opt.nerf.sample_intvs = 2048, 64
     opt.inn.real_nvp.max_pe_iter = steps // 2
     opt.optim.test_photo = False
+    opt.arch.precision = precision
     gen = torch.Generator().manual_seed(seed)
     scale = torch.tensor([0.06, 0.06, 0.03, 0.15, 0.15, 0.05])
     if variant == "rotation_x5":
@@ -74,7 +75,8 @@ def run(variant, seed, steps, device="cuda:0", size=(48, 64), ga=4):
     intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(views, 1, 1).to(device)
     image = render_teacher(opt, pose_GT, intr)
     var0 = edict(idx=torch.arange(views), image=image, intr=intr, pose=torch.eye(3, 4, device=device).repeat(views, 1, 1))
-    tr = engine.INNTrainer(opt, views, seed=seed, ray_sampler="randperm" if variant == "randperm" else None)
+    tr = engine.INNTrainer(opt, views, seed=seed, ray_sampler="randperm" if variant == "randperm" else None,
+                           hip_graph=hip_graph and variant not in ("randperm", "torch_adam"))
     if variant == "per_channel":
         tr.warp_mlp.reference_exact = False
     saved = ops.adam_step
@@ -82,25 +84,33 @@ def run(variant, seed, steps, device="cuda:0", size=(48, 64), ga=4):
         ops.adam_step = torch_adam_step
     ev = evaluation.LLFFEvaluator(opt, tr.graph, pose_GT)
     t0 = time.perf_counter()
+
+    def report(loss):
+        psnr = -10 * torch.log10(loss.render.detach()).item()
+        pose, gt = ev.get_all_training_poses(opt)
+        aligned, _ = ev.prealign_cameras(opt, pose, gt)
+        err = ev.evaluate_camera_alignment(opt, aligned, gt)
+        Rp, Rg = pose[:, :, :3], gt[:, :, :3]
+        rel = camera.rotation_distance(Rp[:, None] @ Rp[None].transpose(-1, -2), Rg[:, None] @ Rg[None].transpose(-1, -2))
+        n = pose.shape[0]
+        centres = -(gt[:, :, :3].transpose(1, 2) @ gt[:, :, 3:])[..., 0]
+        learnt_c = -(pose[:, :, :3].transpose(1, 2) @ pose[:, :, 3:])[..., 0]
+        return dict(variant=variant, seed=seed, steps=tr.it, of_steps=steps, views=views, precision=precision, train_psnr=round(psnr, 2),
+                    rot_err_centre_aligned_deg=round(float(err.R.mean()) * DEG, 3), trans_err_centre_aligned=round(float(err.t.mean()), 4),
+                    rot_err_rotation_aligned_deg=round(rotation_gauge_error(pose, gt), 3),
+                    pairwise_relative_rot_err_deg=round(float(rel.sum() / (n * n - n)) * DEG, 3),
+                    pairwise_centre_distance_err=round(float((torch.cdist(learnt_c, learnt_c) - torch.cdist(centres, centres)).abs().sum() / (n * n - n)), 4),
+                    gt_rotation_spread_deg=round(float(camera.rotation_distance(Rg, torch.eye(3, device=device).expand_as(Rg)).mean()) * DEG, 2),
+                    gt_centre_spread=round(float((centres - centres.mean(0)).norm(dim=-1).mean()), 4), seconds=round(time.perf_counter() - t0, 1))
+
     try:
-        for _ in range(steps):
+        for i in range(steps):
             loss = tr.train_iteration(edict(var0))
+            if log_every and (i + 1) % log_every == 0 and i + 1 < steps:
+                print(json.dumps(report(loss)), flush=True)
     finally:
         ops.adam_step = saved
-    psnr = -10 * torch.log10(loss.render.detach()).item()
-    pose, gt = ev.get_all_training_poses(opt)
-    aligned, _ = ev.prealign_cameras(opt, pose, gt)
-    err = ev.evaluate_camera_alignment(opt, aligned, gt)
-    Rp, Rg = pose[:, :, :3], gt[:, :, :3]
-    rel = camera.rotation_distance(Rp[:, None] @ Rp[None].transpose(-1, -2), Rg[:, None] @ Rg[None].transpose(-1, -2))
-    n = pose.shape[0]
-    centres = -(gt[:, :, :3].transpose(1, 2) @ gt[:, :, 3:])[..., 0]
-    return dict(variant=variant, seed=seed, steps=steps, views=views, train_psnr=round(psnr, 2),
-                rot_err_centre_aligned_deg=round(float(err.R.mean()) * DEG, 3), trans_err_centre_aligned=round(float(err.t.mean()), 4),
-                rot_err_rotation_aligned_deg=round(rotation_gauge_error(pose, gt), 3),
-                pairwise_relative_rot_err_deg=round(float(rel.sum() / (n * n - n)) * DEG, 3),
-                gt_rotation_spread_deg=round(float(camera.rotation_distance(Rg, torch.eye(3, device=device).expand_as(Rg)).mean()) * DEG, 2),
-                gt_centre_spread=round(float((centres - centres.mean(0)).norm(dim=-1).mean()), 4), seconds=round(time.perf_counter() - t0, 1))
+    return report(loss)
 
 
 if __name__ == "__main__":
@@ -109,11 +119,14 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1])
     ap.add_argument("--variants", nargs="+", default=["base", "randperm", "torch_adam", "per_channel", "rotation_x5", "translation_x5", "views_16"])
     ap.add_argument("--out", default="gpurun_out/plateau.json")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the captured iteration (faster at these small shapes; same numbers bit for bit)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"])
+    ap.add_argument("--log-every", type=int, default=0)
     a = ap.parse_args()
     rows = []
     for v in a.variants:
         for s in a.seeds:
-            r = run(v, s, a.steps)
+            r = run(v, s, a.steps, hip_graph=a.hip_graph, precision=a.precision, log_every=a.log_every)
             rows.append(r)
             print(json.dumps(r), flush=True)
             os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
