@@ -26,6 +26,7 @@ struct MlpBwdArgs {
     float* d_ray;
     long long M, Mpad;
     int S, act, ray_grad;
+    int zero;          // always 0: added to the bit positions of the mask decode so that they are not compile-time constants (MaskEpilogue)
 };
 
 // Epilogue policies for stream_layer() (niw_mlp_device.h); all workspace traffic uses buffer addressing.
@@ -38,17 +39,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NBOUT>
 struct MaskEpilogue {
     u32x4 mk;                            // this lane's 16 bytes of the mask record of the layer input
+    int zero;                            // 0 at run time
     float (&out)[16 * NBOUT];
     RowWindow grad;                      // where dY of the producing layer is stored
     static constexpr bool kAccInit = false;
     __device__ __forceinline__ void acc_init(int, f32x16&) const {}
     __device__ __forceinline__ void pre(int, float (&)[16]) const {}
     __device__ __forceinline__ void epi(int nb, int r, float a, float) {
-        // sign-extended 1-bit field = all-ones / zero: the ReLU mask is one AND on the float's bits.  (hipcc turns this into
-        // test-bit / compare / select, three VALU instructions; any inline asm that would pin v_bfe_i32 + v_and_b32 -- even an
-        // empty one that only hides the field's origin -- stops the unrolling of the layer loops and sends the register arrays
-        // to scratch.)
-        const int keep = (int)(mk[nb >> 1] << (16 * (nb & 1) + r)) >> 31;
+        // sign-extended 1-bit field = all-ones / zero, then one AND on the float's bits: v_bfe_i32 + v_and_b32, two VALU instructions.
+        // The bit position carries a run-time zero (a kernel argument; the sum stays on the scalar ALU): with a constant position
+        // LLVM rewrites the pair as test-bit / compare / select -- three instructions plus the wait states of the compare's VCC --
+        // and any inline asm that would pin the pair stops the unrolling of the layer loops.  VALU instructions are what this kernel
+        // pays for: each one issued between the MFMAs of the fp32 chain costs the matrix pipe 4-6 cycles
+        // (tools/mfma_valu_contention.hip).
+        const int keep = __builtin_amdgcn_sbfe((int)mk[nb >> 1], 31 - (16 * (nb & 1) + r) + zero, 1);
         const float g = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
         out[nb * 16 + r] = g;
         if ((r & 3) == 3)                  // four consecutive rows of this lane: one 16-byte store (quad-row image, niw_mlp_device.h)
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
                                                                       // counted from row R of a quad-row image (niw_mlp_device.h)
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
     const long long P = a.Mpad;
+    const int zero = a.zero;
     const PackedWeights pw = packed_weights(a.packed, lane);
     const int pitch4 = (int)(P * 4), voff4 = (int)(((long long)h * P + m) * 16);
     auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };     // gradient rows
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     reinterpret_cast<f32x4*>(a.grad + (long long)kGradRgb1 * P)[qoff] = f32x4{dy9[0], dy9[1], dy9[2], dy9[3]};   // rows 4h + t of the 8-row slot block
     float dyr[64];
     {
-        MaskEpilogue<4> ep{mk_cur, dyr, gwin(kGradRgb0)};
+        MaskEpilogue<4> ep{mk_cur, zero, dyr, gwin(kGradRgb0)};
         stream_layer<1, 0, 4, 4>(pw, wp + bwd_pack_off(9) / 4, dy9, none, ep);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = row block 8 of 9)
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(6);
-        MaskEpilogue<8> ep{mk_cur, dy, gwin(kGradY7)};
+        MaskEpilogue<8> ep{mk_cur, zero, dy, gwin(kGradY7)};
         stream_layer<16, 0, 8, 9>(pw, wp + bwd_pack_off(8) / 4, dyr, none, ep);
     }
     // ---- density head: d sigma_raw (kernel row 256 of layer 7)
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(5);
-        MaskEpilogue<8> ep{mk_cur, nxt, gwin(6 * 256)};
+        MaskEpilogue<8> ep{mk_cur, zero, nxt, gwin(6 * 256)};
         stream_layer<32, 1, 8, 8>(pw, wp + bwd_pack_off(7) / 4, dy, dsig, ep);
         advance();
     }
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l - 2);       // this layer masks with record l-1 (output of layer l-1)
-        MaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
+        MaskEpilogue<8> ep{mk_cur, zero, nxt, gwin((l - 1) * 256)};
         stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), dy, none, ep);
         advance();
     }
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(2);
-        MaskEpilogue<8> ep{mk_cur, nxt, gwin(3 * 256)};
+        MaskEpilogue<8> ep{mk_cur, zero, nxt, gwin(3 * 256)};
         stream_layer<32, 0, 8, 10>(pw, wp + bwd_pack_off(4) / 4, dy, none, ep);
         advance();
     }
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l >= 2 ? l - 2 : 0);
-        MaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
+        MaskEpilogue<8> ep{mk_cur, zero, nxt, gwin((l - 1) * 256)};
         stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), dy, none, ep);
         advance();
     }
@@ -270,6 +275,7 @@ int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float*
     a.save = save; a.grad = gradws; a.d_center = d_center; a.d_ray = d_ray;
     a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
     a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
+    a.zero = 0;
     mlp_bwd_dx_kernel<<<(int)(a.Mpad / 128), 256, 0, stream>>>(a);
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dX chain)");
     if (a.ray_grad) return niw_launch_ray_grad_reduce(gradws, a.Mpad, n_rays, n_samples, d_center, d_ray, stream);

@@ -518,14 +518,18 @@ int niw_launch_mlp_fwd_fast(int precision, const void* image, const float* cente
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ float relu_keep(const u32x4_t& mk, int nb, int r, float a) {
-    const int keep = (int)(mk[nb >> 1] << (16 * (nb & 1) + r)) >> 31;       // sign bit record of the forward -> all ones / zero
+// sign bit record of the forward -> all ones / zero -> one AND: v_bfe_i32 + v_and_b32.  `zero` is a run-time 0 (kernel argument) that
+// keeps the bit position from being a compile-time constant -- with one LLVM rewrites the pair as test-bit / compare / select, three
+// instructions and the compare's wait states (niw_mlp_bwd.hip MaskEpilogue).
+__device__ __forceinline__ float relu_keep(const u32x4_t& mk, int nb, int r, float a, int zero) {
+    const int keep = __builtin_amdgcn_sbfe((int)mk[nb >> 1], 31 - (16 * (nb & 1) + r) + zero, 1);
     return __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
 }
 // mask, planes for the next product, fp32 store of dY for the dW pass
 template <int NBOUT>
 struct FastMaskEpilogue {
     u32x4_t mk;
+    int zero;
     unsigned (&out)[2][8 * NBOUT];
     RowWindow grad;
     float keep[2] = {0.f, 0.f};
@@ -534,7 +538,7 @@ struct FastMaskEpilogue {
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
     }
     __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
-        const float g0 = relu_keep(mk, nb, 2 * rp, a0), g1 = relu_keep(mk, nb, 2 * rp + 1, a1);
+        const float g0 = relu_keep(mk, nb, 2 * rp, a0, zero), g1 = relu_keep(mk, nb, 2 * rp + 1, a1, zero);
         split_pair(g0, g1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
         if (rp & 1) buf_store4(keep[0], keep[1], g0, g1, grad.rsrc(nb * 32), grad.voff4, 8 * (rp >> 1) * grad.pitch4);
         else { keep[0] = g0; keep[1] = g1; }
@@ -582,6 +586,7 @@ struct FastBwdArgs {
     float* grad;
     long long M, Mpad;
     int S, act, ray_grad;
+    int zero;          // always 0 (relu_keep)
 };
 
 template <int TERMS>
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     }
     unsigned dyr[2][32];
     {
-        FastMaskEpilogue<4> ep{mk_cur, dyr, gwin(kGradRgb0)};
+        FastMaskEpilogue<4> ep{mk_cur, a.zero, dyr, gwin(kGradRgb0)};
         stream_layer_bf<1, 0, 4, TERMS, (fast_bwd_chunk(0) / G) % kRingStages>(ws, fast_bwd_chunk(0) / G, dy9p, none, ep);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = slot block 8 of 9)
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(6);
-        FastMaskEpilogue<8> ep{mk_cur, dy, gwin(kGradY7)};
+        FastMaskEpilogue<8> ep{mk_cur, a.zero, dy, gwin(kGradY7)};
         stream_layer_bf<8, 0, 8, TERMS, (fast_bwd_chunk(2) / G) % kRingStages>(ws, fast_bwd_chunk(2) / G, dyr, none, ep);
     }
     // ---- density head: d sigma_raw = reduction row 256 of layer 7 = element 0 of lane half 0 of the 17th step
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(5);
-        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin(6 * 256)};
+        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin(6 * 256)};
         stream_layer_bf<16, 1, 8, TERMS, (fast_bwd_chunk(3) / G) % kRingStages>(ws, fast_bwd_chunk(3) / G, dy, dsigp, ep);
         advance();
     }
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l - 2);
-        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
+        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin((l - 1) * 256)};
         stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(4) / G) % kRingStages>(ws, fast_bwd_chunk(4) / G + (6 - l) * (8 * 16 / G), dy, none, ep);
         advance();
     }
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(2);
-        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin(3 * 256)};
+        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin(3 * 256)};
         stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(7) / G) % kRingStages>(ws, fast_bwd_chunk(7) / G, dy, none, ep);
         advance();
     }
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l >= 2 ? l - 2 : 0);
-        FastMaskEpilogue<8> ep{mk_cur, nxt, gwin((l - 1) * 256)};
+        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin((l - 1) * 256)};
         stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(8) / G) % kRingStages>(ws, fast_bwd_chunk(8) / G + (3 - l) * (8 * 16 / G), dy, none, ep);
         advance();
     }
@@ -735,6 +740,7 @@ int niw_launch_mlp_bwd_dx_fast(int precision, const void* image, const float* ce
     a.center = center; a.ray = ray; a.depth = depth; a.rgb = rgb; a.d_rgb = d_rgb; a.d_sigma = d_sigma; a.save = save; a.grad = gradws;
     a.M = n_rays * (int64_t)n_samples; a.Mpad = niw_mlp_padded_rows(n_rays, n_samples);
     a.S = n_samples; a.act = density_activ; a.ray_grad = (d_center != nullptr && d_ray != nullptr) ? 1 : 0;
+    a.zero = 0;
     const int blocks = (int)(a.Mpad / 128);
 #define NIW_FAST_BWD(T)                                                                                                     \
     do {                                                                                                                    \
