@@ -159,12 +159,19 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
                 // row sums of the dY operand: thread t < rows sums its row of the staged slice
                 const int nrows = bias_side == 1 ? TN : TK;
                 if (tid < nrows) {
+                    // two packed adds per 16-byte read (the halves of a ds_read_b128 are aligned register pairs: v_pk_add_f32 without
+                    // moves) and two scalar adds per step: 18 vector instructions where the scalar form compiled to ~45 -- and vector
+                    // instructions are paid in matrix-pipe time (tools/mfma_valu_contention.hip)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
                     const float* rowp = (bias_side == 1 ? As : Bs) + tid * kLdsStride;
+                    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + c * 4);
-                        bsum += (v[0] + v[1]) + (v[2] + v[3]);
+                        s2 += v.lo;
+                        s2 += v.hi;
                     }
+                    bsum += s2[0] + s2[1];
                 }
             }
         };

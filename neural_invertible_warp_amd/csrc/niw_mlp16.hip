@@ -176,8 +176,23 @@ struct Fwd16Epilogue {
             else keep[r] = v;
             mbits[ob >> 3] = __builtin_amdgcn_alignbit(mbits[ob >> 3], __builtin_bit_cast(unsigned, v) + 0x7fffffffu, 31);
             if (ob == NBOUT - 1 && r == 3) {
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{mbits[0], mbits[1]}, make_rsrc(mrec), lane * 8, 0, 0);
+                // The dX chain (niw_mlp_bwd.hip) owns 32 samples per wave and expects, per lane (sample i, half h), dword nb / 2 with
+                // bit 31 - (16 (nb & 1) + r32) for row 32 nb + 8 (r32 >> 2) + 4 h + (r32 & 3).  This lane (sample j, group g) holds rows
+                // 16 ob + 4 g + r: for the dX lane (i = 16 (wave & 1) + j, h = g & 1) that is every other nibble of the record -- the
+                // even nibbles on the lanes g < 2, the odd ones on their partners g + 2.  Spread the four nibbles of each 16-bit half
+                // over alternate nibble slots, merge the partner's through one cross-half exchange, and let the lanes g < 2 write.
+                unsigned D[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned s16 = (d & 1) ? (mbits[d >> 1] & 0xffffu) : (mbits[d >> 1] >> 16);
+                    unsigned x = (s16 | (s16 << 8)) & 0x00ff00ffu;
+                    x = (x | (x << 4)) & 0x0f0f0f0fu;
+                    D[d] = (lane & 32) ? x : (x << 4);
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) D[d] |= __shfl_xor(D[d], 32);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(u32x4{D[0], D[1], D[2], D[3]}, make_rsrc(mrec), (2 * (lane & 16) + (lane & 15)) * 16, 0, 0);
             }
         }
     }
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(64 * NIW_V16_WAVES, 2) void mlp_fwd16_kernel(Mlp16A
     const long long pair_id = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * NIW_V16_WAVES + wave) >> 1));
     const int half = __builtin_amdgcn_readfirstlane(wave & 1);
     auto mask_rec = [&](int i) {
-        return SAVE ? reinterpret_cast<const char*>(a.save + row_off(kSaveMask)) + (pair_id * kMaskRecords + i) * kMaskRecBytes + half * 512 : nullptr;
+        return SAVE ? reinterpret_cast<const char*>(a.save + row_off(kSaveMask)) + (pair_id * kMaskRecords + i) * kMaskRecBytes + half * 256 : nullptr;
     };
     if (SAVE) {
         const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);

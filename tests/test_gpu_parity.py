@@ -190,6 +190,46 @@ def test_mlp_backward_vs_oracle(S, activ):
     relclose(c2.grad, center.grad, 2e-3); relclose(r2.grad, ray.grad, 2e-3)
 
 
+def test_mlp_backward_with_exactly_zero_preactivations():
+    """ReLU'(0) = 0, as in torch (reference model/nerf.py:422-447 uses torch_F.relu): a layer whose weight and bias are zero has the
+    pre-activation +0.0 on every sample; no gradient may pass it.  The kernels record (activation > 0) -- not the sign bit of the
+    pre-activation, which would let +0.0 through -- so every gradient upstream of the dead layer is EXACTLY zero, the dead layer's
+    own weight and bias gradients are zero, and the layers behind it (fed by the skip connection) match the oracle."""
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(5)
+    N, S = 6, 16
+    p = O.make_nerf_params(9)
+    p["mlp_feat.2.weight"].zero_(); p["mlp_feat.2.bias"].zero_()
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    center, ray, depth = _mlp_inputs(rng, N, S)
+    rgb_ref, sig_ref = O.forward_samples(p, center[None], ray[None], depth[None, :, :, None], density_activ="softplus")
+    g_rgb, g_sig = t(rng.standard_normal((N, S, 3))), t(rng.standard_normal((N, S)))
+    ((rgb_ref[0] * g_rgb).sum() + (sig_ref[0] * g_sig).sum()).backward()
+    names = [f"{n}.{k}" for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]
+    flat = torch.cat([p[n].detach().reshape(-1) for n in names]).to(DEV)
+    st = ops.FieldState(flat)
+    params, off = [], 0
+    for n in names:
+        params.append(flat[off:off + p[n].numel()].view(p[n].shape).requires_grad_(True))
+        off += p[n].numel()
+    rgb, sig = ops.field_mlp(st, params, g(center), g(ray), g(depth), [1.0] * 10, [1.0] * 4, "softplus")
+    close(rgb, rgb_ref[0]); close(sig, sig_ref[0], atol=5e-5, rtol=2e-4)
+    ((rgb * g(g_rgb)).sum() + (sig * g(g_sig)).sum()).backward()
+    for n, prm in zip(names, params):
+        layer = int(n.split(".")[1]) if n.startswith("mlp_feat") else 99
+        if layer <= 2:
+            assert float(p[n].grad.abs().max()) == 0.0                      # the reference's own gradient is zero here ...
+            assert float(prm.grad.abs().max()) == 0.0, n                    # ... and so is ours, exactly
+        elif layer == 3:
+            # input of layer 3 is the dead layer's all-zero output: zero weight gradient, live bias gradient
+            if n.endswith("weight"):
+                assert float(prm.grad.abs().max()) == 0.0, n
+            else:
+                relclose(prm.grad, p[n].grad, 2e-3)
+        else:
+            relclose(prm.grad, p[n].grad, 2e-3)
+
+
 @pytest.mark.parametrize("alpha,exact", [(0.3, True), (1.0, True), (0.45, False)])
 def test_warp_vs_oracle_and_golden(alpha, exact):
     from neural_invertible_warp_amd.model.nvp import nvp_ndr
