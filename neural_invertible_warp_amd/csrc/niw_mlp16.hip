@@ -190,9 +190,13 @@ struct Fwd16Epilogue {
                     D[d] = (lane & 32) ? x : (x << 4);
                 }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) D[d] |= __shfl_xor(D[d], 32);
+                for (int d = 0; d < 4; ++d) {       // v_permlane32_swap: lanes l and l + 32 see each other's value (no LDS round trip)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(D[d], D[d], false, false);
+                    D[d] = sw[0] | sw[1];
+                }
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                if (lane < 32) __builtin_amdgcn_raw_buffer_store_b128(u32x4{D[0], D[1], D[2], D[3]}, make_rsrc(mrec), (2 * (lane & 16) + (lane & 15)) * 16, 0, 0);
+                // (the lanes g >= 2 hold the same merged words as their partners and write them to the same place)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{D[0], D[1], D[2], D[3]}, make_rsrc(mrec), (2 * (lane & 16) + (lane & 15)) * 16, 0, 0);
             }
         }
     }
@@ -292,8 +296,11 @@ __global__ __launch_bounds__(64 * NIW_V16_WAVES, 2) void mlp_fwd16_kernel(Mlp16A
     // ReLU sign-mask records: the 1 KiB record of a 32-sample pair of waves holds this wave's 512 bytes ([lane][8 bytes]) in its half
     const long long pair_id = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * NIW_V16_WAVES + wave) >> 1));
     const int half = __builtin_amdgcn_readfirstlane(wave & 1);
-    auto mask_rec = [&](int i) {
-        return SAVE ? reinterpret_cast<const char*>(a.save + row_off(kSaveMask)) + (pair_id * kMaskRecords + i) * kMaskRecBytes + half * 256 : nullptr;
+    auto mask_rec = [&](int i) -> const char* {
+        if (!SAVE) return nullptr;
+        const unsigned long long p = reinterpret_cast<unsigned long long>(a.save + row_off(kSaveMask)) + (pair_id * kMaskRecords + i) * kMaskRecBytes + half * 256;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));   // wave-uniform: says so
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
     };
     if (SAVE) {
         const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
