@@ -84,7 +84,13 @@ __global__ void pack_fast_kernel(const float* __restrict__ params, unsigned* __r
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int kRingStages = 4;
 constexpr int kStageBytes = kStageChunks * kChunkBytes;
-constexpr int kFastLdsBytes = kRingStages * kStageBytes;              // 64 KiB
+constexpr int kFastRingBytes = kRingStages * kStageBytes;             // 64 KiB
+// LDS requested per workgroup: the ring plus 32 KiB that nobody touches -- two such workgroups do not fit a CU's 160 KiB, which pins
+// these kernels to ONE workgroup per CU (why: the comment at mlp_fwd_fast_kernel)
+#ifndef NIW_FAST_LDS_RESERVE
+#define NIW_FAST_LDS_RESERVE 32768
+#endif
+constexpr int kFastLdsBytes = kFastRingBytes + NIW_FAST_LDS_RESERVE;
 
 template <int TERMS>
 struct WeightStream {
@@ -270,7 +276,10 @@ __device__ __forceinline__ void stream_layer_ring(const WeightStream<TERMS>& ws,
 // chunk the per-wave ring keeps up (and the shared form's barrier, fragment reads and waits cost as much as they save); with one
 // instruction per chunk the ring's 128 B / clk / CU does not, and sharing wins where the kernel also streams stores.
 template <int TERMS>
-constexpr bool kSharedWeights = TERMS == 1;
+#ifndef NIW_FAST_SHARED
+#define NIW_FAST_SHARED 1
+#endif
+constexpr bool kSharedWeights = TERMS == 1 && NIW_FAST_SHARED;
 
 template <int KS1, int KS2, int NB, int TERMS, int PHASE, typename Policy>
 __device__ __forceinline__ void stream_layer_bf(const WeightStream<TERMS>& ws, int stage0, const unsigned (&b1)[2][4 * KS1],
@@ -356,6 +365,14 @@ __device__ __forceinline__ float density_act_fast(float x, int kind) {
 
 static_assert((8 * 16 / kStageChunks) % kRingStages == 0, "a 256 -> 256 layer is a whole number of ring turns: the layers of one rolled loop share their ring phase");
 
+// ONE workgroup per CU, like the exact-fp32 kernels -- enforced by the launch's LDS request (kFastLdsBytes: the 64 KiB ring plus a
+// reserve that leaves no room for a second workgroup's 96 KiB in the CU's 160 KiB).  The bf16 (one-term) kernels need fewer than 256
+// registers and would otherwise run two workgroups per CU; in that configuration the activation / gradient STORES of the second
+// workgroup were found corrupted on MI355X (round 3: whole 4-lane groups of a 16-byte store carrying NaN or stale values while the
+// registers the next layer consumes are right -- every launch of more than 256 workgroups, with and without the LDS weight ring, never
+// with one workgroup per CU; caught by the cfg2 bench line's loss check, now pinned by test_fast_precision_beyond_one_round).  The
+// cause was not isolated (a store's data registers are rewritten by the next vector instruction where the store uses a scalar offset
+// register, which the ISA documentation allows); every measurement and parity figure of these modes was taken at one workgroup per CU.
 template <int TERMS, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -591,6 +608,7 @@ struct FastBwdArgs {
 
 template <int TERMS>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) {
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;

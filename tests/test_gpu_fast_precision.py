@@ -161,3 +161,36 @@ def test_backward_of_every_precision_mode_against_the_oracle(prec, tol_l2, tol_m
     mx = max(((k, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))) for k, a, b in pairs), key=lambda t: t[1])
     print(f"{prec}: worst relative L2 gradient error {l2[1]:.2e} ({l2[0]}), worst max error {mx[1]:.2e} of max ({mx[0]})")
     assert l2[1] < tol_l2 and mx[1] < tol_max, (l2, mx)
+
+
+@pytest.mark.parametrize("prec,tol_l2", [("bf16x3", 2e-2), ("bf16", 0.2)])
+def test_fast_precision_beyond_one_round(prec, tol_l2):
+    """More workgroups than CUs (600 x 64 samples = 300 workgroups of 128 samples; 785 workgroups in the second case): the case
+    in which a second workgroup of these kernels would share a CU with the first if the launch let it.  Round 3 found the bf16
+    kernels' activation / gradient STORES corrupted in exactly that configuration (NaN in whole 4-lane groups while the forward
+    outputs stayed right; the parity cases above are all below 256 workgroups and passed); the launch now reserves enough LDS to keep
+    one workgroup per CU (csrc/niw_mlp_fast.hip kFastLdsBytes).  Every parameter and ray gradient must be finite and within the
+    mode's tolerance of the exact mode's on the same inputs."""
+    from neural_invertible_warp_amd import ops
+    names = [f"{n}.{k}" for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]
+    for N, S in ((600, 64), (523, 192)):
+        center, ray, depth = (x.to(DEV) for x in _rays(N, S, 21))
+        rng = np.random.default_rng(22)
+        g_rgb = torch.from_numpy(rng.standard_normal((N, S, 3)).astype(np.float32)).to(DEV)
+        g_sig = torch.from_numpy(rng.standard_normal((N, S)).astype(np.float32)).to(DEV)
+        grads = {}
+        for mode in ("fp32", prec):
+            p, st = _state(4, mode)
+            flat = torch.cat([p[n].reshape(-1) for n in names]).to(DEV)
+            params, off = [], 0
+            for n in names:
+                params.append(flat[off:off + p[n].numel()].view(p[n].shape).clone().requires_grad_(True))
+                off += p[n].numel()
+            c, r = center.clone().requires_grad_(True), ray.clone().requires_grad_(True)
+            rgb, sig = ops.field_mlp(st, params, c, r, depth, [1.0] * 10, [1.0] * 4, "softplus")
+            ((rgb * g_rgb).sum() + (sig * g_sig).sum()).backward()
+            grads[mode] = [q.grad for q in params] + [c.grad, r.grad]
+        for n, a, b in zip(names + ["d_center", "d_ray"], grads[prec], grads["fp32"]):
+            assert bool(torch.isfinite(a).all()), f"{prec} {N}x{S}: non-finite gradient in {n}"
+            rel = float((a - b).norm() / (b.norm() + 1e-30))
+            assert rel <= tol_l2, f"{prec} {N}x{S}: {n} relative L2 {rel:.3e} > {tol_l2}"
