@@ -3,6 +3,8 @@
 // (GCNHazardRecognizer::createsVALUHazard, "this hazard only exists if the instruction is not using a register in the soffset field").
 // hipcc --offload-arch=gfx950 -O3 tools/store_war_hazard.hip -o tools/store_war_hazard
 // MODE 0: soffset in an SGPR, next instruction overwrites the data;  MODE 1: the same with one s_nop between.
+// Result on MI355X (round 3, two runs): one wave per SIMD 0 / 67,108,864 stores corrupted; waves sharing SIMDs 2,032 and 1,984; with the
+// s_nop 0 / 67,108,864.  Consequences: DESIGN.md section 3.7, tools/check_store_hazard.py (a CPU test).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -46,9 +48,9 @@ void run(unsigned* out, int blocks, int iters, const char* name) {
 }
 
 int main() {
-    unsigned* out; (void)hipMalloc(&out, (size_t)4096 * 256 * 64 * 16);
-    run<0, 1>(out, 256, 64, "soffset SGPR, data overwritten by the next instruction, 256 workgroups");
-    run<0, 2>(out, 4096, 64, "soffset SGPR, data overwritten by the next instruction, 4096 workgroups");
+    unsigned* out; (void)hipMalloc(&out, (size_t)4096 * 256 * 64 * 16);      // 1 GiB: 67 M stores of 16 bytes in every case
+    run<0, 1>(out, 256, 1024, "soffset SGPR, data overwritten by the next instruction, 256 workgroups = one wave per SIMD");
+    run<0, 2>(out, 4096, 64, "soffset SGPR, data overwritten by the next instruction, 4096 workgroups = waves share SIMDs");
     run<1, 2>(out, 4096, 64, "the same with s_nop 0 between");
     return 0;
 }
