@@ -85,10 +85,9 @@ __global__ void pack_fast_kernel(const float* __restrict__ params, unsigned* __r
 constexpr int kRingStages = 4;
 constexpr int kStageBytes = kStageChunks * kChunkBytes;
 constexpr int kFastRingBytes = kRingStages * kStageBytes;             // 64 KiB
-// LDS requested per workgroup: the ring plus 32 KiB that nobody touches -- two such workgroups do not fit a CU's 160 KiB, which pins
-// these kernels to ONE workgroup per CU (why: the comment at mlp_fwd_fast_kernel)
+// LDS requested per workgroup = the ring.  (NIW_FAST_LDS_RESERVE > 16 KiB pins the kernels to one workgroup per CU: a diagnostic.)
 #ifndef NIW_FAST_LDS_RESERVE
-#define NIW_FAST_LDS_RESERVE 32768
+#define NIW_FAST_LDS_RESERVE 0
 #endif
 constexpr int kFastLdsBytes = kFastRingBytes + NIW_FAST_LDS_RESERVE;
 
@@ -332,7 +331,7 @@ struct FastFwdEpilogue {
         const float v1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a1), 0));
         split_pair(v0, v1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
         if (SAVE) {
-            if (rp & 1) buf_store4(keep[0], keep[1], v0, v1, win.rsrc(nb * 32), win.voff4, 8 * (rp >> 1) * win.pitch4);
+            if (rp & 1) buf_store4(keep[0], keep[1], v0, v1, win.rsrc(nb * 32 + 8 * (rp >> 1)), win.voff4, 0);
             else { keep[0] = v0; keep[1] = v1; }
             mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v0) + 0x7fffffffu, 31);
             mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v1) + 0x7fffffffu, 31);
@@ -365,14 +364,15 @@ __device__ __forceinline__ float density_act_fast(float x, int kind) {
 
 static_assert((8 * 16 / kStageChunks) % kRingStages == 0, "a 256 -> 256 layer is a whole number of ring turns: the layers of one rolled loop share their ring phase");
 
-// ONE workgroup per CU, like the exact-fp32 kernels -- enforced by the launch's LDS request (kFastLdsBytes: the 64 KiB ring plus a
-// reserve that leaves no room for a second workgroup's 96 KiB in the CU's 160 KiB).  The bf16 (one-term) kernels need fewer than 256
-// registers and would otherwise run two workgroups per CU; in that configuration the activation / gradient STORES of the second
-// workgroup were found corrupted on MI355X (round 3: whole 4-lane groups of a 16-byte store carrying NaN or stale values while the
-// registers the next layer consumes are right -- every launch of more than 256 workgroups, with and without the LDS weight ring, never
-// with one workgroup per CU; caught by the cfg2 bench line's loss check, now pinned by test_fast_precision_beyond_one_round).  The
-// cause was not isolated (a store's data registers are rewritten by the next vector instruction where the store uses a scalar offset
-// register, which the ISA documentation allows); every measurement and parity figure of these modes was taken at one workgroup per CU.
+// Store-data hazard (round 3, tools/store_war_hazard.hip).  The bf16 (one-term) kernels need fewer than 256
+// registers, so two of their workgroups share a CU -- and on gfx950 a 16-byte buffer store with an SGPR soffset that is followed AT ONCE by
+// a vector write of its data registers stores the new value when waves share a SIMD.  LLVM inserts the wait state only for stores whose
+// soffset is an immediate, and hipcc did schedule that pair in these epilogues: every launch of more than 256 workgroups stored corrupted
+// activations / gradients from its second workgroups (whole 4-lane groups carrying NaN or the next epilogue step's values) while the
+// registers the next layer consumes -- rgb, sigma, the loss of that step -- were right.  All epilogue stores of this file therefore give
+// the row offset to the DESCRIPTOR (scalar ALU) and use soffset 0: the compiler then sees the hazard and pads it.
+// tools/check_store_hazard.py (a CPU test) scans the assembly of every kernel for the pair; test_fast_precision_beyond_one_round runs both
+// modes beyond one round of workgroups.
 template <int TERMS, bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -557,7 +557,7 @@ struct FastMaskEpilogue {
     __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
         const float g0 = relu_keep(mk, nb, 2 * rp, a0, zero), g1 = relu_keep(mk, nb, 2 * rp + 1, a1, zero);
         split_pair(g0, g1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
-        if (rp & 1) buf_store4(keep[0], keep[1], g0, g1, grad.rsrc(nb * 32), grad.voff4, 8 * (rp >> 1) * grad.pitch4);
+        if (rp & 1) buf_store4(keep[0], keep[1], g0, g1, grad.rsrc(nb * 32 + 8 * (rp >> 1)), grad.voff4, 0);
         else { keep[0] = g0; keep[1] = g1; }
     }
 };
@@ -571,7 +571,7 @@ struct FastStashEpilogue {
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
     }
     __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
-        if (rp & 1) { if (store) buf_store4(keep[0], keep[1], a0, a1, win.rsrc(nb * 32), win.voff4, 8 * (rp >> 1) * win.pitch4); }
+        if (rp & 1) { if (store) buf_store4(keep[0], keep[1], a0, a1, win.rsrc(nb * 32 + 8 * (rp >> 1)), win.voff4, 0); }
         else { keep[0] = a0; keep[1] = a1; }
     }
 };

@@ -1,8 +1,6 @@
 """CPU: no kernel that can have a second wave on its SIMD contains the gfx950 store-data hazard (tools/check_store_hazard.py,
-tools/store_war_hazard.hip), and the fast-precision kernels -- which contain the instruction pair -- are
-launched with an LDS request that admits one workgroup per CU."""
+tools/store_war_hazard.hip)."""
 import os
-import re
 
 import pytest
 
@@ -16,13 +14,3 @@ def test_no_unsafe_store_followed_by_a_vector_write_of_its_data():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
-
-
-def test_fast_kernels_request_more_than_half_of_the_lds():
-    src = open(os.path.join(ROOT, "neural_invertible_warp_amd", "csrc", "niw_mlp_fast.hip")).read()
-    reserve = int(re.search(r"#define NIW_FAST_LDS_RESERVE (\d+)", src).group(1))
-    stages = int(re.search(r"constexpr int kRingStages = (\d+);", src).group(1))
-    assert re.search(r"constexpr int kFastLdsBytes = kFastRingBytes \+ NIW_FAST_LDS_RESERVE;", src)
-    assert re.search(r"constexpr int kStageBytes = kStageChunks \* kChunkBytes;", src)
-    ring = stages * 8 * 2048                                   # kStageChunks * kChunkBytes (niw_mlp_fast.h)
-    assert 2 * (ring + reserve) > 160 * 1024, "two workgroups of the fast kernels would fit a CU's 160 KiB of LDS"

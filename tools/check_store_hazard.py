@@ -16,8 +16,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "neural_invertible_warp_amd", "csrc")
-# kernels launched with an LDS request that admits ONE workgroup per CU (csrc/niw_mlp_fast.hip kFastLdsBytes = 96 KiB of 160)
-ONE_WORKGROUP_PER_CU_BY_LDS = ("mlp_fwd_fast_kernel", "mlp_bwd_dx_fast_kernel")
+# kernels launched with an LDS request that admits ONE workgroup per CU, if any (none at present: the fast-precision kernels, which had the
+# pair, now pass their row offsets through the descriptor and store with soffset 0, which the compiler pads)
+ONE_WORKGROUP_PER_CU_BY_LDS = ()
 
 
 def compile_to_asm(src, out):
