@@ -67,3 +67,26 @@ def test_photometric_share_kernel_equals_the_slice_of_the_whole_batch():
         assert torch.allclose(piece.grad[0], rgb.grad.reshape(B * R, 3)[lo:hi], rtol=0, atol=1e-9)
         parts, lo = parts + float(l.detach()), hi
     assert abs(parts - float(whole.detach())) < 1e-6
+
+
+def test_bench_line_through_a_live_rccl_group_eager_and_captured():
+    """bench.py --force-dist: a ONE-rank RCCL process group (everything a one-GPU box can exercise of the N > 1 path on hardware): the
+    rank check (an all-reduce of ones through RCCL), the flat gradient all-reduce, and -- with --hip-graph on -- capture and replay of
+    the iteration while the communicator is live.  Both runs must print a line with ranks_seen 1, backend nccl and the same loss."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    losses = {}
+    for mode in ("off", "on"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29631 + (mode == "on")))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg3", "--lean", "--force-dist", "--hip-graph", mode,
+                            "--steps", "4", "--warmup", "3", "--kernel-steps", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["ranks_seen"] == 1 and line["backend"] == "nccl" and line["hip_graph"] == (mode == "on")
+        losses[mode] = line["loss"]
+    assert abs(losses["on"] - losses["off"]) <= 1e-6 * abs(losses["off"])
