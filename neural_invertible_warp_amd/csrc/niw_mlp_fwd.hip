@@ -251,53 +251,46 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
 
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
-    float act[128], nxt[128];
-    auto advance = [&]() {
-#pragma unroll
-        for (int i = 0; i < 128; ++i) act[i] = nxt[i];
-    };
+    // The 128 activation registers of a layer's input and of its output alternate between two arrays (xa -> xb -> xa ...) instead of
+    // being copied back after every layer (128 vector moves each, paid in matrix-pipe time: tools/mfma_valu_contention.hip):
+    //   0: enc -> xa | 1: xa -> xb | 2: xb -> xa | 3: xa -> xb | 4: xb (+enc) -> xa | 5: xa -> xb | 6: xb -> xa | 7: xa -> xb | 8: xb (+venc) -> hr
+    // The loop below runs (xa -> xb, xb -> xa) three times; the second "xb -> xa" is layer 4 with its skip connection.
+    float xa[128], xb[128];
 
     // every layer leaves the next one its first weight fragments and its first bias fragment (niw_mlp_device.h LayerCarry)
     LayerCarry carry;
     constexpr int kLayerBytes = 32 * 8 * 1024;       // one 256 -> 256 layer of the packed image
+    auto w_bytes = [&](int l) {                       // byte offset of layer l's fragments (l = 1..8), scalar arithmetic
+        return l <= 3 ? 4 * fwd_pack_off(1) + (l - 1) * kLayerBytes : l == 4 ? 4 * fwd_pack_off(4)
+             : l <= 6 ? 4 * fwd_pack_off(5) + (l - 5) * kLayerBytes : l == 7 ? 4 * fwd_pack_off(7) : 4 * fwd_pack_off(8);
+    };
+    auto b_bytes = [&](int l) { return 4 * (bias_pack_off(0) + l * 256); };      // 8 row blocks x 32 floats per layer up to layer 8
+    static_assert(bias_pack_off(7) == bias_pack_off(0) + 7 * 256 && bias_pack_off(8) == bias_pack_off(0) + 8 * 256, "uniform bias stride");
+    auto next_of = [&](int l) { return NextLayer{w_bytes(l + 1), (l + 1 == 8 ? 4 : 8) * 1024, b_bytes(l + 1), hoff}; };
+    auto plain = [&](int l, const float (&in)[128], float (&out)[128]) {          // layers 1, 2, 3, 5, 6
+        FwdEpilogue<8, true, SAVE> ep{pw, b_bytes(l), hoff, out, in, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
+        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + w_bytes(l) / 16, in, none, ep, &carry, next_of(l));
+    };
     // ---- layer 0: 63 -> 256
     {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(0), hoff, nxt, act, window(save_h(1)), 0.f, mask_rec(0), lane};
-        stream_layer<8, 0, 8, 8, decltype(ep), false, true>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep, &carry,
-                                                             NextLayer{4 * fwd_pack_off(1), 8 * 1024, 4 * bias_pack_off(1), hoff});
-        advance();
+        FwdEpilogue<8, true, SAVE> ep{pw, b_bytes(0), hoff, xa, xb, window(save_h(1)), 0.f, mask_rec(0), lane};
+        stream_layer<8, 0, 8, 8, decltype(ep), false, true>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep, &carry, next_of(0));
     }
-    // ---- layers 1..3
 #pragma unroll 1
-    for (int l = 1; l <= 3; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(1) + (l - 1) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
-        const NextLayer nx = l < 3 ? NextLayer{4 * fwd_pack_off(1) + l * kLayerBytes, 8 * 1024, 4 * (bias_pack_off(1) + l * 256), hoff}
-                                   : NextLayer{4 * fwd_pack_off(4), 8 * 1024, 4 * bias_pack_off(4), hoff};
-        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), act, none, ep, &carry, nx);
-        advance();
-    }
-    // ---- layer 4: cat[feat, points_enc] (319) -> 256
-    {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * bias_pack_off(4), hoff, nxt, act, window(save_h(5)), 0.f, mask_rec(4), lane};
-        stream_layer<32, 8, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(4) / 4, act, enc, ep, &carry,
-                                                             NextLayer{4 * fwd_pack_off(5), 8 * 1024, 4 * bias_pack_off(5), hoff});
-        advance();
-    }
-    // ---- layers 5, 6
-#pragma unroll 1
-    for (int l = 5; l <= 6; ++l) {
-        FwdEpilogue<8, true, SAVE> ep{pw, 4 * (bias_pack_off(5) + (l - 5) * 256), hoff, nxt, act, window(save_h(l + 1)), 0.f, mask_rec(l), lane};
-        const NextLayer nx = l < 6 ? NextLayer{4 * fwd_pack_off(5) + kLayerBytes, 8 * 1024, 4 * (bias_pack_off(5) + 256), hoff}
-                                   : NextLayer{4 * fwd_pack_off(7), 8 * 1024, 4 * bias_pack_off(7), hoff};
-        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), act, none, ep, &carry, nx);
-        advance();
+    for (int k = 0; k < 3; ++k) {
+        plain(2 * k + 1, xa, xb);                    // layers 1, 3, 5
+        if (k != 1) {
+            plain(2 * k + 2, xb, xa);                // layers 2, 6
+        } else {
+            // ---- layer 4: cat[feat, points_enc] (319) -> 256
+            FwdEpilogue<8, true, SAVE> ep{pw, b_bytes(4), hoff, xa, xb, window(save_h(5)), 0.f, mask_rec(4), lane};
+            stream_layer<32, 8, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(4) / 4, xb, enc, ep, &carry, next_of(4));
+        }
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
-        FwdEpilogue<8, true, SAVE, 1> ep{pw, 4 * bias_pack_off(7), hoff, nxt, act, window(kSaveFeat), 0.f, mask_rec(7), lane};
-        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(7) / 4, act, none, ep, &carry,
-                                                             NextLayer{4 * fwd_pack_off(8), 4 * 1024, 4 * bias_pack_off(8), hoff});
-        advance();
+        FwdEpilogue<8, true, SAVE, 1> ep{pw, b_bytes(7), hoff, xb, xa, window(kSaveFeat), 0.f, mask_rec(7), lane};
+        stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(7) / 4, xa, none, ep, &carry, next_of(7));
         // density row: the two lane halves hold complementary input slots
         float sig_raw = ep.sig_raw + __shfl_xor(ep.sig_raw, 32) + buf_load1(pw.rsrc, 0, 4 * kHeadBiasOff);
         if (a.noise != nullptr) sig_raw += a.noise[mc];
@@ -310,8 +303,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- colour layer 1 (128 -> 3, sigmoid) rides on layer 0's epilogue: three FMAs per hidden value as it is produced
     float hr[64];
     {
-        FwdEpilogue<4, true, SAVE, 2> ep{pw, 4 * bias_pack_off(8), hoff, hr, act, window(kSaveHr), 0.f, mask_rec(8), lane};
-        stream_layer<32, 4, 4, 4, decltype(ep), true, false>(pw, wp + fwd_pack_off(8) / 4, act, venc, ep, &carry);
+        FwdEpilogue<4, true, SAVE, 2> ep{pw, b_bytes(8), hoff, hr, xb, window(kSaveHr), 0.f, mask_rec(8), lane};
+        stream_layer<32, 4, 4, 4, decltype(ep), true, false>(pw, wp + fwd_pack_off(8) / 4, xb, venc, ep, &carry);
         float o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = ep.col[c] + __shfl_xor(ep.col[c], 32) + buf_load1(pw.rsrc, 0, 4 * (kHeadBiasOff + 1 + c));
