@@ -70,7 +70,7 @@ def psnr_trajectories(dev, steps=25, B=3, H=12, W=16, R=16, S=32, seed=7, precis
     return psnr_gpu, psnr_cpu
 
 
-def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4, seed=0, draw_seed=0, oracle=True, log_every=50):
+def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4, seed=0, draw_seed=0, oracle=True, log_every=50, precision="fp32"):
     """Long-horizon parity on the demo scene (tools/teacher_student_demo.py: analytic density blobs rendered from perturbed poses,
     training starts from identity poses): `steps` chained iterations of barf_inn_llff WITH the alignment term on
       * the HIP engine (engine.INNTrainer: fused kernels, niw_adam_step), and
@@ -89,6 +89,7 @@ def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4
     opt.max_iter = steps
     opt.nerf.sample_intvs, opt.nerf.rand_rays = S, R * B
     opt.inn.real_nvp.max_pe_iter = steps // 2
+    opt.arch.precision = precision                   # the HIP engine's field-MLP arithmetic (include/niw.h niw_precision); the oracle stays fp32
     gen = torch.Generator().manual_seed(seed)
     pose_GT = camera.lie.se3_to_SE3(torch.randn(B, 6, generator=gen) * torch.tensor([0.06, 0.06, 0.03, 0.15, 0.15, 0.05])).to(dev)
     intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(B, 1, 1).to(dev)

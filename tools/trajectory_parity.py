@@ -21,11 +21,12 @@ if __name__ == "__main__":
     ap.add_argument("--size", type=int, nargs=2, default=[48, 64], help="image size H W (300 400: the BASELINE image scale)")
     ap.add_argument("--rays", type=int, default=256, help="rays per view and step")
     ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="field-MLP arithmetic of the HIP engine (the oracle stays fp32)")
     ap.add_argument("--out", default="gpurun_out/trajectory_parity.json")
     a = ap.parse_args()
     from oracle import parity
     t0 = time.perf_counter()
-    kw = dict(views=a.views, size=tuple(a.size), R=a.rays, S=a.samples)
+    kw = dict(views=a.views, size=tuple(a.size), R=a.rays, S=a.samples, precision=a.precision)
     pair = parity.long_trajectories("cuda:0", steps=a.steps, draw_seed=0, oracle=True, **kw)
     print(f"HIP + oracle, {a.steps} steps: {time.perf_counter() - t0:.1f} s", flush=True)
     spread = [parity.long_trajectories("cuda:0", steps=a.steps, draw_seed=s, oracle=False, **kw)["hip"] for s in range(1, 1 + a.spread_runs)]
@@ -38,7 +39,7 @@ if __name__ == "__main__":
                          psnr_draw_spread=round(max(ps) - min(ps), 3), rel_rot_hip=round(pair["hip"]["rel_rot"][i], 3),
                          rel_rot_oracle=round(pair["oracle"]["rel_rot"][i], 3), rel_rot_draw_spread=round(max(rr) - min(rr), 3)))
     tail = rows[len(rows) // 2:]
-    summary = dict(steps=a.steps, shape=f"{a.views} views x {a.rays} rays x {a.samples} samples on {a.size[0]}x{a.size[1]} images", max_abs_psnr_diff_db=round(max(abs(r["psnr_hip"] - r["psnr_oracle"]) for r in rows), 3),
+    summary = dict(steps=a.steps, precision=a.precision, shape=f"{a.views} views x {a.rays} rays x {a.samples} samples on {a.size[0]}x{a.size[1]} images", max_abs_psnr_diff_db=round(max(abs(r["psnr_hip"] - r["psnr_oracle"]) for r in rows), 3),
                    max_psnr_draw_spread_db=round(max(r["psnr_draw_spread"] for r in rows), 3),
                    second_half_mean_abs_psnr_diff_db=round(sum(abs(r["psnr_hip"] - r["psnr_oracle"]) for r in tail) / len(tail), 3),
                    second_half_mean_psnr_draw_spread_db=round(sum(r["psnr_draw_spread"] for r in tail) / len(tail), 3),
