@@ -59,6 +59,9 @@ enum niw_density_activ { NIW_ACT_RELU = 0, NIW_ACT_SOFTPLUS = 1 };
  *   NIW_PREC_BF16X3  opt-in: every operand carried as two bf16 planes (16 significand bits), a product formed as
  *                    hi*hi + hi*mid + mid*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (3/16 of the matrix-pipe time).
  *   NIW_PREC_BF16    opt-in: the leading bf16 plane only (1/16 of the matrix-pipe time; SURVEY 8(c)'s bf16 tolerance class).
+ *                    Its three kernels keep the saved activations / gradients (`save`, `gradws`) as bf16 quad rows inside the same
+ *                    caller-provided buffers (half the bytes; the layout is private to the mode): forward, dX and dW of one
+ *                    step must be called with the SAME precision.
  * A packed-weight image belongs to ONE precision class: fp32 images (niw_mlp_pack_weights*) for NIW_PREC_FP32, the split image of
  * niw_mlp_pack_weights_prec for the two bf16 modes (one image serves both). */
 enum niw_precision { NIW_PREC_FP32 = 0, NIW_PREC_BF16X3 = 1, NIW_PREC_BF16 = 2 };

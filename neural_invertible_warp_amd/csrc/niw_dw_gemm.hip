@@ -395,6 +395,156 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_fast_kernel(GemmBatch ba
     }
 }
 
+// The one-term (bf16) product on bf16 WORKSPACES (niw_mlp_fast.hip kHalfWorkspace): the operands are quad-row images of bf16 -- four rows
+// of one sample in 8 bytes, quad q of sample m at (q * Mpad + m) * 8 -- i.e. already the plane this mode multiplies.  A 16-byte load
+// is one quad of TWO neighbouring samples: transposed in registers (four v_perm_b32) it is the four LDS dwords (row, sample pair) of
+// the same [row][64 B] swizzled image the fp32-workspace loader builds; no split, no lane exchange, half the bytes from HBM -- which is
+// what this kernel is bound by.  A workgroup load covers NT / 16 quads (128 rows for 512 threads); operands whose tile is not a
+// multiple of that (64 or 320 rows) leave part of a load idle.  Bias sums: fp32 sums of the bf16 values (the fp32-workspace form sums
+// the unrounded values).
+template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF>
+__global__ __launch_bounds__(64 * WN * WK) void dw_gemm_half_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
+                                                                    float* __restrict__ partial) {
+    const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
+    const int bias_side = batch.bias_side[blockIdx.y];
+    constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
+    constexpr int ROWS = TN + TK;
+    constexpr int QPL = NT / 16;                            // quads per workgroup load
+    constexpr int LA = (TN / 4 + QPL - 1) / QPL, LB = (TK / 4 + QPL - 1) / QPL, LOADS = LA + LB;
+    constexpr int BUF_BYTES = ROWS * 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int i = lane & 31, h = lane >> 5;
+    const int step0 = blockIdx.x * steps_per_wg;
+    bool live[NBW][KBW];
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y) live[x][y] = !SKIP || ((wn * NBW + x) * 32 < opA.rows && (wk * KBW + y) * 32 < opB.rows);
+    const int nsteps = min(steps_per_wg, steps_total - step0);
+    // bytes between consecutive quads of an operand: row_stride samples of 8 bytes; descriptors end after the last valid quad
+    const int qsA = (int)opA.row_stride * 8, qsB = (int)opB.row_stride * 8;
+    const int cutA = (min(opA.rows, TN) + 3) / 4, cutB = (min(opB.rows, TK) + 3) / 4;
+    const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, cutA * qsA, 0x00020000);
+    const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, cutB * qsB, 0x00020000);
+    const int quad = tid >> 4, w = tid & 15;                 // this thread's quad within a load, its pair of samples within the step
+    const int voffA = quad * qsA + w * 16, voffB = quad * qsB + w * 16;
+    constexpr int STEP_BYTES = 256;                          // 32 samples of 8 bytes
+
+    f32x16 acc[NBW][KBW];
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    float bsum[LOADS][4];
+#pragma unroll
+    for (int k = 0; k < LOADS; ++k)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bsum[k][jj] = 0.f;
+
+    u32x4_t stage[PF][LOADS];
+    auto gload = [&](int step, int slot) {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const bool isA = k < LA;
+            const int q0 = (isA ? k : k - LA) * QPL;         // first quad of this load
+            stage[slot][k] = isA ? __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, step * STEP_BYTES + q0 * qsA, 0))
+                                 : __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, step * STEP_BYTES + q0 * qsB, 0));
+        }
+    };
+    auto lds_off = [&](int row, int ww) { return row * 64 + ((((ww >> 2) ^ (row >> 2)) & 3) << 4) + ((ww & 3) << 2); };
+    auto lstore = [&](int buf, int slot) {
+        char* base = ldsb + buf * BUF_BYTES;
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const bool isA = k < LA;
+            const int row0 = ((isA ? k : k - LA) * QPL + quad) * 4;                  // row inside the operand's tile
+            if (row0 >= (isA ? TN : TK)) continue;                                    // the idle part of a load that overhangs the tile
+            const u32x4_t v = stage[slot][k];                 // {rows 0,1 | rows 2,3} of sample 2w, then of sample 2w + 1
+            unsigned d[4];
+            d[0] = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);
+            d[1] = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);
+            d[2] = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);
+            d[3] = __builtin_amdgcn_perm(v[3], v[1], 0x07060302u);
+            const int row = (isA ? 0 : TN) + row0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<unsigned*>(base + lds_off(row + jj, w)) = d[jj];
+            if ((bias_side == 1 && isA) || (bias_side == 2 && !isA)) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bsum[k][jj] += __builtin_bit_cast(float, d[jj] << 16) + __builtin_bit_cast(float, d[jj] & 0xffff0000u);
+            }
+        }
+    };
+    auto step_body = [&](int s, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int buf = s & 1;
+        if (s + PF < nsteps) gload(step0 + s + PF, slot);
+        const char* base = ldsb + buf * BUF_BYTES;
+        auto frag = [&](int row, int ks) {
+            return *reinterpret_cast<const u32x4_t*>(base + row * 64 + ((((2 * ks + h) ^ (row >> 2)) & 3) << 4));
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4_t af[NBW];
+#pragma unroll
+            for (int x = 0; x < NBW; ++x) af[x] = frag((wn * NBW + x) * 32 + i, ks);
+#pragma unroll
+            for (int y = 0; y < KBW; ++y) {
+                const u32x4_t bf = frag(TN + (wk * KBW + y) * 32 + i, ks);
+#pragma unroll
+                for (int x = 0; x < NBW; ++x)
+                    if (live[x][y]) acc[x][y] = mfma_bf16(af[x], bf, acc[x][y]);
+            }
+            if (ks == 0 && s + 1 < nsteps) lstore(buf ^ 1, (slot + 1) % PF);
+        }
+        __syncthreads();
+    };
+
+    if (nsteps > 0) {
+        gload(step0, 0);
+        lstore(0, 0);
+    }
+    if (PF >= 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
+    if (PF >= 3 && nsteps > 2) gload(step0 + 2, 2 % PF);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += PF) {
+        step_body(s, std::integral_constant<int, 0>{});
+        if (PF >= 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF >= 3 && s + 2 < nsteps) step_body(s + 2, std::integral_constant<int, 2 % PF>{});
+    }
+    float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
+#pragma unroll
+    for (int x = 0; x < NBW; ++x)
+#pragma unroll
+        for (int y = 0; y < KBW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[((wn * NBW + x) * 32 + acc_row(r, h)) * TK + (wk * KBW + y) * 32 + i] = acc[x][y][r];
+    // bias sums: fold the 16 sample pairs of a quad's lanes (fixed xor tree), one write per row
+    if (tid < 256) out[TN * TK + tid] = 0.f;
+    __syncthreads();
+    if (bias_side) {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const bool isA = k < LA;
+            if ((bias_side == 1 && isA) || (bias_side == 2 && !isA)) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float v = bsum[k][jj];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    const int row = ((isA ? k : k - LA) * QPL + quad) * 4 + jj;
+                    if (w == 0 && row < 256 && row < (isA ? TN : TK)) out[TN * TK + row] = v;
+                }
+            }
+        }
+    }
+}
+
 // Deterministic reduction of the partial tiles + scatter into the flat parameter gradient: ONE launch for all pieces of a
 // network (blockIdx.y = piece).
 struct ReduceArgs {
@@ -455,10 +605,12 @@ struct Piece {
     int n_off, k_off, transposed, bias, wide;   // wide: 256x256 tile, else 256x64
 };
 
+// TERMS: 0 exact fp32; 3 bf16x3 (fp32 workspaces); 1 bf16 on bf16 workspaces (dw_gemm_half_kernel); -1 bf16 on fp32 workspaces (diagnostic)
 template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD, int TERMS>
 constexpr auto fast_or_exact() {
     if constexpr (TERMS == 0) return dw_gemm_kernel<WN, WK, NBW, KBW, SKIP, PF, QUAD>;
-    else return dw_gemm_fast_kernel<WN, WK, NBW, KBW, SKIP, PF, TERMS>;
+    else if constexpr (TERMS == 1) return dw_gemm_half_kernel<WN, WK, NBW, KBW, SKIP, PF>;
+    else return dw_gemm_fast_kernel<WN, WK, NBW, KBW, SKIP, PF, (TERMS < 0 ? 1 : TERMS)>;
 }
 
 template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD, int TERMS = 0>
@@ -590,8 +742,10 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         for (int b = 0; b < g.n; ++b) {
             const Piece& p = g.p[b];
             // workspaces are quad-row images of the feature-major [row][Mpad] matrix (every operand starts on a multiple of 4 rows)
-            gb.A[b] = NiwGemmOperand{(p.transposed ? save : gradws) + (long long)p.a_row * mpad, p.a_rows, 0, mpad};
-            gb.B[b] = NiwGemmOperand{(p.transposed ? gradws : save) + (long long)p.b_row * mpad, p.b_rows, 0, mpad};
+            // (bf16 mode: bf16 quad-row images, rows half as far apart -- niw_mlp_fast.hip kHalfWorkspace)
+            const long long row_floats = precision == NIW_PREC_BF16 ? mpad / 2 : mpad;
+            gb.A[b] = NiwGemmOperand{(p.transposed ? save : gradws) + (long long)p.a_row * row_floats, p.a_rows, 0, mpad};
+            gb.B[b] = NiwGemmOperand{(p.transposed ? gradws : save) + (long long)p.b_row * row_floats, p.b_rows, 0, mpad};
             gb.bias_side[b] = p.bias ? (p.transposed ? 2 : 1) : 0;
         }
         int nsplit = 0;

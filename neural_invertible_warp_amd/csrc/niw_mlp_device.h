@@ -47,6 +47,11 @@ __device__ __forceinline__ void buf_store4(float v0, float v1, float v2, float v
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v0, v1, v2, v3}), r, voff, soff, NIW_STORE_AUX);
 }
 
+__device__ __forceinline__ void buf_store2(unsigned d0, unsigned d1, rsrc_t r, int voff, int soff) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{d0, d1}, r, voff, soff, NIW_STORE_AUX);
+}
+
 // The packed-weight image of one network (niw_mlp_pack_weights) as seen by a wave.
 struct PackedWeights {
     rsrc_t rsrc;

@@ -57,14 +57,24 @@ __device__ __forceinline__ void encode_slots(const float (&p)[3], const float* _
 
 // d(point)/d(unit dir) from the gradient of the encoding slots and the saved encoding values:
 // d/dx [w sin(f x)] = f * (w cos(f x)),  d/dx [w cos(f x)] = -f * (w sin(f x)).
-template <int L, int NQ>
+// HALF: the saved encoding is a bf16 quad-row image (niw_mlp_fast.hip kHalfWorkspace): 8 bytes per (quad, sample), rows half as far apart;
+// enc_row0 then points at the image's first byte for row 0 of the encoding.
+template <int L, int NQ, bool HALF = false>
 __device__ __forceinline__ void enc_backward(const float (&de)[4 * NQ], const float* __restrict__ enc_row0, long long mpad,
                                              unsigned qoff, int h, float (&dp)[3]) {
     dp[0] = dp[1] = dp[2] = 0.f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         // rows 8q + 4h + {0..3} of this sample: one quad of the saved encoding (qoff = h*Mpad + m)
-        const f32x4 e = reinterpret_cast<const f32x4*>(enc_row0 + (long long)(8 * q) * mpad)[qoff];
+        f32x4 e;
+        if (HALF) {
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t w = reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(enc_row0) + (long long)(8 * q) * mpad * 2)[qoff];
+            e = f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u), __builtin_bit_cast(float, w[1] << 16),
+                      __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+        } else {
+            e = reinterpret_cast<const f32x4*>(enc_row0 + (long long)(8 * q) * mpad)[qoff];
+        }
         if (q == 0) {
             // half 0: raw coordinates; half 1: pairs 0 and 1
 #pragma unroll

@@ -294,11 +294,23 @@ __device__ __forceinline__ void split_regs(const float (&v)[NV], unsigned (&plan
     for (int r = 0; r < NV / 2; ++r) split_pair(v[2 * r], v[2 * r + 1], planes[0][r], planes[1][r]);
 }
 
+// bf16 workspaces (round 3).  In the one-term mode (NIW_PREC_BF16) the dW GEMMs multiply the LEADING bf16 plane of every saved activation
+// and gradient and nothing else -- so that plane is what the forward and the dX chain store: the quad-row images of `save` / `gradws`
+// hold four bf16 per (quad, sample), 8 bytes where the fp32 image has 16 (same quad numbering, half the pitch: quad q of sample m at
+// (q * Mpad + m) * 8 bytes; the packed pairs are the very dwords the next layer consumes as its operand plane).  Rows that are not MFMA
+// operands keep their fp32 places: the raw-density row and the mask records of `save`, the stash rows of `gradws` -- they lie behind
+// the (now half as long) quad regions.  The kernels of the mode agree on this among themselves; the caller's buffers are unchanged
+// (sized for fp32).  It halves the bytes all three kernels of the mode are bound by.  bf16x3 keeps fp32 workspaces (two planes = the
+// same bytes).  Parameter gradients are bit-identical to the fp32-workspace form of the mode (the dW pass rounded to the same planes
+// on its way into LDS); the ray gradients see the saved encodings rounded to bf16.
+template <int TERMS>
+constexpr bool kHalfWorkspace = TERMS == 1;
+
 // Forward epilogue: the bias is in the accumulator already (acc_init); ReLU; planes of the next layer's operand; training: the fp32
 // activation into the quad-row workspace and the ReLU sign bits into the wave's mask record -- byte for byte what the exact-fp32
 // forward leaves behind, so either backward can consume it.
 // KIND 0: hidden layer; 1: layer 7 (row block 8, register 0 of lane half 0 = raw density); 2: colour output (no ReLU, no planes).
-template <int NBOUT, bool SAVE, int KIND>
+template <int NBOUT, bool SAVE, int KIND, bool HALF = false>
 struct FastFwdEpilogue {
     const PackedWeights& pw;
     int bias_bytes, hoff;                // packed bias of the layer ([row block][half][16] floats); h * 64
@@ -331,8 +343,13 @@ struct FastFwdEpilogue {
         const float v1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a1), 0));
         split_pair(v0, v1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
         if (SAVE) {
-            if (rp & 1) buf_store4(keep[0], keep[1], v0, v1, win.rsrc(nb * 32 + 8 * (rp >> 1)), win.voff4, 0);
-            else { keep[0] = v0; keep[1] = v1; }
+            if (HALF) {                  // the operand plane itself: rows 4q .. 4q+3 = the pairs 2q, 2q+1
+                if (rp & 1) buf_store2(out[0][nb * 8 + rp - 1], out[0][nb * 8 + rp], win.rsrc(nb * 32 + 8 * (rp >> 1)), win.voff4, 0);
+            } else if (rp & 1) {
+                buf_store4(keep[0], keep[1], v0, v1, win.rsrc(nb * 32 + 8 * (rp >> 1)), win.voff4, 0);
+            } else {
+                keep[0] = v0; keep[1] = v1;
+            }
             mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v0) + 0x7fffffffu, 31);
             mbits[nb >> 1] = __builtin_amdgcn_alignbit(mbits[nb >> 1], __builtin_bit_cast(unsigned, v1) + 0x7fffffffu, 31);
             if (nb == NBOUT - 1 && rp == 7)
@@ -407,10 +424,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     const WeightStream<TERMS> ws{pw.rsrc, wlds, __builtin_amdgcn_readfirstlane(wave), lane * 16, 0, kFastFwdChunks / kStageChunks};
     if (kSharedWeights<TERMS>) ws.start();
     constexpr int G = kStageChunks;
-    const int pitch4 = (int)(a.Mpad * 4), voff4 = (int)(((long long)h * a.Mpad + m) * 16), hoff = h * 64;
+    constexpr bool HALF = kHalfWorkspace<TERMS>;          // bf16 quad-row images (see above): half the pitch, 8 bytes per (quad, sample)
+    const int pitch4 = (int)(a.Mpad * (HALF ? 2 : 4)), voff4 = (int)(((long long)h * a.Mpad + m) * (HALF ? 8 : 16)), hoff = h * 64;
     const unsigned mpad32 = (unsigned)a.Mpad;
-    auto row_off = [&](int r) { return (long long)((unsigned long long)(unsigned)r * (unsigned long long)mpad32); };
-    auto window = [&](int r) { return RowWindow{SAVE ? a.save + row_off(r) : nullptr, pitch4, voff4}; };
+    auto row_off = [&](int r) { return (long long)((unsigned long long)(unsigned)r * (unsigned long long)mpad32); };       // floats (fp32 places)
+    auto window = [&](int r) {                             // quad rows of the activation image
+        return RowWindow{SAVE ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.save) + row_off(r) * (HALF ? 2 : 4)) : nullptr, pitch4, voff4};
+    };
     const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     auto mask_rec = [&](int i) {
         return SAVE ? reinterpret_cast<const char*>(a.save + row_off(kSaveMask)) + (wave_id * kMaskRecords + i) * kMaskRecBytes : nullptr;
@@ -418,9 +438,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     if (SAVE) {
         const RowWindow we = window(kSaveEnc), wv = window(kSaveVenc);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) buf_store4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3], we.rsrc(0), voff4, 8 * q * pitch4);
+        for (int q = 0; q < 8; ++q) {
+            if (HALF) buf_store2(pack_bf16(enc[4 * q], enc[4 * q + 1]), pack_bf16(enc[4 * q + 2], enc[4 * q + 3]), we.rsrc(8 * q), voff4, 0);
+            else buf_store4(enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3], we.rsrc(8 * q), voff4, 0);
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) buf_store4(venc[4 * q], venc[4 * q + 1], venc[4 * q + 2], venc[4 * q + 3], wv.rsrc(0), voff4, 8 * q * pitch4);
+        for (int q = 0; q < 4; ++q) {
+            if (HALF) buf_store2(pack_bf16(venc[4 * q], venc[4 * q + 1]), pack_bf16(venc[4 * q + 2], venc[4 * q + 3]), wv.rsrc(8 * q), voff4, 0);
+            else buf_store4(venc[4 * q], venc[4 * q + 1], venc[4 * q + 2], venc[4 * q + 3], wv.rsrc(8 * q), voff4, 0);
+        }
     }
     unsigned encp[2][16], vencp[2][8];
     split_regs<32>(enc, encp);
@@ -435,33 +461,33 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     };
     // ---- layer 0: 63 -> 256
     {
-        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(0), hoff, nxt, window(save_h(1)), mask_rec(0), lane};
+        FastFwdEpilogue<8, SAVE, 0, HALF> ep{pw, fast_bias_off(0), hoff, nxt, window(save_h(1)), mask_rec(0), lane};
         stream_layer_bf<4, 0, 8, TERMS, (fast_fwd_chunk(0) / G) % kRingStages>(ws, fast_fwd_chunk(0) / G, encp, none, ep);
         advance();
     }
     // ---- layers 1..3
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(1) + (l - 1) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
+        FastFwdEpilogue<8, SAVE, 0, HALF> ep{pw, fast_bias_off(1) + (l - 1) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
         stream_layer_bf<16, 0, 8, TERMS, (fast_fwd_chunk(1) / G) % kRingStages>(ws, fast_fwd_chunk(1) / G + (l - 1) * (8 * 16 / G), act, none, ep);
         advance();
     }
     // ---- layer 4: cat[feat, points_enc] (319) -> 256
     {
-        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(4), hoff, nxt, window(save_h(5)), mask_rec(4), lane};
+        FastFwdEpilogue<8, SAVE, 0, HALF> ep{pw, fast_bias_off(4), hoff, nxt, window(save_h(5)), mask_rec(4), lane};
         stream_layer_bf<16, 4, 8, TERMS, (fast_fwd_chunk(4) / G) % kRingStages>(ws, fast_fwd_chunk(4) / G, act, encp, ep);
         advance();
     }
     // ---- layers 5, 6
 #pragma unroll 1
     for (int l = 5; l <= 6; ++l) {
-        FastFwdEpilogue<8, SAVE, 0> ep{pw, fast_bias_off(5) + (l - 5) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
+        FastFwdEpilogue<8, SAVE, 0, HALF> ep{pw, fast_bias_off(5) + (l - 5) * 8 * 128, hoff, nxt, window(save_h(l + 1)), mask_rec(l), lane};
         stream_layer_bf<16, 0, 8, TERMS, (fast_fwd_chunk(5) / G) % kRingStages>(ws, fast_fwd_chunk(5) / G + (l - 5) * (8 * 16 / G), act, none, ep);
         advance();
     }
     // ---- layer 7: 256 -> 256 features + the density row (row block 8)
     {
-        FastFwdEpilogue<8, SAVE, 1> ep{pw, fast_bias_off(7), hoff, nxt, window(kSaveFeat), mask_rec(7), lane};
+        FastFwdEpilogue<8, SAVE, 1, HALF> ep{pw, fast_bias_off(7), hoff, nxt, window(kSaveFeat), mask_rec(7), lane};
         stream_layer_bf<16, 0, 9, TERMS, (fast_fwd_chunk(7) / G) % kRingStages>(ws, fast_fwd_chunk(7) / G, act, none, ep);
         advance();
         float sig_raw = ep.head[0];
@@ -474,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fast_kernel(FastFwdArgs a) {
     // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
     unsigned hr[2][32];
     {
-        FastFwdEpilogue<4, SAVE, 0> ep{pw, fast_bias_off(8), hoff, hr, window(kSaveHr), mask_rec(8), lane};
+        FastFwdEpilogue<4, SAVE, 0, HALF> ep{pw, fast_bias_off(8), hoff, hr, window(kSaveHr), mask_rec(8), lane};
         stream_layer_bf<16, 2, 4, TERMS, (fast_fwd_chunk(8) / G) % kRingStages>(ws, fast_fwd_chunk(8) / G, act, vencp, ep);
     }
     // ---- colour layer 1: 128 -> 3, sigmoid
@@ -543,7 +569,7 @@ __device__ __forceinline__ float relu_keep(const u32x4_t& mk, int nb, int r, flo
     return __builtin_bit_cast(float, __builtin_bit_cast(int, a) & keep);
 }
 // mask, planes for the next product, fp32 store of dY for the dW pass
-template <int NBOUT>
+template <int NBOUT, bool HALF = false>
 struct FastMaskEpilogue {
     u32x4_t mk;
     int zero;
@@ -557,8 +583,13 @@ struct FastMaskEpilogue {
     __device__ __forceinline__ void epi2(int nb, int rp, float a0, float a1) {
         const float g0 = relu_keep(mk, nb, 2 * rp, a0, zero), g1 = relu_keep(mk, nb, 2 * rp + 1, a1, zero);
         split_pair(g0, g1, out[0][nb * 8 + rp], out[1][nb * 8 + rp]);
-        if (rp & 1) buf_store4(keep[0], keep[1], g0, g1, grad.rsrc(nb * 32 + 8 * (rp >> 1)), grad.voff4, 0);
-        else { keep[0] = g0; keep[1] = g1; }
+        if (HALF) {                      // bf16 workspace: the operand plane itself (see kHalfWorkspace)
+            if (rp & 1) buf_store2(out[0][nb * 8 + rp - 1], out[0][nb * 8 + rp], grad.rsrc(nb * 32 + 8 * (rp >> 1)), grad.voff4, 0);
+        } else if (rp & 1) {
+            buf_store4(keep[0], keep[1], g0, g1, grad.rsrc(nb * 32 + 8 * (rp >> 1)), grad.voff4, 0);
+        } else {
+            keep[0] = g0; keep[1] = g1;
+        }
     }
 };
 // park a result in the stash rows (d encoding slots of the skip connection, d view-encoding slots)
@@ -621,8 +652,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     const WeightStream<TERMS> ws{pw.rsrc, wlds, __builtin_amdgcn_readfirstlane(wave), lane * 16, kFastBwdOffBytes, kFastBwdChunks / kStageChunks};
     if (kSharedWeights<TERMS>) ws.start();
     constexpr int G = kStageChunks;
+    constexpr bool HALF = kHalfWorkspace<TERMS>;          // bf16 quad-row images for everything the dW pass multiplies (see kHalfWorkspace)
     const int pitch4 = (int)(P * 4), voff4 = (int)(((long long)h * P + m) * 16);
-    auto gwin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };
+    auto swin = [&](int r) { return RowWindow{a.grad + (long long)r * P, pitch4, voff4}; };            // stash rows: fp32, at their fp32 places
+    auto gwin = [&](int r) {                                                                            // dY rows
+        return HALF ? RowWindow{reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.grad) + (long long)r * P * 2), (int)(P * 2), (int)(((long long)h * P + m) * 8)}
+                    : swin(r);
+    };
+    // a quad of four values of this lane's sample at quad row `r` of the gradient image (rows 4h + t of an 8-row slot block)
+    auto store_quad = [&](int r, float g0, float g1, float g2, float g3) {
+        if (HALF) {
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            reinterpret_cast<u32x2_t*>(reinterpret_cast<char*>(a.grad) + (long long)r * P * 2)[qoff] = u32x2_t{pack_bf16(g0, g1), pack_bf16(g2, g3)};
+        } else {
+            reinterpret_cast<f32x4*>(a.grad + (long long)r * P)[qoff] = f32x4{g0, g1, g2, g3};
+        }
+    };
     const long long wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     const char* mbase = reinterpret_cast<const char*>(a.save + (long long)kSaveMask * P) + wave_id * kMaskRecords * kMaskRecBytes;
     auto mask_rec = [&](int i) {
@@ -649,23 +694,23 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
                 g[t] = a.d_rgb[mc * 3 + t] * o * (1.f - o);
             }
         }
-        reinterpret_cast<f32x4*>(a.grad + (long long)kGradRgb1 * P)[qoff] = f32x4{g[0], g[1], g[2], g[3]};
+        store_quad(kGradRgb1, g[0], g[1], g[2], g[3]);
         split_pair(g[0], g[1], dy9p[0][0], dy9p[1][0]);
         split_pair(g[2], g[3], dy9p[0][1], dy9p[1][1]);
     }
     unsigned dyr[2][32];
     {
-        FastMaskEpilogue<4> ep{mk_cur, a.zero, dyr, gwin(kGradRgb0)};
+        FastMaskEpilogue<4, HALF> ep{mk_cur, a.zero, dyr, gwin(kGradRgb0)};
         stream_layer_bf<1, 0, 4, TERMS, (fast_bwd_chunk(0) / G) % kRingStages>(ws, fast_bwd_chunk(0) / G, dy9p, none, ep);
     }
     // ---- colour layer 0 transposed: 128 -> 256 features (+ 32 view-encoding slots = slot block 8 of 9)
     {   // (always run: the weight stream is linear; without a ray gradient only its stores are dropped)
-        FastStashEpilogue ep{gwin(kGradStashVenc), a.ray_grad != 0};
+        FastStashEpilogue ep{swin(kGradStashVenc), a.ray_grad != 0};
         stream_layer_bf<8, 0, 1, TERMS, (fast_bwd_chunk(1) / G) % kRingStages>(ws, fast_bwd_chunk(1) / G, dyr, none, ep);
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(6);
-        FastMaskEpilogue<8> ep{mk_cur, a.zero, dy, gwin(kGradY7)};
+        FastMaskEpilogue<8, HALF> ep{mk_cur, a.zero, dy, gwin(kGradY7)};
         stream_layer_bf<8, 0, 8, TERMS, (fast_bwd_chunk(2) / G) % kRingStages>(ws, fast_bwd_chunk(2) / G, dyr, none, ep);
     }
     // ---- density head: d sigma_raw = reduction row 256 of layer 7 = element 0 of lane half 0 of the 17th step
@@ -677,13 +722,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
             const float dact = a.act == NIW_ACT_RELU ? (raw > 0.f ? 1.f : 0.f) : (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
             g = a.d_sigma[mc] * dact;
         }
-        reinterpret_cast<f32x4*>(a.grad + (long long)(kGradY7 + 256) * P)[qoff] = f32x4{g, 0.f, 0.f, 0.f};
+        store_quad(kGradY7 + 256, g, 0.f, 0.f, 0.f);
         split_pair(g, 0.f, dsigp[0][0], dsigp[1][0]);
     }
     // ---- layer 7 transposed (257 -> 256), mask with h7
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(5);
-        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin(6 * 256)};
+        FastMaskEpilogue<8, HALF> ep{mk_cur, a.zero, nxt, gwin(6 * 256)};
         stream_layer_bf<16, 1, 8, TERMS, (fast_bwd_chunk(3) / G) % kRingStages>(ws, fast_bwd_chunk(3) / G, dy, dsigp, ep);
         advance();
     }
@@ -691,18 +736,18 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l - 2);
-        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin((l - 1) * 256)};
+        FastMaskEpilogue<8, HALF> ep{mk_cur, a.zero, nxt, gwin((l - 1) * 256)};
         stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(4) / G) % kRingStages>(ws, fast_bwd_chunk(4) / G + (6 - l) * (8 * 16 / G), dy, none, ep);
         advance();
     }
     // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots = slot blocks 8, 9 of 10)
     {
-        FastStashEpilogue ep{gwin(kGradStashEnc), a.ray_grad != 0};
+        FastStashEpilogue ep{swin(kGradStashEnc), a.ray_grad != 0};
         stream_layer_bf<16, 0, 2, TERMS, (fast_bwd_chunk(6) / G) % kRingStages>(ws, fast_bwd_chunk(6) / G, dy, none, ep);
     }
     {
         mk_cur = mk_nxt; mk_nxt = mask_rec(2);
-        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin(3 * 256)};
+        FastMaskEpilogue<8, HALF> ep{mk_cur, a.zero, nxt, gwin(3 * 256)};
         stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(7) / G) % kRingStages>(ws, fast_bwd_chunk(7) / G, dy, none, ep);
         advance();
     }
@@ -710,7 +755,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
         mk_cur = mk_nxt; mk_nxt = mask_rec(l >= 2 ? l - 2 : 0);
-        FastMaskEpilogue<8> ep{mk_cur, a.zero, nxt, gwin((l - 1) * 256)};
+        FastMaskEpilogue<8, HALF> ep{mk_cur, a.zero, nxt, gwin((l - 1) * 256)};
         stream_layer_bf<16, 0, 8, TERMS, (fast_bwd_chunk(8) / G) % kRingStages>(ws, fast_bwd_chunk(8) / G + (3 - l) * (8 * 16 / G), dy, none, ep);
         advance();
     }
@@ -718,7 +763,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     // ---- layer 0 transposed: 256 -> 64 encoding slots, starting from the parked skip-connection part
     float denc[32], dvenc[16];
     {
-        FastAddStashEpilogue<2> ep{gwin(kGradStashEnc), denc};
+        FastAddStashEpilogue<2> ep{swin(kGradStashEnc), denc};
         stream_layer_bf<16, 0, 2, TERMS, (fast_bwd_chunk(11) / G) % kRingStages>(ws, fast_bwd_chunk(11) / G, dy, none, ep);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -728,8 +773,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_fast_kernel(FastBwdArgs a) 
     }
     // ---- encodings -> point / direction -> per-sample ray gradients (fp32, as in the exact chain), parked for the per-ray reduction
     float dp[3], du[3];
-    enc_backward<NIW_L3D, 8>(denc, a.save + (long long)kSaveEnc * P, P, qoff, h, dp);
-    enc_backward<NIW_LVIEW, 4>(dvenc, a.save + (long long)kSaveVenc * P, P, qoff, h, du);
+    enc_backward<NIW_L3D, 8, HALF>(denc, a.save + (long long)kSaveEnc * P / (HALF ? 2 : 1), P, qoff, h, dp);
+    enc_backward<NIW_LVIEW, 4, HALF>(dvenc, a.save + (long long)kSaveVenc * P / (HALF ? 2 : 1), P, qoff, h, du);
     const long long ri = mc / a.S;
     const float d = a.depth[mc];
     const float rx = a.ray[ri * 3], ry = a.ray[ri * 3 + 1], rz = a.ray[ri * 3 + 2];
