@@ -21,53 +21,68 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t& a, const unsigned (&b
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// image builder (once per optimizer step): one thread per dword of the fragment sections / per float of the bias section
+// image builder (once per optimizer step): one thread per (chunk, lane) of the fragment sections -- it decodes the chunk once, gathers
+// the lane's eight weights and writes their 16 bytes of BOTH planes -- and one thread per float of the bias section.  (One thread per
+// dword, each decoding its chunk twice, took 52 us per network: a tenth of a millisecond of a 5.9 ms bf16 step.)
 // ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int frag_source(int byte, int j) {
-    // -> index into the flat parameter vector of element j (0..7) of the chunk lane that owns `byte`, or -1 (zero padding)
-    const int chunk = byte / kChunkBytes, lane = (byte % 1024) / 16;
-    const int i = lane & 31, h = lane >> 5;
-    int l, blk, q;
-    bool bwd = chunk >= kFastFwdChunks;
-    if (!bwd) {
-        l = 0;
-        while (l + 1 < kLayers && chunk >= fast_fwd_chunk(l + 1)) ++l;
-        const int local = chunk - fast_fwd_chunk(l);
-        blk = local / fast_ks(l); q = local % fast_ks(l);
+struct FragChunk { int l, blk, q; bool bwd, pad; };
+__device__ __forceinline__ FragChunk frag_chunk(int chunk) {
+    FragChunk c{0, 0, 0, chunk >= kFastFwdChunks, false};
+    if (!c.bwd) {
+        while (c.l + 1 < kLayers && chunk >= fast_fwd_chunk(c.l + 1)) ++c.l;
+        const int local = chunk - fast_fwd_chunk(c.l);
+        c.blk = local / fast_ks(c.l); c.q = local % fast_ks(c.l);
     } else {
-        const int c = chunk - kFastFwdChunks;
+        const int cc = chunk - kFastFwdChunks;
         int sgm = 0;
-        while (sgm + 1 < kFastBwdSegs && c >= fast_bwd_chunk(sgm + 1)) ++sgm;
+        while (sgm + 1 < kFastBwdSegs && cc >= fast_bwd_chunk(sgm + 1)) ++sgm;
         const FastBwdSeg sg = fast_bwd_seg(sgm);
-        const int local = c - fast_bwd_chunk(sgm);
-        l = sg.layer;
-        if (local >= sg.nob * fast_rs(l)) return -1;               // padding chunks of the segment
-        blk = sg.ob0 + local / fast_rs(l); q = local % fast_rs(l);
+        const int local = cc - fast_bwd_chunk(sgm);
+        c.l = sg.layer;
+        c.pad = local >= sg.nob * fast_rs(c.l);                    // padding chunks of the segment
+        c.blk = sg.ob0 + local / fast_rs(c.l); c.q = local % fast_rs(c.l);
     }
-    const int red = 16 * q + fast_perm(h, j);                     // reduction index of this element
-    const int row = out_row(l, bwd ? red : blk * 32 + i), col = fwd_slot_col(l, bwd ? blk * 32 + i : red);
-    return (row >= 0 && col >= 0) ? weight_off(l) + row * layer_k(l) + col : -1;
+    return c;
+}
+// index into the flat parameter vector of element j (0..7) of lane (i, h) of the chunk, or -1 (zero padding)
+__device__ __forceinline__ int frag_source(const FragChunk& c, int i, int h, int j) {
+    if (c.pad) return -1;
+    const int red = 16 * c.q + fast_perm(h, j);                   // reduction index of this element
+    const int row = out_row(c.l, c.bwd ? red : c.blk * 32 + i), col = fwd_slot_col(c.l, c.bwd ? c.blk * 32 + i : red);
+    return (row >= 0 && col >= 0) ? weight_off(c.l) + row * layer_k(c.l) + col : -1;
 }
 
+constexpr int kFastChunks = kFastFwdChunks + kFastBwdChunks;
+constexpr int kFastBiasFloats = (kFastImageBytes - kFastChunks * kChunkBytes) / 4;
+static_assert(kFastChunks * kChunkBytes == fast_bias_off(0), "the bias section follows the chunk streams");
+
 __global__ void pack_fast_kernel(const float* __restrict__ params, unsigned* __restrict__ image) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;          // dword index
-    if (d >= kFastImageBytes / 4) return;
-    const int byte = 4 * d;
-    if (byte >= fast_bias_off(0)) {
-        int l = 0;
-        while (l + 1 < kLayers && byte >= fast_bias_off(l + 1)) ++l;
-        const int local = (byte - fast_bias_off(l)) / 4;          // [nb][h][16]
-        const int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
-        const int row = out_row(l, nb * 32 + acc_row(r, h));
-        image[d] = __builtin_bit_cast(unsigned, row >= 0 ? params[bias_off(l) + row] : 0.f);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < kFastChunks * 64) {
+        const int chunk = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+        const FragChunk c = frag_chunk(chunk);
+        u32x4_t hi, mid;
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            const int s0 = frag_source(c, i, h, 2 * jp), s1 = frag_source(c, i, h, 2 * jp + 1);
+            unsigned a, b;
+            split_pair(s0 >= 0 ? params[s0] : 0.f, s1 >= 0 ? params[s1] : 0.f, a, b);
+            hi[jp] = a; mid[jp] = b;
+        }
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(image) + (long long)chunk * kChunkBytes + lane * 16);
+        dst[0] = hi;                     // plane 0
+        dst[64] = mid;                   // plane 1: 1 KiB further
         return;
     }
-    const int plane = (byte % kChunkBytes) / 1024, jp = (byte % 16) / 4;
-    const int s0 = frag_source(byte, 2 * jp), s1 = frag_source(byte, 2 * jp + 1);
-    const float w0 = s0 >= 0 ? params[s0] : 0.f, w1 = s1 >= 0 ? params[s1] : 0.f;
-    unsigned hi, mid;
-    split_pair(w0, w1, hi, mid);
-    image[d] = plane ? mid : hi;
+    const int f = t - kFastChunks * 64;
+    if (f >= kFastBiasFloats) return;
+    const int byte = fast_bias_off(0) + 4 * f;
+    int l = 0;
+    while (l + 1 < kLayers && byte >= fast_bias_off(l + 1)) ++l;
+    const int local = (byte - fast_bias_off(l)) / 4;              // [nb][h][16]
+    const int r = local & 15, h = (local >> 4) & 1, nb = local >> 5;
+    const int row = out_row(l, nb * 32 + acc_row(r, h));
+    image[byte / 4] = __builtin_bit_cast(unsigned, row >= 0 ? params[bias_off(l) + row] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -521,7 +536,7 @@ extern "C" int64_t niw_mlp_fast_image_bytes(void) { return kFastImageBytes; }
 
 extern "C" int niw_mlp_pack_weights_fast(const float* params, void* image, niw_stream_t stream) {
     NIW_REQUIRE(params && image, "niw_mlp_pack_weights_fast: null pointer");
-    pack_fast_kernel<<<(kFastImageBytes / 4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, reinterpret_cast<unsigned*>(image));
+    pack_fast_kernel<<<(kFastChunks * 64 + kFastBiasFloats + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, reinterpret_cast<unsigned*>(image));
     NIW_LAUNCH_CHECK("niw_mlp_pack_weights_fast");
     return NIW_OK;
 }
