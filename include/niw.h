@@ -97,7 +97,8 @@ int niw_mlp_pack_weights_indexed(const float* params, const int32_t* index, floa
  *   noise        [n_rays*n_samples] or NULL (density_noise_reg * randn, nerf.py:428-429)
  *   rgb [n_rays,n_samples,3], sigma [n_rays,n_samples]  (outputs)
  *   save         [NIW_SAVE_ROWS, Mpad] or NULL; non-NULL = training mode (activations kept
- *                for niw_mlp_bwd; the same fp32 workspace in every precision mode).
+ *                for niw_mlp_bwd: fp32 quad rows under NIW_PREC_FP32 / NIW_PREC_BF16X3, bf16 half-pitch quad rows inside the
+ *                same buffer under NIW_PREC_BF16 -- the backward entry points must be called with the forward's precision).
  *   precision    enum niw_precision; `packed` must be the image of that class */
 int niw_mlp_fwd(const float* packed, const float* center, const float* ray,
                 const float* depth, const float* noise, int64_t n_rays, int n_samples,

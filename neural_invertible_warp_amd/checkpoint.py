@@ -121,10 +121,12 @@ def load_optimizer_state_dicts(trainer, checkpoint):
 
 
 def save_checkpoint(opt, trainer, ep, it, latest=False, children=None):
-    """reference util.py:147-163; `trainer` plays the reference's `model` (has .graph and optimizer state)"""
+    """reference util.py:147-163; `trainer` plays the reference's `model` (has .graph and optimizer state).  Issues NO collective:
+    under ray sharding the caller runs `trainer.sync_state()` on EVERY rank first (Model.save_checkpoint does) and only then lets
+    rank 0 write -- a collective behind a rank gate would pair with the other ranks' next gradient all-reduce."""
     os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
     if hasattr(trainer, "sync_state"):
-        trainer.sync_state()
+        trainer.sync_state(collective=False)
     sd = trainer.graph.state_dict()
     if children is not None:
         sd = {k: v for k, v in sd.items() if k.startswith(children)}

@@ -275,24 +275,35 @@ class INNTrainer:
         return loss
 
     def _check_static_inputs(self, var):
-        """A replay reads the batch tensors the capture saw, at the addresses it saw them.  A caller that hands over the same data in
-        new storage (a re-allocated image after .to(), another batch) gets it copied into the captured tensors when the shapes agree
-        -- stream-ordered in front of the replay -- and an error when they do not; a replay never trains silently on stale inputs."""
-        for k, ref in self._static_inputs.items():
+        """A replay reads PRIVATE copies of the batch tensors (made at capture time), never the caller's storage.  The copy of a tensor
+        is refreshed -- stream-ordered in front of the replay -- whenever the caller hands over another tensor, other storage or a
+        tensor written since (its version counter); the same untouched tensor costs nothing.  A shape / dtype / device change is an
+        error: a replay never trains silently on stale inputs, and never writes into memory the caller owns (round 3 copied a new
+        batch INTO the first batch's tensor, corrupting a harness that alternates batches)."""
+        for k, (mine, seen) in self._static_inputs.items():
             t = var.get(k) if hasattr(var, "get") else getattr(var, k, None)
             if t is None:
                 raise NiwError(f"train_iteration: the captured iteration reads var.{k}, which this call does not provide")
             if not isinstance(t, torch.Tensor):
                 raise NiwError(f"train_iteration: var.{k} was a tensor when the iteration was captured, now {type(t).__name__}")
-            if t.data_ptr() == ref.data_ptr() and t.shape == ref.shape and t.dtype == ref.dtype:
-                continue
-            if t.shape != ref.shape or t.dtype != ref.dtype or t.device != ref.device:
+            if t.shape != mine.shape or t.dtype != mine.dtype or t.device != mine.device:
                 raise NiwError(f"train_iteration: var.{k} is {tuple(t.shape)} {t.dtype} on {t.device}, the captured iteration was recorded with "
-                               f"{tuple(ref.shape)} {ref.dtype} on {ref.device}; build a new trainer (or hip_graph=False) for another batch shape")
-            ref.copy_(t)
+                               f"{tuple(mine.shape)} {mine.dtype} on {mine.device}; build a new trainer (or hip_graph=False) for another batch shape")
+            now = (t.data_ptr(), t._version)
+            if now != seen:
+                mine.copy_(t)
+                self._static_inputs[k] = (mine, now)
         for k, v in var.items():
             if isinstance(v, torch.Tensor) and k not in self._static_inputs:
                 raise NiwError(f"train_iteration: var.{k} was not part of the captured iteration")
+
+    def _private_batch(self, var):
+        """trainer-owned copies of the batch tensors the captured iteration will read in place -> a var of the same type over them"""
+        self._static_inputs = {k: (v.clone(), (v.data_ptr(), v._version)) for k, v in var.items() if isinstance(v, torch.Tensor)}
+        mine = type(var)(var)
+        for k, (t, _) in self._static_inputs.items():
+            mine[k] = t
+        return mine
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -308,7 +319,7 @@ class INNTrainer:
         live_group = parallel._collectives_live()
         # (round 3: no collective sits inside the forward any more -- the warp and the alignment term are replicated, ..parallel --
         # so a sharded iteration is captured like any other: forward + backward + gather | all-reduce, eager | Adam)
-        self._static_inputs = {k: v for k, v in var.items() if isinstance(v, torch.Tensor)}      # must stay alive and in place
+        var = self._private_batch(var)              # the graph reads the trainer's own copies, in place, for as long as it lives
         torch.cuda.synchronize()
         try:
             # ranks with a live RCCL communicator: its watchdog thread polls events while we capture, which "global" error mode
@@ -342,13 +353,16 @@ class INNTrainer:
         self._bind_constants(False)
         return False
 
-    def sync_state(self):
+    def sync_state(self, collective=True):
         """bring device-side mirrors of host state up to date (the c2f `progress` Parameter is only written on demand under
-        graph replay): call before reading state_dict()"""
+        graph replay): call before reading state_dict().  Under ray sharding the per-view pose tables are collected from the ranks
+        that own the views -- an all-reduce, so EVERY rank must make this call at the same point of its program (validate() and
+        save_checkpoint() of the Model do, before any rank gate); `collective=False` is the host-only part, for a caller that runs on
+        one rank after all ranks have synchronised (checkpoint.save_checkpoint on rank 0)."""
         for n in self.nets:
             if hasattr(n, "set_progress"):
                 n.set_progress(self.it / self.opt.max_iter if self.it else float(n.progress_host or 0.0))
-        if self.world > 1:
+        if self.world > 1 and collective:
             # per-view pose tables: under ray sharding every rank has refreshed the rows of its own views only
             win = getattr(self.graph, "_last_window", None)
             if self.family == "dtu":

@@ -192,6 +192,7 @@ class Model:
         return out
 
     def evaluate_full(self, opt):
+        self.trainer.sync_state()                  # every rank (a collective under ray sharding)
         allv = self.test_data.all
         views = [edict({k: v[i:i + 1] for k, v in allv.items()}) for i in range(len(self.test_data))]
         out = self._evaluator(opt).evaluate_full(opt, views)
@@ -205,5 +206,7 @@ class Model:
 
     def save_checkpoint(self, opt, ep=0, it=0, latest=False):
         from .. import checkpoint
+        # every rank: the per-view pose table is collected with an all-reduce (engine.INNTrainer.sync_state); only then the rank gate
+        self.trainer.sync_state()
         if self.trainer.rank == 0:
             checkpoint.save_checkpoint(opt, self.trainer, ep=ep, it=it, latest=latest)

@@ -318,6 +318,10 @@ class Graph(_BaseGraph):
         Sf = opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0
         step = max(1, min(total, self.FUSED_SAMPLES // (B * (S + (S + Sf if Sf else 0)))))
         fine = getattr(self, "nerf_fine", None) if Sf else None
+        if fine is not None and fine._state.precision != self.nerf._state.precision:
+            # niw_render_fwd takes ONE precision for both packed images of the call
+            raise NiwError(f"render: nerf runs in {self.nerf._state.precision!r} and nerf_fine in {fine._state.precision!r}; "
+                           "set_precision() both networks alike")
         image = None
         with self._hold_weights():
             for first in range(0, total, step):
@@ -346,11 +350,18 @@ class Graph(_BaseGraph):
         num_rays = num_rays or opt.H * opt.W
         S = opt.nerf.sample_intvs
         if opt.nerf.sample_stratified and opt.nerf.get("stratified_rng") == "philox":
-            # the draw happens inside the kernel (what the engine selects): stream keyed by (opt.seed, iteration of the draw, a
-            # counter of the sample_depth calls inside that iteration), replayable from a captured graph through `draw_dev`
+            # the draw happens inside the kernel (what the engine selects).  A stream is a pure function of (key, draw): the draw is the
+            # number of the pixel draw of the current training iteration (`_depth_draw`, set by draw_ray_idx; replayable from a
+            # captured graph through `draw_dev`), the key folds in opt.seed, the rank (ranks render different rays) and the number of
+            # this sample_depth call SINCE that pixel draw -- so the slices of a full-image sweep and the validation renders between
+            # two train steps each get a stream of their own (round 3: they all reused the last train step's).  Before the first
+            # pixel draw the running count of calls numbers the draw.
             self._depth_calls = getattr(self, "_depth_calls", 0) + 1
-            rank = (getattr(opt, "ray_shard", None) or (0, 1))[0]            # ranks render different rays: different streams
-            stream_seed = (int(getattr(opt, "seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5D1F + rank * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+            call = getattr(self, "_depth_call_in_iter", 0)
+            self._depth_call_in_iter = call + 1
+            rank = (getattr(opt, "ray_shard", None) or (0, 1))[0]
+            stream_seed = (int(getattr(opt, "seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5D1F + rank * 0xD1B54A32D192ED03
+                           + call * 0x632BE59BD9B4E019) & (2 ** 64 - 1)
             d = ops.sample_stratified_rng(stream_seed, getattr(self, "_depth_draw", self._depth_calls), batch_size * num_rays, S, rng,
                                           opt.nerf.depth.param, opt.device, draw_dev=getattr(self, "draw_dev", None))
             return d.view(batch_size, num_rays, S, 1)

@@ -106,6 +106,7 @@ class Graph(nerf.Graph):
         self._ray_draws = getattr(self, "_ray_draws", 0) + 1
         number = self._ray_draws if draw is None else int(draw) + 1
         self._depth_draw = number                  # the in-kernel stratified draw of this forward uses the same number (nerf.Graph.sample_depth)
+        self._depth_call_in_iter = 0               # ... and numbers its sample_depth calls from here (one stream per call)
         if opt.nerf.get("ray_sampler", "randperm") == "feistel":
             return ops.draw_ray_idx(opt.H * opt.W, n, int(getattr(opt, "seed", 0) or 0), number, opt.device, draw_dev=getattr(self, "draw_dev", None))
         if getattr(opt, "ray_shard", None) is None:

@@ -17,8 +17,8 @@ L3D, LVIEW = 10, 4
 TRAIN_LAUNCH_SAMPLES = (1 << 31) // (288 * 4)          # samples per differentiable field_mlp launch (see field_mlp)
 ACT = {"relu": 0, "softplus": 1}
 PREC = {"fp32": 0, "bf16x3": 1, "bf16": 2}         # enum niw_precision (include/niw.h); "fp32" = exact, the default everywhere
-DX_PRECISIONS = {"fp32", "bf16x3", "bf16"}           # precisions whose dX chain / dW GEMMs exist; a missing one falls back to the
-DW_PRECISIONS = {"fp32", "bf16x3", "bf16"}           # exact-fp32 kernel on the same (fp32) workspaces
+DX_PRECISIONS = {"fp32", "bf16x3", "bf16"}           # precisions whose dX chain / dW GEMMs exist.  A missing "bf16x3" pass would fall back to
+DW_PRECISIONS = {"fp32", "bf16x3", "bf16"}           # the exact-fp32 kernel (same fp32 workspaces); "bf16" cannot (bf16 workspaces, see _backward_precision)
 
 
 def _p(t):
@@ -289,6 +289,14 @@ class FieldState:
         return packed
 
 
+def _backward_precision(precision, built, what):
+    if precision in built:
+        return precision
+    if precision == "bf16":
+        raise _lib.NiwError(f"field MLP: the {what} of precision 'bf16' are not built, and its bf16 workspaces cannot be handed to the fp32 kernels")
+    return "fp32"
+
+
 class _FieldMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state, band3d, bandview, band_dev, activ, noise, grad_mode, grad_sink, center, ray, depth, *params):
@@ -314,10 +322,11 @@ class _FieldMLP(torch.autograd.Function):
             _lib.call("niw_mlp_fwd", _p(packed), _p(center), _p(ray), _p(depth), _p(noise), n_rays, S,
                       b3, bv, _p(band_dev), ACT[activ], PREC[state.precision], _p(rgb), _p(sigma), _p(save), _stream())
         ctx.state, ctx.b3, ctx.bv, ctx.activ, ctx.mpad = state, b3, bv, activ, mpad
-        # the backward of the fast modes that has no kernel of its own yet runs on the exact-fp32 kernels (the forward's saves are the
-        # same fp32 workspace in every mode) and needs the fp32 image of the same weights
-        ctx.dx_precision = state.precision if state.precision in DX_PRECISIONS else "fp32"
-        ctx.dw_precision = state.precision if state.precision in DW_PRECISIONS else "fp32"
+        # a backward pass of "bf16x3" that had no kernel of its own would run on the exact-fp32 kernels (that mode's saves are the
+        # same fp32 workspace) with the fp32 image of the same weights; "bf16" keeps bf16 half-pitch quad rows in `save` /
+        # `gradws` (niw_mlp_fast.hip kHalfWorkspace), which the fp32 kernels would read as garbage -- no fallback there
+        ctx.dx_precision = _backward_precision(state.precision, DX_PRECISIONS, "dX chain")
+        ctx.dw_precision = _backward_precision(state.precision, DW_PRECISIONS, "dW GEMMs")
         ctx.save_ws, ctx.grad_sink = save, grad_sink
         ctx.packed = packed if (not need or ctx.dx_precision == state.precision) else state.packed_fp32()
         ctx.set_materialize_grads(False)

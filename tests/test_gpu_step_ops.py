@@ -312,7 +312,8 @@ def test_eval_render_under_hip_graph_uses_the_host_bands_not_the_step_buffer():
 
 def test_hip_graph_replay_refuses_or_refreshes_inputs_it_was_not_captured_with():
     """Round 2 advisor finding: a replay reads the tensors saved at capture time and used to ignore the `var` it was handed.  Same
-    data in new storage is copied into the captured tensors (training continues on the NEW values); another shape is an error."""
+    data in new storage is copied into the trainer's PRIVATE copies (training continues on the NEW values, the caller's tensors are never
+    written); another shape is an error."""
     from neural_invertible_warp_amd import configs, engine
     from neural_invertible_warp_amd._lib import NiwError
     opt = configs.cfg3_barf_inn_llff(device=DEV)
@@ -323,17 +324,25 @@ def test_hip_graph_replay_refuses_or_refreshes_inputs_it_was_not_captured_with()
     var1 = type(var0)(var0)
     var1.image = torch.full_like(var0.image, 0.25)             # a constant image in NEW storage
     assert var1.image.data_ptr() != var0.image.data_ptr()
-    # what the fourth step on the new image must give: the eager engine (run first -- the refresh below writes INTO var0.image)
+    # what the fourth step on the new image, and the fifth back on the first one, must give: the eager engine
     ref = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=5, hip_graph=False)
     for _ in range(3):
         ref.train_iteration(type(var0)(var0))
     loss_ref = float(ref.train_iteration(type(var1)(var1)).render.detach())
+    loss_back = float(ref.train_iteration(type(var0)(var0)).render.detach())
+    image0 = var0.image.clone()
     tr = engine.INNTrainer(opt, 5, warp_perturb=0.02, seed=5, hip_graph=True)
     for _ in range(3):
         tr.train_iteration(type(var0)(var0))
     assert tr._captured is not None
     loss_new = float(tr.train_iteration(var1).render.detach())
     assert abs(loss_new - loss_ref) <= 2e-3 * loss_ref, (loss_new, loss_ref)
+    # round 3 advisor finding: the refresh wrote batch B INTO the caller's batch-A tensor.  The replay owns private copies now: the
+    # caller's first batch is untouched, and alternating back trains on its values again
+    assert torch.equal(var0.image, image0), "a replay wrote into the caller's tensor"
+    loss_a = float(tr.train_iteration(type(var0)(var0)).render.detach())
+    assert abs(loss_a - loss_back) <= 2e-3 * loss_back, (loss_a, loss_back)
+    assert torch.equal(var0.image, image0)
     var2 = type(var0)(var0)
     var2.image = var0.image[:, :, :6].contiguous()
     with pytest.raises(NiwError, match="captured iteration"):

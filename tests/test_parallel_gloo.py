@@ -222,3 +222,60 @@ def test_every_rank_draws_the_same_pixels_and_the_shares_partition_the_rays():
         assert max(sizes) - min(sizes) <= 1
     # the case that motivated it: 18 views x 113 rays x 128 samples over 8 ranks fits ONE 32,768-sample round of the MLP kernels
     assert max(hi - lo for lo, hi in (parallel.flat_share(18 * 113, r, 8) for r in range(8))) * 128 <= 32768
+
+
+# ---------------------------------------------------------------------------------------------
+# validate / save_checkpoint under a live group (round 3 advisor finding): the per-view pose table is collected with an
+# all-reduce, which every rank must reach BEFORE the rank gate -- rank 0 alone posting it pairs with the others' gradient all-reduce
+# ---------------------------------------------------------------------------------------------
+def _ckpt_worker(rank, world, port, out_dir, q):
+    from neural_invertible_warp_amd import checkpoint, configs, engine, parallel
+    from neural_invertible_warp_amd.model import barf_inn_llff
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_from_env(backend="gloo")
+    Bv, Rv = 5, 7
+    opt = configs.cfg3_barf_inn_llff(device="cpu")
+    opt.nerf.rand_rays, opt.output_path = Bv * Rv, out_dir
+    tr = engine.INNTrainer(opt, Bv, rank=rank, world=world)
+    g = tr.graph
+    # what a sharded train iteration leaves behind: every rank has refreshed the rows of ITS window of views
+    win = g._last_window = parallel.ViewWindow(Bv, Rv, rank, world)
+    g.global_rigid.weight.data[win.views] = float(10 + rank)
+    model = barf_inn_llff.Model.__new__(barf_inn_llff.Model)
+    model.opt, model.trainer, model.graph = opt, tr, g
+    for step in range(2):
+        # the engine's order of collectives around a checkpoint iteration: gradient all-reduce, checkpoint, gradient all-reduce
+        tr.bucket.flat.fill_(1.0 + rank)
+        tr.bucket.all_reduce()
+        assert float(tr.bucket.flat[0]) == 3.0 and float(tr.bucket.flat[-1]) == 3.0
+        tr.it = step + 1
+        model.save_checkpoint(opt, ep=None, it=tr.it)           # all ranks call it (Model.train does); rank 0 writes
+        tr.sync_state()                                         # what validate() does first, on every rank
+    tr.bucket.flat.fill_(1.0)
+    tr.bucket.all_reduce()
+    assert float(tr.bucket.flat.sum()) == 2.0 * tr.bucket.flat.numel()
+    if rank == 0:
+        q.put(g.global_rigid.weight.data.clone().numpy())
+    dist.destroy_process_group()
+
+
+def test_checkpoint_and_validate_collectives_pair_up_on_every_rank(tmp_path):
+    from neural_invertible_warp_amd import parallel
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    table = torch.from_numpy(q.get(timeout=240))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    # every view's row comes from the rank that owns the view
+    wins = [parallel.ViewWindow(5, 7, r, world) for r in range(world)]
+    for r, w in enumerate(wins):
+        assert bool((table[w.own0:w.own1] == 10.0 + r).all())
+    ck = torch.load(tmp_path / "model.ckpt", weights_only=False)
+    assert ck["iter"] == 2 and torch.equal(ck["graph"]["global_rigid.weight"], table)
+    assert (tmp_path / "model" / "1.ckpt").exists() and (tmp_path / "model" / "2.ckpt").exists()
