@@ -327,6 +327,124 @@ int niw_mse_fwd_bwd(const float* rgb, const float* image, const int64_t* ray_idx
 int niw_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int step, const float* hyper_dev, niw_stream_t stream);
 
+/* Adam over several flat buffers in ONE launch (the engine's optimizer groups: NeRF, fine NeRF, warp network, latent table;
+ * reference model/nerf.py:34-38, model/barf_inn_llff.py:84-104 build one torch.optim.Adam per pair of groups and step them one
+ * after the other -- per element the same arithmetic as niw_adam_step).  `groups` is a HOST array of n_groups (<= 8) entries;
+ * hyper_dev: DEVICE array [n_groups][2] = {lr / (1 - beta1^step), sqrt(1 - beta2^step)} per group or NULL (then formed from
+ * lr / step of each entry on the host).  A group with n = 0 is skipped. */
+typedef struct niw_adam_group {
+    float* param;             /* device */
+    const float* grad;        /* device */
+    float* exp_avg;           /* device */
+    float* exp_avg_sq;        /* device */
+    int64_t n;
+    double lr;
+    int32_t step;             /* 1-based */
+    int32_t reserved;
+} niw_adam_group;
+int niw_adam_step_multi(const niw_adam_group* groups, int n_groups, double beta1, double beta2, double eps, const float* hyper_dev,
+                        niw_stream_t stream);
+
+/* ------------------------------------------------------------------ one INN train iteration, forward and backward, one call
+ * The body of the reference's train step between zero_grad and the optimizers (model/nerf_inn_llff.py:493-573 Graph.forward +
+ * compute_loss, model/barf_inn_llff.py:305-364 get_pose, model/base.py:130-142 summarize_loss, and the backward pass autograd runs
+ * through all of it; the DTU family: model/nerf_inn_dtu.py:371-415, model/pose_models/inn.py:63-102):
+ *
+ *   pixel draw -> camera-frame grid / centre points per view (-> world by the initial poses, DTU) -> NVP warp of [grid ; centre]
+ *   -> rays -> stratified depths -> field MLP -> compositing [-> inverse-CDF resampling, merge, fine field MLP, compositing]
+ *   -> photometric loss(es) + rigid registration of the warped onto the un-warped points and the alignment loss
+ *   -> loss.all = sum_k 10^w_k loss_k -> backward of every stage -> parameter gradients of the field network(s), the warp
+ *   network and the latent table, written to the caller's four buffers (overwritten; the engine's all-reduce / Adam bucket).
+ *
+ * The entry point only SEQUENCES the library's own stages (the entry points above, same kernels, same launch shapes) on the
+ * caller's stream into ONE caller-provided workspace, plus three small kernels of its own for what the reference does as tensor
+ * glue (stack / split of the point sets, the sum of the gradient routes into the warp, the weighted loss total).  No allocation,
+ * no synchronisation, no host read-back; capturable into a HIP graph (the per-step scalars then come from band_dev / window_dev /
+ * draw_dev).  The reference's Python `Graph.forward / compute_loss` interface stays available on the mirror classes (autograd over
+ * the per-stage entry points); this call is what the engine runs per iteration.
+ *
+ * Ray sharding (one process per GPU): the rank handles the whole views [view0, view1) in the warp and the alignment term (it
+ * counts the alignment loss of the views [own0, own1)) and the rays [ray_lo, ray_hi) of the flattened view-major
+ * [n_views][rays_per_view] list in everything per (ray, sample); unsharded: view0 = own0 = 0, view1 = own1 = n_views, ray_lo = 0,
+ * ray_hi = n_views * rays_per_view.  Losses are normalised by the GLOBAL element counts, so per-rank losses and gradients SUM to
+ * the unsharded step.
+ *
+ * niw_train_desc is a HOST struct; pointer members are device pointers unless stated. */
+enum niw_train_stage {          /* the call executes the stages [stage_begin, stage_end); a timing harness calls them one by one */
+    NIW_STAGE_RAYS = 0,         /* pixel draw, un-warped points [grid ; centre] per view */
+    NIW_STAGE_WARP_FWD,         /* operand preparation, warp, rays = grid - centre */
+    NIW_STAGE_SAMPLE,           /* stratified depths */
+    NIW_STAGE_PACK,             /* weight images of the field network(s) */
+    NIW_STAGE_MLP_FWD,          /* coarse field */
+    NIW_STAGE_COMPOSITE_FWD,
+    NIW_STAGE_RESAMPLE,         /* inverse-CDF depths merged with the coarse ones (n_fine > 0) */
+    NIW_STAGE_MLP_FWD_FINE,
+    NIW_STAGE_COMPOSITE_FWD_FINE,
+    NIW_STAGE_LOSS,             /* photometric loss(es), registration, alignment loss, weighted total */
+    NIW_STAGE_COMPOSITE_BWD_FINE,
+    NIW_STAGE_MLP_BWD_DX_FINE,
+    NIW_STAGE_MLP_BWD_DW_FINE,
+    NIW_STAGE_COMPOSITE_BWD,
+    NIW_STAGE_MLP_BWD_DX,
+    NIW_STAGE_MLP_BWD_DW,
+    NIW_STAGE_WARP_BWD,         /* sum of the gradient routes into the warped points, warp backward, operand-preparation backward */
+    NIW_STAGE_END
+};
+
+typedef struct niw_train_desc {
+    /* the resident batch */
+    const float* image;         /* [n_views,3,H*W] */
+    const float* intr;          /* [n_views,3,3] */
+    const float* pose_init;     /* [n_views,3,4] world->camera initial poses (DTU, camera.py:382-384) or NULL (LLFF) */
+    int32_t n_views, H, W;
+    int32_t view0, view1, own0, own1;      /* ray sharding, see above */
+    int32_t stratified;         /* opt.nerf.sample_stratified: Philox draws (niw_sample_stratified_rng); 0: interval mid-points */
+    int64_t rays_per_view;      /* of the GLOBAL batch: rand_rays // n_views */
+    int64_t ray_lo, ray_hi;
+    /* draws: pixel subset niw_draw_ray_idx(pixel_seed, draw), depths niw_sample_stratified_rng(depth_seed, draw) */
+    uint64_t pixel_seed, depth_seed, draw;
+    const uint64_t* draw_dev;   /* device word overriding `draw` at run time, or NULL */
+    /* sampling */
+    int32_t n_samples, n_fine;  /* n_fine = 0: no fine pass */
+    int32_t inverse_depth;      /* opt.nerf.depth.param == "inverse" */
+    int32_t density_activ;      /* enum niw_density_activ */
+    double depth_min, depth_max;
+    const float* unif;          /* inverse-CDF tables of niw_sample_pdf_merge (n_fine > 0) */
+    const float* bins;
+    /* field networks: flat parameters in state-dict order (NIW_NERF_PARAM_FLOATS each) */
+    const float* nerf_params;
+    const float* nerf_fine_params;   /* n_fine > 0 */
+    const int32_t* pack_index;  /* table of niw_mlp_pack_index (fp32 images) or NULL (the image is decoded per element) */
+    int32_t precision;          /* enum niw_precision */
+    int32_t use_index_window;   /* with window_dev: whether the index window applies (niw_warp_fwd) */
+    const float* band_w3d;      /* HOST [10] or NULL: c2f band weights of both networks (they share `progress`) */
+    const float* band_wview;    /* HOST [4] or NULL */
+    const float* band_dev;      /* device [14] or NULL */
+    /* warp */
+    const float* warp_params;   /* [NIW_WARP_PARAM_FLOATS] */
+    const float* latent;        /* [n_views,128] the whole table (rows view0..view1 are used) */
+    const float* chan_w;        /* HOST [6] or NULL */
+    const float* index_window;  /* HOST [6] or NULL */
+    const float* window_dev;    /* device [12] or NULL */
+    /* loss: weights 10^w of model/base.py:130-142; a NEGATIVE weight = the term is absent (yaml weight `null`) */
+    float w_render, w_render_fine, w_align;
+    int32_t always_register;    /* DTU: the registration runs (and refreshes `poses`) also without the alignment term (inn.py:96-102) */
+    double mse_norm;            /* element count of the photometric mean: 3 * n_views * rays_per_view of the GLOBAL batch */
+    /* outputs */
+    float* loss;                /* [4] = {render, render_fine, global_alignment, all}; absent terms 0 */
+    float* d_nerf;              /* [NIW_NERF_PARAM_FLOATS] */
+    float* d_nerf_fine;         /* n_fine > 0 */
+    float* d_warp;              /* [NIW_WARP_PARAM_FLOATS] */
+    float* d_latent;            /* [n_views,128]; rows outside [view0, view1) are zeroed */
+    float* poses;               /* [n_views,12] registered [R|t] per view (global_rigid / pose_global); rows view0..view1 refreshed; or NULL */
+    float* rgb;                 /* optional [n_rays,3] rendered colours of the share (NULL: kept in the workspace only) */
+    float* rgb_fine;            /* optional */
+} niw_train_desc;
+
+/* floats of the workspace (16-byte aligned); <= 0 with niw_last_error_string() set when the descriptor is not supported */
+int64_t niw_train_step_workspace_floats(const niw_train_desc* desc);
+int niw_train_step(const niw_train_desc* desc, float* workspace, int stage_begin, int stage_end, niw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,32 @@ class RenderDesc(ctypes.Structure):
                 ("band_w3d_fine", ctypes.POINTER(_f)), ("band_wview_fine", ctypes.POINTER(_f)), ("band_dev_fine", _vp)]
 
 
+class AdamGroup(ctypes.Structure):
+    """niw_adam_group of include/niw.h"""
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("n", _i64), ("lr", _d), ("step", _i32), ("reserved", _i32)]
+
+
+class TrainDesc(ctypes.Structure):
+    """niw_train_desc of include/niw.h, field for field"""
+    _fp = ctypes.POINTER(_f)
+    _fields_ = [("image", _vp), ("intr", _vp), ("pose_init", _vp), ("n_views", _i32), ("H", _i32), ("W", _i32),
+                ("view0", _i32), ("view1", _i32), ("own0", _i32), ("own1", _i32), ("stratified", _i32),
+                ("rays_per_view", _i64), ("ray_lo", _i64), ("ray_hi", _i64),
+                ("pixel_seed", _u64), ("depth_seed", _u64), ("draw", _u64), ("draw_dev", _vp),
+                ("n_samples", _i32), ("n_fine", _i32), ("inverse_depth", _i32), ("density_activ", _i32),
+                ("depth_min", _d), ("depth_max", _d), ("unif", _vp), ("bins", _vp),
+                ("nerf_params", _vp), ("nerf_fine_params", _vp), ("pack_index", _vp), ("precision", _i32), ("use_index_window", _i32),
+                ("band_w3d", _fp), ("band_wview", _fp), ("band_dev", _vp),
+                ("warp_params", _vp), ("latent", _vp), ("chan_w", _fp), ("index_window", _fp), ("window_dev", _vp),
+                ("w_render", _f), ("w_render_fine", _f), ("w_align", _f), ("always_register", _i32), ("mse_norm", _d),
+                ("loss", _vp), ("d_nerf", _vp), ("d_nerf_fine", _vp), ("d_warp", _vp), ("d_latent", _vp), ("poses", _vp),
+                ("rgb", _vp), ("rgb_fine", _vp)]
+
+
+# train stages (enum niw_train_stage), in execution order
+TRAIN_STAGES = ("rays", "warp_fwd", "sample", "pack", "mlp_fwd", "composite_fwd", "resample", "mlp_fwd_fine", "composite_fwd_fine", "loss",
+                "composite_bwd_fine", "mlp_bwd_dx_fine", "mlp_bwd_dw_fine", "composite_bwd", "mlp_bwd_dx", "mlp_bwd_dw", "warp_bwd")
+
 # name -> (restype, argtypes); mirrors include/niw.h one to one
 SIGNATURES = {
     "niw_version": (_i, []),
@@ -65,6 +91,9 @@ SIGNATURES = {
     "niw_render_fwd_workspace_floats": (_i64, [_i, _i64, _i, _i]),
     "niw_render_fwd": (_i, [ctypes.POINTER(RenderDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp, _vp]),
+    "niw_adam_step_multi": (_i, [ctypes.POINTER(AdamGroup), _i, _d, _d, _d, _vp, _vp]),
+    "niw_train_step_workspace_floats": (_i64, [ctypes.POINTER(TrainDesc)]),
+    "niw_train_step": (_i, [ctypes.POINTER(TrainDesc), _vp, _i, _i, _vp]),
 }
 
 _lib = None

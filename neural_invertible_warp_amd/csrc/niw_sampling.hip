@@ -120,12 +120,14 @@ __device__ __forceinline__ void inv3x3(const float* __restrict__ K, float (&o)[9
 }
 
 __global__ void raygen_kernel(const float* __restrict__ intr, const float* __restrict__ pose, const int64_t* __restrict__ ray_idx,
-                              long long first_pixel, int B, long long R, int H, int W, int mode, float* __restrict__ out_a,
-                              float* __restrict__ out_b) {
+                              long long first_pixel, int B, long long R, int H, int W, int mode, long long view_stride,
+                              float* __restrict__ out_a, float* __restrict__ out_b) {
+    // view_stride: output rows between two views (R: dense [B,R,3] outputs; 2R: the two halves of a stacked [B,2R,3] point set)
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * R) return;
     const int b = (int)(i / R);
     const long long r = i % R;
+    const long long o = b * view_stride + r;
     const long long pix = ray_idx ? ray_idx[r] : first_pixel + r;
     const float x = (float)(pix % W) + 0.5f, y = (float)(pix / W) + 0.5f;
     float Ki[9];
@@ -149,8 +151,8 @@ __global__ void raygen_kernel(const float* __restrict__ intr, const float* __res
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        out_a[i * 3 + k] = c[k];
-        out_b[i * 3 + k] = mode == 1 ? g[k] - c[k] : g[k];
+        out_a[o * 3 + k] = c[k];
+        out_b[o * 3 + k] = mode == 1 ? g[k] - c[k] : g[k];
     }
 }
 
@@ -311,8 +313,18 @@ extern "C" int niw_raygen(const float* intr, const float* pose, const int64_t* r
     NIW_REQUIRE(ray_idx || (first_pixel >= 0 && first_pixel + n_rays_per_view <= (int64_t)H * W),
                 "niw_raygen: pixel range [%lld, %lld) leaves the %dx%d image", (long long)first_pixel, (long long)(first_pixel + n_rays_per_view), H, W);
     const long long n = (long long)n_views * n_rays_per_view;
-    raygen_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(intr, pose, ray_idx, first_pixel, n_views, n_rays_per_view, H, W, mode, out_a, out_b);
+    raygen_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(intr, pose, ray_idx, first_pixel, n_views, n_rays_per_view, H, W, mode,
+                                                                           n_rays_per_view, out_a, out_b);
     NIW_LAUNCH_CHECK("niw_raygen");
+    return NIW_OK;
+}
+
+// mode 0 straight into a stacked point set [n_views][2R][3] = [grid ; centre] per view (the warp's input batch; niw_step.hip)
+int niw_launch_raygen_stacked(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, long long R, int H, int W,
+                              float* stacked, hipStream_t st) {
+    const long long n = (long long)n_views * R;
+    raygen_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(intr, pose, ray_idx, 0, n_views, R, H, W, 0, 2 * R, stacked + 3 * R, stacked);
+    NIW_LAUNCH_CHECK("niw_train_step (ray generation)");
     return NIW_OK;
 }
 

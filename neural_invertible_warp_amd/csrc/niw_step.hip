@@ -1,0 +1,390 @@
+// One INN train iteration (forward + backward) as ONE call, and the Adam step of all optimizer groups as one launch.
+//
+// niw_train_step replaces, for the engine, what the reference runs between zero_grad and the optimizers: Graph.forward in train
+// mode (model/nerf_inn_llff.py:493-546, model/nerf_inn_dtu.py:371-396) with get_pose = ray generation + NVP warp
+// (model/barf_inn_llff.py:305-364, model/pose_models/inn.py:63-102), compute_loss (nerf_inn_llff.py:548-573, nerf_inn_dtu.py:398-415),
+// summarize_loss (model/base.py:130-142) and loss.all.backward().  It only SEQUENCES the library's own per-stage entry points -- the
+// same kernels and launch shapes the autograd mirror (ops.py) uses -- into one caller-provided workspace, and adds three small
+// kernels for what the reference does as tensor glue around them:
+//   split_rays_kernel   warped [grid ; centre] point sets -> contiguous rays (grid - centre) and centres   (barf_inn_llff.py:360-363)
+//   combine_kernel      the sum of every gradient route into the warped points (sample points and view directions of both field
+//                       networks, ray lengths of both compositing passes, the alignment residual), the zero rows of the latent
+//                       gradient outside a rank's window, and loss.all = sum_k 10^w_k loss_k
+//   fill_kernel         zero gradients of a network that receives no loss term
+// Route sums are formed in the order autograd's accumulation would (fine compositing, fine field, coarse compositing, coarse field;
+// separately rounded), so the engine's parameters agree bit for bit with the autograd mirror on the same inputs.
+#include "niw_common.h"
+
+int niw_launch_raygen_stacked(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, long long R, int H, int W,
+                              float* stacked, hipStream_t st);
+
+namespace {
+
+using niw::add_rn;
+using niw::mul_rn;
+using niw::sub_rn;
+
+struct Carve {             // hands out consecutive 16-byte aligned pieces of the workspace
+    float* p;
+    long long used = 0;
+    float* take(long long n) {
+        float* r = p ? p + used : nullptr;
+        used += (n + 3) / 4 * 4;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- glue kernels
+__global__ void split_rays_kernel(const float* __restrict__ warped, long long V, long long R, float* __restrict__ ray,
+                                  float* __restrict__ center) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * R * 3) return;
+    const long long v = i / (3 * R), rem = i - v * 3 * R;
+    const float g = warped[v * 6 * R + rem], c = warped[v * 6 * R + 3 * R + rem];
+    ray[i] = sub_rn(g, c);
+    center[i] = c;
+}
+
+struct CombineArgs {
+    const float* d_ray[4];      // per-ray gradients of the share [n,3], in accumulation order; NULL = route absent
+    const float* d_center[2];
+    const float* d_target;      // [V,2R,3] alignment gradient (rows of the owned views valid) or NULL
+    float* d_warped;            // [V,2R,3]
+    long long V, R, a, b;       // window views, rays per view, the share as [a, b) of the window's flattened rays
+    int own_lo, own_hi;         // owned views, window-local
+    float w_align;
+    // latent rows outside the window
+    float* d_latent;
+    long long lat_lo, lat_hi, lat_n;   // floats [lat_lo, lat_hi) are the window's rows of the lat_n-float table
+    // loss total
+    float* loss;
+    float w[3];
+    int present[3];             // term k was computed by the LOSS stage (else it is written as 0 here)
+};
+
+__global__ void combine_kernel(CombineArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.V * a.R * 3) {
+        const long long v = i / (3 * a.R), rem = i - v * 3 * a.R, q = i / 3;
+        float g = 0.f, c = 0.f;
+        if (q >= a.a && q < a.b) {
+            const long long j = i - a.a * 3;
+            float dr = 0.f, dc = 0.f;
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (a.d_ray[k]) { dr = first ? a.d_ray[k][j] : add_rn(dr, a.d_ray[k][j]); first = false; }
+            first = true;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (a.d_center[k]) { dc = first ? a.d_center[k][j] : add_rn(dc, a.d_center[k][j]); first = false; }
+            g = dr;                       // d grid   = d ray
+            c = sub_rn(dc, dr);           // d centre = d centre - d ray        (ray = grid - centre)
+        }
+        if (a.d_target && v >= a.own_lo && v < a.own_hi) {
+            g = add_rn(g, mul_rn(a.d_target[v * 6 * a.R + rem], a.w_align));
+            c = add_rn(c, mul_rn(a.d_target[v * 6 * a.R + 3 * a.R + rem], a.w_align));
+        }
+        a.d_warped[v * 6 * a.R + rem] = g;
+        a.d_warped[v * 6 * a.R + 3 * a.R + rem] = c;
+    }
+    if (a.d_latent && i < a.lat_n && (i < a.lat_lo || i >= a.lat_hi)) a.d_latent[i] = 0.f;
+    if (i == 0) {
+        float total = 0.f;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!a.present[k]) { a.loss[k] = 0.f; continue; }      // absent term (weight `null`, no fine pass, no owned view): reported as 0
+            total = first ? mul_rn(a.loss[k], a.w[k]) : fmaf(a.w[k], a.loss[k], total);
+            first = false;
+        }
+        a.loss[3] = total;
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int fill(float* p, long long n, float v, hipStream_t st) {
+    fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p, n, v);
+    NIW_LAUNCH_CHECK("niw_train_step (fill)");
+    return NIW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- Adam, all groups
+constexpr int kMaxAdamGroups = 8;
+struct AdamGroupDev {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    float step_size, bc2_sqrt;
+    int first_block;
+};
+struct AdamBatch {
+    AdamGroupDev g[kMaxAdamGroups];
+    int n_groups;
+    float w1, b2, w2, eps;
+};
+
+__global__ void adam_multi_kernel(AdamBatch b, const float* __restrict__ hyper_dev) {
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxAdamGroups; ++k)
+        if (k < b.n_groups && (int)blockIdx.x >= b.g[k].first_block) gi = k;
+    const AdamGroupDev& G = b.g[gi];
+    const long long i = (long long)((int)blockIdx.x - G.first_block) * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    float step_size = G.step_size, bc2_sqrt = G.bc2_sqrt;
+    if (hyper_dev) { step_size = hyper_dev[2 * gi]; bc2_sqrt = hyper_dev[2 * gi + 1]; }
+    // the arithmetic of adam_kernel (niw_sampling.hip) = torch.optim.Adam's single-tensor path, element for element
+    const float gr = G.g[i];
+    const float mi = G.m[i] + b.w1 * (gr - G.m[i]);
+    const float vi = G.v[i] * b.b2 + (b.w2 * gr) * gr;
+    G.m[i] = mi; G.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + b.eps;
+    G.p[i] -= step_size * (mi / denom);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- workspace layout
+struct Layout {
+    long long V, R, n, S, T, mpad_c, mpad_f;
+    int n_own;
+    float *ray_idx, *stacked_in, *warped, *xin, *w_emb, *view_b, *w_head, *prep_ws, *ray, *center;
+    float *z, *rgb_s, *sigma_s, *prob, *rgb, *depth, *opacity;
+    float *z_all, *rgb_f, *sigma_f, *rgb_fine, *depth_fine, *opacity_fine;
+    float *packed_c, *packed_f, *save_c, *save_f, *gradws, *partial;
+    float *d_rgb, *d_rgb_f, *d_rgb_s, *d_sigma_s, *comp_d_ray_c, *comp_d_ray_f, *mlp_d_c, *mlp_d_f;   // mlp_d_*: [2][n][3] = {d_center, d_ray}
+    float *mom, *poses, *d_target, *d_warped, *warp_ws, *d_w_emb, *d_view_b, *d_w_head, *prep_bwd_ws;
+    long long total;
+};
+
+int check_desc(const niw_train_desc* d) {
+    NIW_REQUIRE(d, "niw_train_step: null descriptor");
+    NIW_REQUIRE(d->image && d->intr && d->nerf_params && d->warp_params && d->latent, "niw_train_step: batch, field parameters, warp parameters and latent table are required");
+    NIW_REQUIRE(d->loss && d->d_nerf && d->d_warp && d->d_latent, "niw_train_step: loss and gradient outputs are required");
+    NIW_REQUIRE(d->n_views > 0 && d->n_views <= 64 && d->H > 0 && d->W > 0 && d->rays_per_view > 0, "niw_train_step: n_views=%d (1..64) H=%d W=%d rays_per_view=%lld",
+                d->n_views, d->H, d->W, (long long)d->rays_per_view);
+    NIW_REQUIRE(d->rays_per_view <= (int64_t)d->H * d->W, "niw_train_step: %lld rays per view from a %d x %d image", (long long)d->rays_per_view, d->H, d->W);
+    NIW_REQUIRE(d->n_samples > 0 && d->n_fine >= 0, "niw_train_step: n_samples=%d n_fine=%d", d->n_samples, d->n_fine);
+    NIW_REQUIRE(0 <= d->view0 && d->view0 < d->view1 && d->view1 <= d->n_views, "niw_train_step: view window [%d, %d) of %d views", d->view0, d->view1, d->n_views);
+    NIW_REQUIRE(d->view0 <= d->own0 && d->own0 <= d->own1 && d->own1 <= d->view1, "niw_train_step: owned views [%d, %d) outside the window [%d, %d)", d->own0, d->own1,
+                d->view0, d->view1);
+    NIW_REQUIRE(d->ray_lo < d->ray_hi && d->ray_lo >= (int64_t)d->view0 * d->rays_per_view && d->ray_hi <= (int64_t)d->view1 * d->rays_per_view,
+                "niw_train_step: rays [%lld, %lld) outside the window's rays [%lld, %lld)", (long long)d->ray_lo, (long long)d->ray_hi,
+                (long long)d->view0 * d->rays_per_view, (long long)d->view1 * d->rays_per_view);
+    NIW_REQUIRE(d->density_activ == NIW_ACT_RELU || d->density_activ == NIW_ACT_SOFTPLUS, "niw_train_step: unknown density activation %d", d->density_activ);
+    NIW_REQUIRE(d->precision == NIW_PREC_FP32 || d->precision == NIW_PREC_BF16X3 || d->precision == NIW_PREC_BF16, "niw_train_step: unknown precision %d", d->precision);
+    NIW_REQUIRE(d->mse_norm > 0, "niw_train_step: mse_norm must be the element count of the photometric mean");
+    if (d->n_fine > 0) {
+        NIW_REQUIRE(d->nerf_fine_params && d->d_nerf_fine && d->unif && d->bins, "niw_train_step: the fine pass needs nerf_fine_params, d_nerf_fine and the two inverse-CDF tables");
+        NIW_REQUIRE(d->n_samples + d->n_fine <= 1024, "niw_train_step: S+Sf=%d exceeds 1024", d->n_samples + d->n_fine);
+    }
+    const long long n = d->ray_hi - d->ray_lo, T = d->n_fine > 0 ? d->n_samples + d->n_fine : d->n_samples;
+    if (niw_mlp_padded_rows(n, (int)T) * 288ll * 4 >= (1ll << 31)) {
+        niw_set_error("niw_train_step: %lld rays x %lld samples exceed one differentiable field launch (1.86 M samples); split the batch over the autograd mirror", n, T);
+        return NIW_ERR_UNSUPPORTED;
+    }
+    return NIW_OK;
+}
+
+Layout make_layout(const niw_train_desc* d, float* base) {
+    Layout L{};
+    L.V = d->view1 - d->view0; L.R = d->rays_per_view; L.n = d->ray_hi - d->ray_lo; L.S = d->n_samples;
+    L.T = d->n_fine > 0 ? d->n_samples + d->n_fine : 0;
+    L.n_own = d->own1 - d->own0;
+    L.mpad_c = niw_mlp_padded_rows(L.n, (int)L.S);
+    L.mpad_f = L.T ? niw_mlp_padded_rows(L.n, (int)L.T) : 0;
+    const long long P = L.V * 2 * L.R, n = L.n, S = L.S, T = L.T, M = T > S ? T : S;
+    Carve ws{base};
+    L.ray_idx = ws.take(2 * L.R);                      // int64 [R]
+    L.stacked_in = ws.take(3 * P); L.warped = ws.take(3 * P); L.xin = ws.take(9 * P);
+    L.w_emb = ws.take(NIW_WARP_WEMB_FLOATS); L.view_b = ws.take(L.V * 3 * 2 * 128); L.w_head = ws.take(NIW_WARP_WHEAD_FLOATS);
+    L.prep_ws = ws.take(niw_warp_prep_fwd_workspace_floats((int)L.V));
+    L.ray = ws.take(3 * L.V * L.R); L.center = ws.take(3 * L.V * L.R);
+    L.z = ws.take(n * S); L.rgb_s = ws.take(3 * n * S); L.sigma_s = ws.take(n * S); L.prob = ws.take(n * S);
+    L.rgb = ws.take(3 * n); L.depth = ws.take(n); L.opacity = ws.take(n);
+    if (T) {
+        L.z_all = ws.take(n * T); L.rgb_f = ws.take(3 * n * T); L.sigma_f = ws.take(n * T);
+        L.rgb_fine = ws.take(3 * n); L.depth_fine = ws.take(n); L.opacity_fine = ws.take(n);
+    }
+    const long long packed = (niw_mlp_packed_bytes(d->precision) + 3) / 4;
+    L.packed_c = ws.take(packed);
+    if (T) L.packed_f = ws.take(packed);
+    L.save_c = ws.take((long long)NIW_SAVE_ROWS * L.mpad_c);
+    if (T) L.save_f = ws.take((long long)NIW_SAVE_ROWS * L.mpad_f);
+    L.gradws = ws.take((long long)NIW_GRAD_ROWS * (L.mpad_f > L.mpad_c ? L.mpad_f : L.mpad_c));
+    L.partial = ws.take(niw_mlp_bwd_workspace_floats(n, (int)M));
+    L.d_rgb = ws.take(3 * n);
+    if (T) L.d_rgb_f = ws.take(3 * n);
+    L.d_rgb_s = ws.take(3 * n * M); L.d_sigma_s = ws.take(n * M);
+    L.comp_d_ray_c = ws.take(3 * n); L.mlp_d_c = ws.take(6 * n);
+    if (T) { L.comp_d_ray_f = ws.take(3 * n); L.mlp_d_f = ws.take(6 * n); }
+    L.mom = ws.take(2 * 16 * L.V);                     // double [V,16]
+    L.poses = ws.take(12 * L.V);
+    L.d_target = ws.take(3 * P); L.d_warped = ws.take(3 * P);
+    L.warp_ws = ws.take(niw_warp_bwd_workspace_floats((int)L.V, 2 * L.R));
+    L.d_w_emb = ws.take(NIW_WARP_WEMB_FLOATS); L.d_view_b = ws.take(L.V * 3 * 2 * 128); L.d_w_head = ws.take(NIW_WARP_WHEAD_FLOATS);
+    L.prep_bwd_ws = ws.take(niw_warp_prep_bwd_workspace_floats((int)L.V));
+    L.total = ws.used;
+    return L;
+}
+
+int pack(const niw_train_desc* d, const float* params, float* image, niw_stream_t stream) {
+    if (d->precision != NIW_PREC_FP32) return niw_mlp_pack_weights_prec(params, d->precision, image, stream);
+    return d->pack_index ? niw_mlp_pack_weights_indexed(params, d->pack_index, image, stream) : niw_mlp_pack_weights(params, image, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t niw_train_step_workspace_floats(const niw_train_desc* d) {
+    if (check_desc(d) != NIW_OK) return 0;
+    return make_layout(d, nullptr).total;
+}
+
+#define NIW_RUN(call)                    \
+    do {                                 \
+        const int rc_ = (call);          \
+        if (rc_ != NIW_OK) return rc_;   \
+    } while (0)
+
+extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int stage_begin, int stage_end, niw_stream_t stream) {
+    NIW_RUN(check_desc(d));
+    NIW_REQUIRE(workspace, "niw_train_step: null workspace");
+    NIW_REQUIRE(0 <= stage_begin && stage_begin < stage_end && stage_end <= NIW_STAGE_END, "niw_train_step: stages [%d, %d) of %d", stage_begin, stage_end, (int)NIW_STAGE_END);
+    const Layout L = make_layout(d, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = L.n, R = L.R, V = L.V;
+    const int S = (int)L.S, T = (int)L.T;
+    const long long a = d->ray_lo - (long long)d->view0 * R;                 // the share inside the window's flattened rays
+    const float* ray = L.ray + 3 * a;
+    const float* center = L.center + 3 * a;
+    const int64_t* ray_idx = reinterpret_cast<const int64_t*>(L.ray_idx);
+    const bool fine = T > 0;
+    const bool loss_c = d->w_render >= 0.f, loss_f = fine && d->w_render_fine >= 0.f, align = d->w_align >= 0.f;
+    const bool registration = align || d->always_register;
+    float* poses = d->poses ? d->poses + 12ll * d->view0 : L.poses;
+    float* rgb = d->rgb ? d->rgb : L.rgb;
+    float* rgb_fine = d->rgb_fine ? d->rgb_fine : L.rgb_fine;
+    const long long own_off = d->own0 - d->view0;
+    auto in = [&](int s) { return stage_begin <= s && s < stage_end; };
+
+    if (in(NIW_STAGE_RAYS)) {
+        NIW_RUN(niw_draw_ray_idx((int64_t)d->H * d->W, R, d->pixel_seed, d->draw, d->draw_dev, 0, 1, reinterpret_cast<int64_t*>(L.ray_idx), stream));
+        NIW_RUN(niw_launch_raygen_stacked(d->intr + 9ll * d->view0, d->pose_init ? d->pose_init + 12ll * d->view0 : nullptr, ray_idx, (int)V, R, d->H, d->W,
+                                          L.stacked_in, st));
+    }
+    if (in(NIW_STAGE_WARP_FWD)) {
+        NIW_RUN(niw_warp_prep_fwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.prep_ws, L.w_emb, L.view_b, L.w_head, stream));
+        NIW_RUN(niw_warp_fwd(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window, nullptr,
+                             nullptr, 0, L.warped, L.xin, stream));
+        split_rays_kernel<<<(unsigned)((V * R * 3 + 255) / 256), 256, 0, st>>>(L.warped, V, R, L.ray, L.center);
+        NIW_LAUNCH_CHECK("niw_train_step (split rays)");
+    }
+    if (in(NIW_STAGE_SAMPLE)) {
+        if (d->stratified)
+            NIW_RUN(niw_sample_stratified_rng(d->depth_seed, d->draw, d->draw_dev, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, nullptr, stream));
+        else
+            NIW_RUN(niw_sample_stratified(nullptr, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, stream));
+    }
+    if (in(NIW_STAGE_PACK)) {
+        NIW_RUN(pack(d, d->nerf_params, L.packed_c, stream));
+        if (fine) NIW_RUN(pack(d, d->nerf_fine_params, L.packed_f, stream));
+    }
+    if (in(NIW_STAGE_MLP_FWD))
+        NIW_RUN(niw_mlp_fwd(L.packed_c, center, ray, L.z, nullptr, n, S, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_s, L.sigma_s,
+                            (loss_c ? L.save_c : nullptr), stream));
+    if (in(NIW_STAGE_COMPOSITE_FWD))
+        NIW_RUN(niw_composite_fwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, rgb, L.depth, L.opacity, L.prob, stream));
+    if (fine) {
+        if (in(NIW_STAGE_RESAMPLE)) NIW_RUN(niw_sample_pdf_merge(L.prob, L.z, d->unif, d->bins, n, S, d->n_fine, nullptr, L.z_all, stream));
+        if (in(NIW_STAGE_MLP_FWD_FINE))
+            NIW_RUN(niw_mlp_fwd(L.packed_f, center, ray, L.z_all, nullptr, n, T, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_f,
+                                L.sigma_f, (loss_f ? L.save_f : nullptr), stream));
+        if (in(NIW_STAGE_COMPOSITE_FWD_FINE))
+            NIW_RUN(niw_composite_fwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, rgb_fine, L.depth_fine, L.opacity_fine, nullptr, stream));
+    }
+    if (in(NIW_STAGE_LOSS)) {
+        const int64_t hw = (int64_t)d->H * d->W;
+        if (loss_c) NIW_RUN(niw_mse_fwd_bwd(rgb, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render, d->loss + 0, L.d_rgb, stream));
+        if (loss_f) NIW_RUN(niw_mse_fwd_bwd(rgb_fine, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render_fine, d->loss + 1, L.d_rgb_f, stream));
+        if (registration) {
+            // rigid registration of the warped onto the un-warped points, whole views: no collective under sharding either
+            NIW_RUN(niw_align_moments(L.warped, L.stacked_in, (int)V, 2 * R, reinterpret_cast<double*>(L.mom), stream));
+            NIW_RUN(niw_align_solve(reinterpret_cast<const double*>(L.mom), (int)V, poses, stream));
+        }
+        if (align && L.n_own > 0)
+            NIW_RUN(niw_align_loss(L.warped + own_off * 6 * R, L.stacked_in + own_off * 6 * R, poses + own_off * 12, L.n_own, 2 * R, 3.0 * d->n_views * 2.0 * (double)R,
+                                   d->loss + 2, L.d_target + own_off * 6 * R, stream));
+    }
+    if (fine) {
+        if (loss_f) {
+            if (in(NIW_STAGE_COMPOSITE_BWD_FINE))
+                NIW_RUN(niw_composite_bwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, L.d_rgb_f, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
+            if (in(NIW_STAGE_MLP_BWD_DX_FINE))
+                NIW_RUN(niw_mlp_bwd_dx(L.packed_f, center, ray, L.z_all, n, T, d->density_activ, d->precision, L.rgb_f, L.d_rgb_s, L.d_sigma_s, L.save_f, L.gradws,
+                                       L.mlp_d_f, L.mlp_d_f + 3 * n, stream));
+            if (in(NIW_STAGE_MLP_BWD_DW_FINE)) NIW_RUN(niw_mlp_bwd_dw(L.save_f, L.gradws, n, T, d->precision, L.partial, d->d_nerf_fine, stream));
+        } else if (in(NIW_STAGE_MLP_BWD_DW_FINE)) {
+            NIW_RUN(fill(d->d_nerf_fine, NIW_NERF_PARAM_FLOATS, 0.f, st));
+        }
+    }
+    if (loss_c) {
+        if (in(NIW_STAGE_COMPOSITE_BWD))
+            NIW_RUN(niw_composite_bwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, L.d_rgb, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_c, stream));
+        if (in(NIW_STAGE_MLP_BWD_DX))
+            NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, L.d_rgb_s, L.d_sigma_s, L.save_c, L.gradws, L.mlp_d_c,
+                                   L.mlp_d_c + 3 * n, stream));
+        if (in(NIW_STAGE_MLP_BWD_DW)) NIW_RUN(niw_mlp_bwd_dw(L.save_c, L.gradws, n, S, d->precision, L.partial, d->d_nerf, stream));
+    } else if (in(NIW_STAGE_MLP_BWD_DW)) {
+        NIW_RUN(fill(d->d_nerf, NIW_NERF_PARAM_FLOATS, 0.f, st));
+    }
+    if (in(NIW_STAGE_WARP_BWD)) {
+        CombineArgs c{};
+        // accumulation order of autograd on the shared `ray` / `center` tensors: fine compositing, fine field, coarse compositing, coarse field
+        c.d_ray[0] = loss_f ? L.comp_d_ray_f : nullptr; c.d_ray[1] = loss_f ? L.mlp_d_f + 3 * n : nullptr;
+        c.d_ray[2] = loss_c ? L.comp_d_ray_c : nullptr; c.d_ray[3] = loss_c ? L.mlp_d_c + 3 * n : nullptr;
+        c.d_center[0] = loss_f ? L.mlp_d_f : nullptr; c.d_center[1] = loss_c ? L.mlp_d_c : nullptr;
+        c.d_target = (align && L.n_own > 0) ? L.d_target : nullptr;
+        c.d_warped = L.d_warped;
+        c.V = V; c.R = R; c.a = a; c.b = a + n;
+        c.own_lo = (int)own_off; c.own_hi = (int)own_off + L.n_own;
+        c.w_align = d->w_align;
+        c.d_latent = d->d_latent; c.lat_lo = 128ll * d->view0; c.lat_hi = 128ll * d->view1; c.lat_n = 128ll * d->n_views;
+        c.loss = d->loss;
+        c.w[0] = d->w_render; c.w[1] = d->w_render_fine; c.w[2] = d->w_align;
+        c.present[0] = loss_c; c.present[1] = loss_f; c.present[2] = align && L.n_own > 0;
+        const long long work = V * R * 3 > c.lat_n ? V * R * 3 : c.lat_n;
+        combine_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(c);
+        NIW_LAUNCH_CHECK("niw_train_step (combine)");
+        NIW_RUN(niw_warp_bwd(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window, nullptr, nullptr,
+                             L.xin, L.d_warped, L.warp_ws, L.d_w_emb, L.d_view_b, L.d_w_head, nullptr, stream));
+        NIW_RUN(niw_warp_prep_bwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.d_w_emb, L.d_view_b, L.d_w_head, L.prep_bwd_ws, d->d_warp,
+                                  d->d_latent + 128ll * d->view0, stream));
+    }
+    return NIW_OK;
+}
+
+extern "C" int niw_adam_step_multi(const niw_adam_group* groups, int n_groups, double beta1, double beta2, double eps, const float* hyper_dev,
+                                   niw_stream_t stream) {
+    NIW_REQUIRE(groups && n_groups > 0 && n_groups <= kMaxAdamGroups, "niw_adam_step_multi: 1..%d groups (got %d)", kMaxAdamGroups, n_groups);
+    AdamBatch b{};
+    b.n_groups = n_groups;
+    b.w1 = (float)(1.0 - beta1); b.b2 = (float)beta2; b.w2 = (float)(1.0 - beta2); b.eps = (float)eps;
+    int blocks = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        const niw_adam_group& g = groups[k];
+        NIW_REQUIRE(g.n >= 0, "niw_adam_step_multi: group %d has n=%lld", k, (long long)g.n);
+        NIW_REQUIRE(g.n == 0 || (g.param && g.grad && g.exp_avg && g.exp_avg_sq), "niw_adam_step_multi: null pointer in group %d", k);
+        NIW_REQUIRE(g.n == 0 || g.step >= 1 || hyper_dev, "niw_adam_step_multi: group %d step=%d", k, g.step);
+        const int step = g.step < 1 ? 1 : g.step;
+        // the scalars are formed in double like torch.optim.Adam forms them in Python floats, and rounded to fp32 once (niw_adam_step)
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        b.g[k] = AdamGroupDev{g.param, g.grad, g.exp_avg, g.exp_avg_sq, g.n, (float)(g.lr / bc1), (float)sqrt(bc2), blocks};
+        blocks += (int)((g.n + 255) / 256);
+    }
+    if (blocks == 0) return NIW_OK;
+    adam_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(b, hyper_dev);
+    NIW_LAUNCH_CHECK("niw_adam_step_multi");
+    return NIW_OK;
+}

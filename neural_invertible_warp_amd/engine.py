@@ -14,6 +14,9 @@ import math
 
 import torch
 
+import ctypes
+
+from . import _lib as _lib_mod
 from . import ops, parallel
 from ._lib import NiwError
 from .util import edict
@@ -35,6 +38,7 @@ class StepConstants:
         f = lambda buf, off, n: buf[off:off + 4 * n].view(torch.float32)
         self.band, self.window = f(self.dev, self.BAND, 14), f(self.dev, self.WINDOW, 12)
         self.hyper = [f(self.dev, self.HYPER + 8 * g, 2) for g in range(n_groups)]
+        self.hyper_all = f(self.dev, self.HYPER, 2 * n_groups)                 # [n_groups][2], what niw_adam_step_multi reads
         self.draw = self.dev[self.DRAW:self.DRAW + 8].view(torch.int64)
 
     def upload(self, band, window, hyper, draw):
@@ -63,12 +67,220 @@ def _sched_gamma(lr0, lr_end, sched, max_iter, what):
     return float(sched.get("gamma") or 1.0)
 
 
+
+class FusedStep:
+    """One train iteration of an INN trainer -- forward, losses, backward of every stage -- as ONE library call (niw_train_step,
+    csrc/niw_step.hip) into ONE persistent workspace: no autograd tape, no torch arithmetic, no allocation inside the iteration.  It
+    runs the same kernels with the same launch shapes as the autograd mirror (Graph.forward + compute_loss + backward over ..ops), and
+    sums the gradient routes in autograd's order, so the two train bit for bit alike (tests/test_gpu_fused_step.py); the mirror stays
+    the reference-shaped interface of a stand-alone Graph and the fallback for what the call does not cover (`unsupported`)."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.ws = None                 # workspace, allocated at the first iteration (the batch fixes its size)
+        self.ring = None               # [slots, 4] loss rows: a returned loss stays valid for `slots` further iterations (eager mode)
+        self.desc = None
+        self._keep = []
+
+    @staticmethod
+    def unsupported(trainer):
+        """-> None when niw_train_step covers this trainer's configuration, else the reason (the autograd mirror then runs)"""
+        from .model import nerf_inn_llff
+        opt = trainer.opt
+        if torch.device(opt.device).type != "cuda":
+            return "no GPU"
+        if opt.nerf.ray_sampler != "feistel":
+            return "ray_sampler is not 'feistel' (draws injected through torch.randperm)"
+        if opt.nerf.sample_stratified and opt.nerf.stratified_rng != "philox":
+            return "stratified draws injected through torch.rand"
+        if opt.camera.ndc:
+            return "camera.ndc (the gradient through the NDC reparametrisation runs as torch algebra)"
+        if opt.nerf.density_noise_reg:
+            return "nerf.density_noise_reg"
+        if opt.nerf.setbg_opaque:
+            return "nerf.setbg_opaque"
+        if opt.data.dataset == "blender":
+            return "blender initial poses"
+        if nerf_inn_llff.ALIGN_BACKEND is not None:
+            return "a test backend of the alignment term is plugged in"
+        if trainer.n_views > 64:
+            return "more than 64 views"
+        if len({n._state.precision for n in trainer.nets}) != 1:
+            return "networks of different precision"
+        if not opt.nerf.rand_rays:
+            return "nerf.rand_rays unset"
+        return None
+
+    # ------------------------------------------------------------------ descriptor
+    def _weights(self):
+        lw = self.tr.opt.loss_weight
+        w = lambda k: -1.0 if lw.get(k) is None else 10 ** float(lw[k])
+        return w("render"), w("render_fine"), w("global_alignment")
+
+    def _build(self, var):
+        tr, opt = self.tr, self.tr.opt
+        g = tr.graph
+        B = len(var.idx)
+        if B != tr.n_views:
+            raise NiwError(f"train_iteration: the batch holds {B} views, the trainer was built for {tr.n_views}")
+        R = opt.nerf.rand_rays // B
+        win = g.view_window(opt, B, R)
+        g._last_window = win
+        S = opt.nerf.sample_intvs
+        Sf = (opt.nerf.sample_intvs_fine or 0) if opt.nerf.fine_sampling else 0
+        dev = var.image.device
+        image, intr = ops._f32(var.image, "var.image"), ops._f32(var.intr, "var.intr")
+        if image.shape[0] != B or image.shape[-1] * image.shape[-2] != opt.H * opt.W:
+            raise NiwError(f"train_iteration: var.image is {tuple(image.shape)}, expected [{B},3,{opt.H},{opt.W}]")
+        d = _lib_mod.TrainDesc()
+        d.image, d.intr = image.data_ptr(), intr.data_ptr()
+        self._keep = [image, intr]
+        if tr.family == "dtu":
+            pose_init = ops._f32(tr.pose_net.initial_poses_w2c, "initial_poses_w2c")
+            self._keep.append(pose_init)
+            d.pose_init = pose_init.data_ptr()
+            if opt.nerf.depth.param == "inverse":
+                rng = opt.nerf.depth.range
+            else:
+                rng = g._host_depth_range(var.depth_range)
+        else:
+            rng = opt.nerf.depth.range
+        d.n_views, d.H, d.W, d.rays_per_view = B, opt.H, opt.W, R
+        if win is None:
+            d.view0, d.view1, d.own0, d.own1, d.ray_lo, d.ray_hi = 0, B, 0, B, 0, B * R
+        else:
+            d.view0, d.view1, d.own0, d.own1, d.ray_lo, d.ray_hi = win.v0, win.v1, win.own0, win.own1, win.lo, win.hi
+        n = d.ray_hi - d.ray_lo
+        if n <= 0:
+            raise NiwError("train_iteration: this rank's share of the rays is empty (more ranks than rays)")
+        d.stratified = 1 if opt.nerf.sample_stratified else 0
+        seed = int(getattr(opt, "seed", 0) or 0)
+        rank = (getattr(opt, "ray_shard", None) or (0, 1))[0]
+        d.pixel_seed = seed & (2 ** 64 - 1)
+        d.depth_seed = (seed * 0x9E3779B97F4A7C15 + 0x5D1F + rank * 0xD1B54A32D192ED03) & (2 ** 64 - 1)      # model/nerf.py Graph.sample_depth, call 0
+        d.n_samples, d.n_fine = S, Sf
+        d.inverse_depth = 1 if opt.nerf.depth.param == "inverse" else 0
+        d.density_activ = ops.ACT[opt.arch.density_activ]
+        d.depth_min, d.depth_max = float(rng[0]), float(rng[1])
+        if Sf:
+            unif, bins = ops._pdf_tables(S, Sf, opt.nerf.depth.range, dev)          # bins: the yaml range, also for DTU (nerf_inn_dtu.py:549)
+            d.unif, d.bins = unif.data_ptr(), bins.data_ptr()
+        d.precision = ops.PREC[tr.nets[0]._state.precision]
+        if d.precision == 0:
+            d.pack_index = ops.pack_index(dev).data_ptr()
+        d.use_index_window = 1 if tr.warp_mlp.reference_exact else 0
+        d.w_render, d.w_render_fine, d.w_align = self._weights()
+        if not Sf:
+            d.w_render_fine = -1.0
+        d.always_register = 1 if tr.family == "dtu" else 0
+        d.mse_norm = float(getattr(opt, "loss_norm_elements", None) or 3 * B * R)
+        if tr.family == "dtu":
+            table = tr.pose_net.pose_global.weight
+        else:
+            table = g.global_rigid.weight if hasattr(g, "global_rigid") else None
+        self.pose_table = table
+        self.rgb = torch.empty(n, 3, device=dev)
+        self.rgb_fine = torch.empty(n, 3, device=dev) if Sf else None
+        d.rgb, d.rgb_fine = self.rgb.data_ptr(), (self.rgb_fine.data_ptr() if Sf else None)
+        self.shape = (B, R, S, Sf, n, win)
+        self.desc = d
+        self._refresh(var)
+        floats = _lib_mod.load().niw_train_step_workspace_floats(ctypes.byref(d))
+        if floats <= 0:
+            raise NiwError("niw_train_step: " + _lib_mod.load().niw_last_error_string().decode())
+        self.ws = torch.empty(floats, device=dev, dtype=torch.float32)
+        slots = 1 if tr.hip_graph else 64
+        self.ring = torch.zeros(slots, 4, device=dev)
+
+    def _refresh(self, var):
+        """the members that can change between two iterations without a new descriptor: parameter / gradient / table storage"""
+        tr, d = self.tr, self.desc
+        tr._install_grad_sinks()
+        n_nets = len(tr.nets)
+        d.nerf_params, d.d_nerf = tr.nets[0].flat_params.data_ptr(), tr.bucket.segment(0).data_ptr()
+        if n_nets > 1:
+            d.nerf_fine_params, d.d_nerf_fine = tr.nets[1].flat_params.data_ptr(), tr.bucket.segment(1).data_ptr()
+        d.warp_params, d.d_warp = tr.warp_mlp.flat_params.data_ptr(), tr.bucket.segment(n_nets).data_ptr()
+        latent = tr.warp_latent.weight
+        if not latent.is_contiguous():
+            raise NiwError("the latent table must be contiguous")
+        d.latent, d.d_latent = latent.data_ptr(), tr.bucket.segment(n_nets + 1).data_ptr()
+        table = self.pose_table
+        d.poses = None if table is None else table.data.data_ptr()
+
+    def _same_batch(self, var):
+        B, R, S, Sf, n, win = self.shape
+        opt = self.tr.opt
+        return (len(var.idx) == B and opt.nerf.rand_rays // B == R and opt.nerf.sample_intvs == S and var.image.data_ptr() == self.desc.image
+                and var.intr.data_ptr() == self.desc.intr and self._weights()[2] == self.desc.w_align and self._weights()[0] == self.desc.w_render)
+
+    # ------------------------------------------------------------------ one iteration
+    def run(self, var, it):
+        """forward + backward of 0-based iteration `it` on the resident batch -> loss edict (views of a device row: render[, render_fine]
+        [, global_alignment], all); the gradients of all optimizer groups are in the trainer's bucket afterwards"""
+        tr, opt = self.tr, self.tr.opt
+        if self.desc is None or not self._same_batch(var):
+            self._build(var)
+        else:
+            self._refresh(var)
+        d = self.desc
+        from .model.nvp import nvp_ndr
+        net = tr.nets[0]
+        consts = tr.consts if tr.hip_graph else None
+        b3, bv = ops._farr(net.band_weights(opt, ops.L3D), ops.L3D), ops._farr(net.band_weights(opt, ops.LVIEW), ops.LVIEW)
+        chan_w, index_window = tr.warp_mlp._anneal(float(nvp_ndr.embedding_anneal_ratio(opt, it)))
+        cw = ops._farr(chan_w, 6)
+        iw = None if index_window is None else ops._farr(index_window, 6)
+        fp = ctypes.POINTER(ctypes.c_float)
+        d.band_w3d, d.band_wview = ctypes.cast(b3, fp), ctypes.cast(bv, fp)
+        d.chan_w = ctypes.cast(cw, fp)
+        d.index_window = ctypes.cast(iw, fp) if iw is not None else None
+        d.band_dev = None if consts is None else consts.band.data_ptr()
+        d.window_dev = None if consts is None else consts.window.data_ptr()
+        d.draw_dev = None if consts is None else consts.draw.data_ptr()
+        d.draw = int(it) + 1
+        row = self.ring[0 if consts is not None else it % self.ring.shape[0]]
+        d.loss = row.data_ptr()
+        B, R, S, Sf, n, win = self.shape
+        st = ops._stream()
+        if ops.TIMING.enabled:
+            # per-stage device events (bench.py's kernel table): the same call, stage by stage
+            units = {"mlp_fwd": n * S, "mlp_bwd_dx": n * S, "mlp_bwd_dw": n * S, "composite_fwd": n * S, "composite_bwd": n * S,
+                     "mlp_fwd_fine": n * (S + Sf), "mlp_bwd_dx_fine": n * (S + Sf), "mlp_bwd_dw_fine": n * (S + Sf), "composite_fwd_fine": n * (S + Sf),
+                     "composite_bwd_fine": n * (S + Sf)}
+            alias = {"mlp_fwd": "mlp_fwd_train", "mlp_fwd_fine": "mlp_fwd_train"}
+            for k, name in enumerate(_lib_mod.TRAIN_STAGES):
+                if name.endswith("_fine") and not Sf or name == "resample" and not Sf:
+                    continue
+                base = name[:-5] if name.endswith("_fine") else name
+                with ops.timed(alias.get(name, base), units.get(name, n)):
+                    _lib_mod.call("niw_train_step", ctypes.byref(d), ops._p(self.ws), k, k + 1, st)
+        else:
+            _lib_mod.call("niw_train_step", ctypes.byref(d), ops._p(self.ws), 0, len(_lib_mod.TRAIN_STAGES), st)
+        loss = edict()
+        if d.w_render >= 0:
+            loss.render = row[0]
+        if d.w_render_fine >= 0:
+            loss.render_fine = row[1]
+        if d.w_align >= 0:
+            loss.global_alignment = row[2]
+        loss.all = row[3]
+        var.rgb = self.rgb.view(B, R, 3) if win is None else self.rgb.view(1, n, 3)
+        if Sf:
+            var.rgb_fine = self.rgb_fine.view(B, R, 3) if win is None else self.rgb_fine.view(1, n, 3)
+        var.view_window = win
+        return loss
+
+
 class INNTrainer:
-    def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None, ray_sampler=None, hip_graph=False):
+    def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None, ray_sampler=None, hip_graph=False,
+                 fused_step="auto"):
         """ray_sampler: "feistel" (one sort-free launch, default on the GPU) or "randperm" (the reference's torch.randperm call).
         hip_graph: capture the whole iteration (forward, backward, gradient gather, Adam) into a HIP graph after two eager
         steps and replay it from then on -- one graph launch + one 256-byte constants upload per step instead of ~140 launches;
-        needs inputs that stay at the same device addresses from step to step (the engine's resident `var` tensors do)."""
+        needs inputs that stay at the same device addresses from step to step (the engine's resident `var` tensors do).
+        fused_step: "auto" (default) runs the iteration as one niw_train_step call (FusedStep) wherever that call covers the
+        configuration and through the autograd mirror elsewhere; True insists (NiwError otherwise); False = always the mirror."""
         self.opt, self.rank, self.world, self.n_views = opt, rank, world, n_views
         o = opt.optim
         if o.get("algo", "Adam") != "Adam":
@@ -133,6 +345,14 @@ class INNTrainer:
                 raise NiwError("hip_graph=True needs ray_sampler='feistel' (torch.randperm cannot be replayed with a fresh draw)")
             self.consts = StepConstants(dev, len(self.bucket.groups))
         self._bind_constants(False)                      # outside a train iteration the modules read host state (see _bind_constants)
+        self.fused = None
+        if fused_step:
+            why = FusedStep.unsupported(self)
+            if why is None:
+                self.fused = FusedStep(self)
+            elif fused_step is True:
+                raise NiwError(f"fused_step=True: niw_train_step does not cover this configuration ({why})")
+        self.fused_fallback_reason = None if self.fused is not None else (FusedStep.unsupported(self) if fused_step else "fused_step=False")
         if world > 1 or parallel.FORCE_COLLECTIVES:      # (a forced one-rank group shards 1-way: same arithmetic, collectives issued)
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)
@@ -185,6 +405,8 @@ class INNTrainer:
 
     def _forward_backward(self, var, it):
         opt = self.opt
+        if self.fused is not None:
+            return self.fused.run(var, it)
         self._install_grad_sinks()
         self._bind_constants(True)
         try:
@@ -217,10 +439,11 @@ class INNTrainer:
         torch.autograd.backward([loss[k] for k in keys], [self._loss_w[k][1] for k in keys])
 
     def _optimizer_step(self, it):
-        for i, flat in enumerate(self._flats()):
-            if self.trainable[i]:
-                ops.adam_step(flat, self.bucket.segment(i), self.m[i], self.v[i], self.learning_rate(i, it), it + 1,
-                              hyper_dev=self.consts.hyper[i] if self.hip_graph else None)
+        """torch.optim.Adam's update of every trained group (reference nerf.py:34-38, barf_inn_llff.py:84-104: two optimizers stepped one
+        after the other) as ONE launch over the flat buffers"""
+        groups = [(flat, self.bucket.segment(i), self.m[i], self.v[i], self.learning_rate(i, it), it + 1) if self.trainable[i] else None
+                  for i, flat in enumerate(self._flats())]
+        ops.adam_step_multi(groups, hyper_dev=self.consts.hyper_all if self.hip_graph else None)
 
     def _upload_constants(self, it):
         """the scalars of 0-based iteration `it` (progress it / max_iter was set after the previous step, barf_inn_llff.py:117)"""
@@ -245,16 +468,24 @@ class INNTrainer:
         self.it = it + 1
         for n in self.nets:
             if hasattr(n, "set_progress"):
-                n.set_progress(self.it / self.opt.max_iter, device_copy=not self.hip_graph)
+                # (host copy only: the kernels take the bands by value / from the step constants; the Parameter itself is written when
+                # state is read, sync_state() -- a fill launch per network and step otherwise)
+                n.set_progress(self.it / self.opt.max_iter, device_copy=False)
         return loss
 
     def _graph_iteration(self, var, it, replay=True):
         self._upload_constants(it)
-        if self._captured is not None and replay:
-            self._check_static_inputs(var)             # (a capture made in THIS call replays the var it has just recorded)
+        # the iteration -- warm-up, capture and every replay alike -- reads the trainer's PRIVATE copies of the batch tensors, in place
+        if getattr(self, "_static_inputs", None) is None:
+            mine = self._private_batch(var)
+        else:
+            self._check_static_inputs(var)
+            mine = type(var)(var)
+            for k, (t, _) in self._static_inputs.items():
+                mine[k] = t
         if self._captured is None or not replay:
             self._eager_runs = getattr(self, "_eager_runs", 0)
-            if not replay or self._eager_runs < 2 or not self._capture(var, it):
+            if not replay or self._eager_runs < 2 or not self._capture(mine, it):
                 # (two launch-by-launch iterations of THIS trainer come first, whatever `it` is: a resumed run starts at a large one)
                 self._eager_runs += 1
                 # warm-up (allocator, lazily built tables, kernel attributes) and fall-back: the same body, launch by launch, on the
@@ -262,7 +493,7 @@ class INNTrainer:
                 side = self._side_stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    loss = self._forward_backward(var, it)
+                    loss = self._forward_backward(mine, it)
                     self.bucket.all_reduce()
                     self._optimizer_step(it)
                 torch.cuda.current_stream().wait_stream(side)
@@ -319,8 +550,7 @@ class INNTrainer:
         live_group = parallel._collectives_live()
         # (round 3: no collective sits inside the forward any more -- the warp and the alignment term are replicated, ..parallel --
         # so a sharded iteration is captured like any other: forward + backward + gather | all-reduce, eager | Adam)
-        var = self._private_batch(var)              # the graph reads the trainer's own copies, in place, for as long as it lives
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                    # (`var` holds the trainer's own copies of the batch: the graph reads them in place)
         try:
             # ranks with a live RCCL communicator: its watchdog thread polls events while we capture, which "global" error mode
             # would treat as a capture violation

@@ -223,6 +223,30 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999
               float(beta2), float(eps), int(step), _p(hyper_dev), _stream())
 
 
+def adam_step_multi(groups, beta1=0.9, beta2=0.999, eps=1e-8, hyper_dev=None):
+    """Adam over several flat buffers in ONE launch (niw_adam_step_multi).  groups: list of (param, grad, exp_avg, exp_avg_sq, lr, step)
+    or None for a group that is not trained (it keeps its slot: hyper_dev [len(groups), 2] is indexed by position)."""
+    arr = (_lib.AdamGroup * len(groups))()
+    for k, g in enumerate(groups):
+        if g is None:
+            continue
+        param, grad, m, v, lr, step = g
+        arr[k] = _lib.AdamGroup(param=param.data_ptr(), grad=grad.data_ptr(), exp_avg=m.data_ptr(), exp_avg_sq=v.data_ptr(), n=param.numel(),
+                                lr=float(lr), step=int(step))
+    with timed("adam", sum(g[0].numel() for g in groups if g is not None)):
+        _lib.call("niw_adam_step_multi", arr, len(groups), float(beta1), float(beta2), float(eps), _p(hyper_dev), _stream())
+
+
+def pack_index(device):
+    """gather table of the packed fp32 weight layout (architecture constant, built once per device)"""
+    key = str(device)
+    if key not in FieldState._index:
+        idx = torch.empty(_lib.load().niw_mlp_packed_floats(), device=device, dtype=torch.int32)
+        _lib.call("niw_mlp_pack_index", _p(idx), _stream())
+        FieldState._index[key] = idx
+    return FieldState._index[key]
+
+
 # ------------------------------------------------------------------------------------------
 # field MLP
 # ------------------------------------------------------------------------------------------
@@ -266,13 +290,8 @@ class FieldState:
 
     def packed_fp32(self):
         n = _lib.load().niw_mlp_packed_floats()
-        key = str(self.flat.device)
-        if key not in FieldState._index:
-            idx = torch.empty(n, device=self.flat.device, dtype=torch.int32)
-            _lib.call("niw_mlp_pack_index", _p(idx), _stream())
-            FieldState._index[key] = idx
         packed = torch.empty(n, device=self.flat.device, dtype=torch.float32)
-        _lib.call("niw_mlp_pack_weights_indexed", _p(self.flat), _p(FieldState._index[key]), _p(packed), _stream())
+        _lib.call("niw_mlp_pack_weights_indexed", _p(self.flat), _p(pack_index(self.flat.device)), _p(packed), _stream())
         return packed
 
     def _pack_fast(self):

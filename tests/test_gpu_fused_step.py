@@ -1,0 +1,148 @@
+"""The engine's one-call train iteration (niw_train_step, csrc/niw_step.hip; engine.FusedStep) against the autograd mirror of the
+reference's call sequence (Graph.forward + compute_loss + backward over the per-stage entry points, `fused_step=False`): the two run
+the same kernels on the same operands and sum the gradient routes in the same order, so losses, gradients and trained parameters
+must be IDENTICAL -- unsharded and as one rank of a sharded job, LLFF and DTU, with and without the fine network, eager and as a
+captured graph.  The mirror itself is held to the oracle by tests/test_gpu_parity.py and tests/test_gpu_baseline_shapes.py.
+Needs a GPU."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=None, rays=None, S=16):
+    from neural_invertible_warp_amd import configs, engine
+    if cfg == "dtu":
+        opt = configs.cfg5_barf_inn_dtu(device=DEV)
+        B = B or 3
+        var0, init = engine.synthetic_dtu_scene(opt, B)
+    else:
+        opt = getattr(configs, cfg)(device=DEV)
+        B = B or 5
+        var0, init = engine.synthetic_scene(opt, B), None
+    opt.nerf.sample_stratified = stratified
+    opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = rays or B * 37, S, 40
+    opt.inn.real_nvp.max_pe_iter = 20                       # bands, windows and learning rates all move within the run
+    if opt.nerf.fine_sampling:
+        opt.nerf.sample_intvs_fine = S
+    tr = engine.INNTrainer(opt, B, rank=rank, world=world, warp_perturb=0.02, seed=4, initial_poses_w2c=init, hip_graph=hip_graph, fused_step=fused)
+    assert (tr.fused is not None) == bool(fused), tr.fused_fallback_reason
+    return tr, var0
+
+
+def _run(cfg, fused, steps=5, **kw):
+    tr, var0 = _trainer(cfg, fused, **kw)
+    losses = []
+    for _ in range(steps):
+        loss = tr.train_iteration(type(var0)(var0))
+        losses.append({k: float(v.detach()) for k, v in loss.items()})
+    torch.cuda.synchronize()
+    return tr, losses
+
+
+@pytest.mark.parametrize("cfg", ["cfg3_barf_inn_llff", "cfg2_nerf_inn_llff_hier", "dtu"])
+def test_fused_iteration_trains_bit_for_bit_like_the_autograd_mirror(cfg):
+    a, la = _run(cfg, False)
+    b, lb = _run(cfg, True)
+    assert [sorted(x) for x in la] == [sorted(x) for x in lb]
+    for x, y in zip(la, lb):
+        for k in x:
+            if k == "all":          # the weighted total: the mirror forms it with torch.add(alpha=), the call with one fma per term
+                assert abs(x[k] - y[k]) <= 1e-6 * max(abs(x[k]), 1e-6), (k, x[k], y[k])
+            else:
+                assert x[k] == y[k], (k, x[k], y[k])
+    assert torch.equal(a.bucket.flat, b.bucket.flat), float((a.bucket.flat - b.bucket.flat).abs().max())
+    for fa, fb in zip(a._flats(), b._flats()):
+        assert torch.equal(fa, fb)
+    for ma, mb in zip(a.m + a.v, b.m + b.v):
+        assert torch.equal(ma, mb)
+    # the registered per-view poses (global_rigid / pose_global) are refreshed by both
+    ta = a.pose_net.pose_global.weight if cfg == "dtu" else a.graph.global_rigid.weight
+    tb = b.pose_net.pose_global.weight if cfg == "dtu" else b.graph.global_rigid.weight
+    if cfg != "cfg2_nerf_inn_llff_hier":                    # (no alignment term there: the LLFF table keeps its initial identity poses)
+        assert not torch.equal(tb.data, torch.eye(3, 4, device=DEV).reshape(1, 12).repeat(tb.shape[0], 1))
+    assert torch.equal(ta.data, tb.data)
+
+
+@pytest.mark.parametrize("cfg,world", [("cfg3_barf_inn_llff", 3), ("cfg2_nerf_inn_llff_hier", 2), ("dtu", 4)])
+def test_fused_iteration_of_a_rank_equals_the_mirror_under_ray_sharding(cfg, world):
+    """every rank of a sharded job (run one after the other, no process group): window of whole views, contiguous share of the rays,
+    alignment terms of the owned views, zero latent rows outside the window"""
+    for rank in range(world):
+        outs = []
+        for fused in (False, True):
+            tr, var0 = _trainer(cfg, fused, rank=rank, world=world, stratified=False)
+            tr.it = 7
+            for n in tr.nets:
+                n.set_progress(0.3)
+            loss = tr._forward_backward(type(var0)(var0), tr.it)
+            outs.append(({k: float(v.detach()) for k, v in loss.items()}, tr.bucket.flat.clone(), tr))
+        (la, ga, ta), (lb, gb, tb) = outs
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-6 * max(abs(la[k]), 1e-6), (rank, k, la[k], lb[k])
+        assert torch.equal(ga, gb), (rank, float((ga - gb).abs().max()))
+        n_nets = len(ta.nets)
+        lat = gb[tb.bucket.offsets[n_nets + 1]:tb.bucket.offsets[n_nets + 2]].view(-1, 128)
+        win = tb.graph._last_window
+        assert bool((lat[:win.v0] == 0).all()) and bool((lat[win.v1:] == 0).all()) and float(lat[win.v0:win.v1].abs().max()) > 0
+
+
+def test_fused_iteration_stage_by_stage_equals_the_single_call():
+    """bench.py's kernel table times the stages of the call one by one (niw_train_step(stage, stage + 1)): same numbers"""
+    from neural_invertible_warp_amd import ops
+    a, la = _run("cfg2_nerf_inn_llff_hier", True, steps=3)
+    ops.TIMING.enabled = True
+    ops.TIMING.reset()
+    try:
+        b, lb = _run("cfg2_nerf_inn_llff_hier", True, steps=3)
+    finally:
+        ops.TIMING.enabled = False
+    table = ops.TIMING.summary()
+    assert la == lb and torch.equal(a.bucket.flat, b.bucket.flat)
+    for name in ("mlp_fwd_train", "mlp_bwd_dx", "mlp_bwd_dw", "composite_fwd", "composite_bwd", "rays", "warp_fwd", "warp_bwd", "loss", "pack", "adam"):
+        assert name in table and table[name][1] > 0, name
+    assert table["mlp_fwd_train"][0] == 6 and table["resample"][0] == 3          # coarse + fine per step
+
+
+def test_fused_iteration_captured_graph_equals_eager():
+    a, la = _run("cfg3_barf_inn_llff", True, steps=7)
+    b, lb = _run("cfg3_barf_inn_llff", True, steps=7, hip_graph=True)
+    assert b._captured is not None
+    assert la == lb
+    for fa, fb in zip(a._flats(), b._flats()):
+        assert torch.equal(fa, fb)
+
+
+def test_fused_iteration_is_refused_or_bypassed_where_it_does_not_apply():
+    from neural_invertible_warp_amd import configs, engine
+    from neural_invertible_warp_amd._lib import NiwError
+    opt = configs.cfg3_barf_inn_llff(device=DEV)
+    opt.camera.ndc = True
+    tr = engine.INNTrainer(opt, 3, fused_step="auto")
+    assert tr.fused is None and "ndc" in tr.fused_fallback_reason
+    with pytest.raises(NiwError, match="does not cover"):
+        engine.INNTrainer(configs.cfg3_barf_inn_llff(device=DEV), 3, ray_sampler="randperm", fused_step=True)
+
+
+def test_adam_of_all_groups_in_one_launch_equals_the_per_group_launches():
+    from neural_invertible_warp_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    sizes = [530052, 165900, 18 * 128, 7]
+    mk = lambda: [torch.randn(n, device=DEV, generator=gen) for n in sizes]
+    p, g, m, v = mk(), mk(), mk(), [x.abs() for x in mk()]
+    p2, m2, v2 = [x.clone() for x in p], [x.clone() for x in m], [x.clone() for x in v]
+    lrs, step = [1e-3, 5e-4, 5e-4, 2e-3], 37
+    for k in range(4):
+        if k != 2:
+            ops.adam_step(p[k], g[k], m[k], v[k], lrs[k], step)
+    ops.adam_step_multi([None if k == 2 else (p2[k], g[k], m2[k], v2[k], lrs[k], step) for k in range(4)])
+    for k in range(4):
+        assert torch.equal(p[k], p2[k]) and torch.equal(m[k], m2[k]) and torch.equal(v[k], v2[k]), k
+    # step scalars read from device memory (graph replays): [groups][2]
+    hyper = torch.tensor([ops.adam_hyper(lr, step + 1) for lr in lrs], device=DEV, dtype=torch.float32)
+    for k in range(4):
+        ops.adam_step(p[k], g[k], m[k], v[k], lrs[k], step + 1)
+    ops.adam_step_multi([(p2[k], g[k], m2[k], v2[k], 123.0, 1) for k in range(4)], hyper_dev=hyper)
+    for k in range(4):
+        assert torch.equal(p[k], p2[k]), k
