@@ -197,6 +197,19 @@ __device__ __forceinline__ void sincos_band(double t, int k, float& s, float& c)
     c = (qi == 1 || qi == 2) ? -cc : cc;
 }
 
+// One element of torch.optim.Adam's single-tensor update (no amsgrad / weight decay), shared by adam_kernel (niw_sampling.hip) and
+// adam_multi_kernel (niw_step.hip) so that both round alike.  Explicit about what is fused: torch's lerp_ and addcmul_ / addcdiv_
+// kernels evaluate `a + w * b` forms (one fma each), while mul_(beta2), the division by sqrt(bias_correction2) and add_(eps) are
+// separate tensor ops (separately rounded).
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float w1, float b2, float w2, float eps, float step_size,
+                                            float bc2_sqrt) {
+    const float mi = fmaf(w1, sub_rn(g, m), m);                        // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(mul_rn(w2, g), g, mul_rn(v, b2));            // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    m = mi; v = vi;
+    const float denom = add_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);   // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+    p = fmaf(-step_size, __fdiv_rn(mi, denom), p);                     // addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

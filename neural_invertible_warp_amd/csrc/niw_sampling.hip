@@ -227,12 +227,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (hyper_dev) { step_size = hyper_dev[0]; bc2_sqrt = hyper_dev[1]; }
-    const float gi = g[i];
-    const float mi = m[i] + w1 * (gi - m[i]);                 // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + (w2 * gi) * gi;              // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;           // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
-    p[i] -= step_size * (mi / denom);                         // addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
+    float pi = p[i], mi = m[i], vi = v[i];
+    niw::adam_update(pi, g[i], mi, vi, w1, b2, w2, eps, step_size, bc2_sqrt);
+    p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
 // ---------------------------------------------------------------- G0: var.ray_idx = randperm(H*W)[:n] (nerf_inn_llff.py:510)

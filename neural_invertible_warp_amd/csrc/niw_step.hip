@@ -138,12 +138,9 @@ __global__ void adam_multi_kernel(AdamBatch b, const float* __restrict__ hyper_d
     float step_size = G.step_size, bc2_sqrt = G.bc2_sqrt;
     if (hyper_dev) { step_size = hyper_dev[2 * gi]; bc2_sqrt = hyper_dev[2 * gi + 1]; }
     // the arithmetic of adam_kernel (niw_sampling.hip) = torch.optim.Adam's single-tensor path, element for element
-    const float gr = G.g[i];
-    const float mi = G.m[i] + b.w1 * (gr - G.m[i]);
-    const float vi = G.v[i] * b.b2 + (b.w2 * gr) * gr;
-    G.m[i] = mi; G.v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + b.eps;
-    G.p[i] -= step_size * (mi / denom);
+    float pi = G.p[i], mi = G.m[i], vi = G.v[i];
+    niw::adam_update(pi, G.g[i], mi, vi, b.w1, b.b2, b.w2, b.eps, step_size, bc2_sqrt);
+    G.p[i] = pi; G.m[i] = mi; G.v[i] = vi;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- workspace layout

@@ -185,12 +185,15 @@ class FusedStep:
         self.shape = (B, R, S, Sf, n, win)
         self.desc = d
         self._refresh(var)
+        if self.ring is None:
+            self.ring = torch.zeros(1 if tr.hip_graph else 64, 4, device=dev)
+        d.loss = self.ring.data_ptr()
         floats = _lib_mod.load().niw_train_step_workspace_floats(ctypes.byref(d))
         if floats <= 0:
-            raise NiwError("niw_train_step: " + _lib_mod.load().niw_last_error_string().decode())
-        self.ws = torch.empty(floats, device=dev, dtype=torch.float32)
-        slots = 1 if tr.hip_graph else 64
-        self.ring = torch.zeros(slots, 4, device=dev)
+            raise NiwError(_lib_mod.load().niw_last_error_string().decode())
+        if self.ws is None or self.ws.numel() != floats:
+            self.ws = None                                 # (release the old block before asking for the new one)
+            self.ws = torch.empty(floats, device=dev, dtype=torch.float32)
 
     def _refresh(self, var):
         """the members that can change between two iterations without a new descriptor: parameter / gradient / table storage"""

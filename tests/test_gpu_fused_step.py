@@ -76,6 +76,10 @@ def test_fused_iteration_of_a_rank_equals_the_mirror_under_ray_sharding(cfg, wor
             tr.it = 7
             for n in tr.nets:
                 n.set_progress(0.3)
+            # the latent columns of the warp's first layers are zero-initialised (nvp_ndr.py:278-282), which makes the latent gradient
+            # exactly zero at the first step: move every warp parameter off its initial value
+            with torch.no_grad():
+                tr.warp_mlp.flat_params.add_(0.01 * torch.randn(tr.warp_mlp.flat_params.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)))
             loss = tr._forward_backward(type(var0)(var0), tr.it)
             outs.append(({k: float(v.detach()) for k, v in loss.items()}, tr.bucket.flat.clone(), tr))
         (la, ga, ta), (lb, gb, tb) = outs
