@@ -371,10 +371,8 @@ int niw_adam_step_multi(const niw_adam_group* groups, int n_groups, double beta1
  *
  * niw_train_desc is a HOST struct; pointer members are device pointers unless stated. */
 enum niw_train_stage {          /* the call executes the stages [stage_begin, stage_end); a timing harness calls them one by one */
-    NIW_STAGE_RAYS = 0,         /* pixel draw, un-warped points [grid ; centre] per view */
+    NIW_STAGE_FRONT = 0,        /* one launch: pixel draw, un-warped points [grid ; centre] per view, stratified depths, weight images */
     NIW_STAGE_WARP_FWD,         /* operand preparation, warp, rays = grid - centre */
-    NIW_STAGE_SAMPLE,           /* stratified depths */
-    NIW_STAGE_PACK,             /* weight images of the field network(s) */
     NIW_STAGE_MLP_FWD,          /* coarse field */
     NIW_STAGE_COMPOSITE_FWD,
     NIW_STAGE_RESAMPLE,         /* inverse-CDF depths merged with the coarse ones (n_fine > 0) */
@@ -439,6 +437,13 @@ typedef struct niw_train_desc {
     float* poses;               /* [n_views,12] registered [R|t] per view (global_rigid / pose_global); rows view0..view1 refreshed; or NULL */
     float* rgb;                 /* optional [n_rays,3] rendered colours of the share (NULL: kept in the workspace only) */
     float* rgb_fine;            /* optional */
+    /* != 0 (and the call spans all stages): the small stages that do not depend on each other run on a second, library-owned
+     * stream beside the field-MLP kernels -- the registration and alignment loss beside the field forward, the whole warp backward
+     * beside the coarse network's dW GEMMs -- forked from and joined back into `stream`
+     * with events (capturable: the branches become parallel branches of a HIP graph).  Same kernels, same numbers.  0: every
+     * launch on `stream`, in stage order. */
+    int32_t overlap;
+    int32_t reserved;
 } niw_train_desc;
 
 /* floats of the workspace (16-byte aligned); <= 0 with niw_last_error_string() set when the descriptor is not supported */

@@ -44,11 +44,11 @@ class TrainDesc(ctypes.Structure):
                 ("warp_params", _vp), ("latent", _vp), ("chan_w", _fp), ("index_window", _fp), ("window_dev", _vp),
                 ("w_render", _f), ("w_render_fine", _f), ("w_align", _f), ("always_register", _i32), ("mse_norm", _d),
                 ("loss", _vp), ("d_nerf", _vp), ("d_nerf_fine", _vp), ("d_warp", _vp), ("d_latent", _vp), ("poses", _vp),
-                ("rgb", _vp), ("rgb_fine", _vp)]
+                ("rgb", _vp), ("rgb_fine", _vp), ("overlap", _i32), ("reserved", _i32)]
 
 
 # train stages (enum niw_train_stage), in execution order
-TRAIN_STAGES = ("rays", "warp_fwd", "sample", "pack", "mlp_fwd", "composite_fwd", "resample", "mlp_fwd_fine", "composite_fwd_fine", "loss",
+TRAIN_STAGES = ("front", "warp_fwd", "mlp_fwd", "composite_fwd", "resample", "mlp_fwd_fine", "composite_fwd_fine", "loss",
                 "composite_bwd_fine", "mlp_bwd_dx_fine", "mlp_bwd_dw_fine", "composite_bwd", "mlp_bwd_dx", "mlp_bwd_dw", "warp_bwd")
 
 # name -> (restype, argtypes); mirrors include/niw.h one to one

@@ -27,9 +27,14 @@ namespace {
 
 constexpr int kMom = 16;      // n, sum x[3], sum y[3], sum y x^T [9] (row-major: y index major)
 
+__device__ __forceinline__ void solve_view(const double* m, float* __restrict__ pose);
+
+// poses != NULL: the workgroup that has just summed a view's moments also solves the view's registration (niw_train_step: a view's
+// moments are complete in its own workgroup -- no reduction over ranks in between -- so the separate solve launch is saved)
 __global__ __launch_bounds__(256) void align_moments_kernel(const float* __restrict__ x, const float* __restrict__ y, long long N,
-                                                            double* __restrict__ mom) {
+                                                            double* __restrict__ mom, float* __restrict__ poses) {
     __shared__ double red[4][kMom];
+    __shared__ double total[kMom];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (long long)b * N * 3;
     const float* yb = y + (long long)b * N * 3;
@@ -56,13 +61,18 @@ __global__ __launch_bounds__(256) void align_moments_kernel(const float* __restr
         if (lane == 0) red[wave][k] = v;
     }
     __syncthreads();
-    if (tid < kMom) mom[b * kMom + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < kMom) {
+        const double t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        mom[b * kMom + tid] = t;
+        total[tid] = t;
+    }
+    if (poses) {
+        __syncthreads();
+        if (tid == 0) solve_view(total, poses + b * 12);
+    }
 }
 
-__global__ void align_solve_kernel(const double* __restrict__ mom, int B, float* __restrict__ poses) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double* m = mom + b * kMom;
+__device__ __forceinline__ void solve_view(const double* m, float* __restrict__ pose) {
     const double n = m[0] > 0.0 ? m[0] : 1.0;
     const double xm[3] = {m[1] / n, m[2] / n, m[3] / n}, ym[3] = {m[4] / n, m[5] / n, m[6] / n};
     double M[3][3], R[3][3], U[3][3], V[3][3], s[3];
@@ -70,9 +80,15 @@ __global__ void align_solve_kernel(const double* __restrict__ mom, int B, float*
         for (int d = 0; d < 3; ++d) M[c][d] = m[7 + 3 * c + d] - n * ym[c] * xm[d];
     niw::kabsch_rotation(M, R, U, V, s);
     for (int c = 0; c < 3; ++c) {
-        for (int d = 0; d < 3; ++d) poses[b * 12 + c * 4 + d] = (float)R[c][d];
-        poses[b * 12 + c * 4 + 3] = (float)(ym[c] - (R[c][0] * xm[0] + R[c][1] * xm[1] + R[c][2] * xm[2]));
+        for (int d = 0; d < 3; ++d) pose[c * 4 + d] = (float)R[c][d];
+        pose[c * 4 + 3] = (float)(ym[c] - (R[c][0] * xm[0] + R[c][1] * xm[1] + R[c][2] * xm[2]));
     }
+}
+
+__global__ void align_solve_kernel(const double* __restrict__ mom, int B, float* __restrict__ poses) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    solve_view(mom + b * kMom, poses + b * 12);
 }
 
 // one workgroup of 1024 threads over all B*N points, views in order
@@ -114,8 +130,16 @@ extern "C" int niw_align_moments(const float* target, const float* source, int n
                                  niw_stream_t stream) {
     NIW_REQUIRE(target && source && moments, "niw_align_moments: null pointer");
     NIW_REQUIRE(n_views > 0 && n_points > 0, "niw_align_moments: empty input (views=%d, points=%lld)", n_views, (long long)n_points);
-    align_moments_kernel<<<n_views, 256, 0, (hipStream_t)stream>>>(target, source, n_points, moments);
+    align_moments_kernel<<<n_views, 256, 0, (hipStream_t)stream>>>(target, source, n_points, moments, nullptr);
     NIW_LAUNCH_CHECK("niw_align_moments");
+    return NIW_OK;
+}
+
+// niw_align_moments + niw_align_solve of the same views in ONE launch (niw_step.hip)
+int niw_launch_align_register(const float* target, const float* source, int n_views, int64_t n_points, double* moments, float* poses, hipStream_t st) {
+    NIW_REQUIRE(target && source && moments && poses, "niw_train_step (registration): null pointer");
+    align_moments_kernel<<<n_views, 256, 0, st>>>(target, source, n_points, moments, poses);
+    NIW_LAUNCH_CHECK("niw_train_step (registration)");
     return NIW_OK;
 }
 

@@ -266,6 +266,111 @@ __global__ void draw_ray_idx_kernel(long long n_pixels, long long n, unsigned lo
     out[i] = (int64_t)v;
 }
 
+// draw_ray_idx_kernel + raygen_kernel (mode 0, stacked outputs) in one launch: every (view, ray) thread forms its ray's pixel index from
+// the keyed permutation itself (a few dozen integer instructions), the threads of the first view also leave the indices behind for the
+// photometric loss.  Same indices, same points.
+__device__ __forceinline__ void draw_raygen_body(long long i, long long n_pixels, unsigned long long seed, unsigned long long draw,
+                                                 const unsigned long long* __restrict__ draw_dev, int half, const float* __restrict__ intr,
+                                                 const float* __restrict__ pose, int B, long long R, int W, int64_t* __restrict__ ray_idx,
+                                                 float* __restrict__ stacked) {
+    if (i >= (long long)B * R) return;
+    const int b = (int)(i / R);
+    const long long r = i % R;
+    if (draw_dev) draw = draw_dev[0];
+    unsigned key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        key[k] = mix32((unsigned)(seed >> (16 * (k & 1))) + 0x9e3779b9u * (unsigned)(k + 1)) ^ mix32((unsigned)draw + 0x7f4a7c15u * (unsigned)(k + 1)) ^
+                 mix32((unsigned)(draw >> 32) ^ (unsigned)(seed >> 32));
+    unsigned long long v = (unsigned long long)r;
+    do { v = feistel(v, half, key); } while (v >= (unsigned long long)n_pixels);
+    const long long pix = (long long)v;
+    if (b == 0) ray_idx[r] = pix;
+    const float x = (float)(pix % W) + 0.5f, y = (float)(pix / W) + 0.5f;
+    float Ki[9];
+    inv3x3(intr + b * 9, Ki);
+    float g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = Ki[k * 3] * x + Ki[k * 3 + 1] * y + Ki[k * 3 + 2];
+    float c[3] = {0.f, 0.f, 0.f};
+    if (pose) {
+        const float* P = pose + b * 12;
+        float gw[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float tk = -(P[0 * 4 + k] * P[3] + P[1 * 4 + k] * P[7] + P[2 * 4 + k] * P[11]);
+            gw[k] = P[0 * 4 + k] * g[0] + P[1 * 4 + k] * g[1] + P[2 * 4 + k] * g[2] + tk;
+            c[k] = tk;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = gw[k];
+    }
+    const long long o = b * 2 * R + r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        stacked[o * 3 + k] = g[k];                 // [grid ; centre] per view
+        stacked[(o + R) * 3 + k] = c[k];
+    }
+}
+
+// The FRONT of a train iteration as one launch (niw_step.hip): everything that depends on nothing but the iteration number and the
+// parameters -- pixel draw + un-warped points, stratified depths, the fp32 weight images of the field network(s) (the gather of
+// niw_mlp_pack_weights_indexed), the zero pad columns of the warp backward's factor rows.  Block ranges select the job; every job is
+// the body of the stand-alone kernel of the same name.
+struct FrontArgs {
+    int first_block[5];            // jobs: 0 rays, 1 depths, 2 weight image (coarse), 3 weight image (fine), 4 pad columns; first_block[k+1] ends job k
+    int end_block;
+    // rays
+    long long n_pixels; unsigned long long seed, draw; const unsigned long long* draw_dev; int half;
+    const float* intr; const float* pose; int B; long long R; int W; int64_t* ray_idx; float* stacked;
+    // depths
+    unsigned long long depth_seed; long long n_depth; int S; float dmin, span; int inverse, stratified; float* depth;
+    // weight images
+    const float* params[2]; const int4* index; f32x4* packed[2];
+    // pad columns
+    float* pad_ws; long long pad_rows, ppad; int first_pad, n_pad;
+};
+
+__global__ void step_front_kernel(FrontArgs a) {
+    const int blk = blockIdx.x;
+    int job = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+        if (blk >= a.first_block[k]) job = k;
+    const long long i = (long long)(blk - a.first_block[job]) * blockDim.x + threadIdx.x;
+    if (job == 0) {
+        draw_raygen_body(i, a.n_pixels, a.seed, a.draw, a.draw_dev, a.half, a.intr, a.pose, a.B, a.R, a.W, a.ray_idx, a.stacked);
+    } else if (job == 1) {
+        if (4 * i >= a.n_depth) return;
+        unsigned long long draw = a.draw_dev ? *a.draw_dev : a.draw;
+        unsigned c[4] = {(unsigned)i, (unsigned)(i >> 32), (unsigned)draw, (unsigned)(draw >> 32)};
+        if (a.stratified) philox4x32_10(c, (unsigned)a.depth_seed, (unsigned)(a.depth_seed >> 32));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long long e = 4 * i + t;
+            if (e >= a.n_depth) break;
+            const float u = a.stratified ? (float)(c[t] >> 8) * 5.9604644775390625e-08f : 0.5f;
+            const float r = u + (float)(int)(e % a.S);
+            float d = niw::add_rn(niw::mul_rn(__fdiv_rn(r, (float)a.S), a.span), a.dmin);
+            if (a.inverse) d = __fdiv_rn(1.f, niw::add_rn(d, 1e-8f));
+            a.depth[e] = d;
+        }
+    } else if (job == 2 || job == 3) {
+        if (i >= niw::kPackedFloats / 4) return;
+        const float* __restrict__ params = a.params[job - 2];
+        const int4 s = a.index[i];
+        a.packed[job - 2][i] = f32x4{s.x >= 0 ? params[s.x] : 0.f, s.y >= 0 ? params[s.y] : 0.f, s.z >= 0 ? params[s.z] : 0.f, s.w >= 0 ? params[s.w] : 0.f};
+    } else {
+        if (i < a.pad_rows * a.n_pad) a.pad_ws[(i / a.n_pad) * a.ppad + a.first_pad + (int)(i % a.n_pad)] = 0.f;
+    }
+}
+
+__global__ void draw_raygen_kernel(long long n_pixels, unsigned long long seed, unsigned long long draw, const unsigned long long* __restrict__ draw_dev,
+                                   int half, const float* __restrict__ intr, const float* __restrict__ pose, int B, long long R, int W,
+                                   int64_t* __restrict__ ray_idx, float* __restrict__ stacked) {
+    draw_raygen_body((long long)blockIdx.x * blockDim.x + threadIdx.x, n_pixels, seed, draw, draw_dev, half, intr, pose, B, R, W, ray_idx, stacked);
+}
+
 }  // namespace
 
 extern "C" int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, double depth_min, double depth_max,
@@ -313,6 +418,55 @@ extern "C" int niw_raygen(const float* intr, const float* pose, const int64_t* r
     raygen_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(intr, pose, ray_idx, first_pixel, n_views, n_rays_per_view, H, W, mode,
                                                                            n_rays_per_view, out_a, out_b);
     NIW_LAUNCH_CHECK("niw_raygen");
+    return NIW_OK;
+}
+
+// The front of a train iteration in one launch (step_front_kernel): niw_draw_ray_idx + stacked mode-0 ray generation; niw_sample_stratified(_rng);
+// niw_mlp_pack_weights_indexed of one or two networks (packed[k] == NULL: skipped); the pad columns [n_cols, ppad) of `pad_rows` factor rows
+int niw_launch_step_front(int64_t n_pixels, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, const float* intr, const float* pose, int n_views,
+                          long long R, int H, int W, int64_t* ray_idx, float* stacked,
+                          uint64_t depth_seed, int stratified, long long n_rays, int S, double depth_min, double depth_max, int inverse, float* depth,
+                          const float* params0, const float* params1, const int32_t* index, float* packed0, float* packed1,
+                          float* pad_ws, long long pad_rows, long long ppad, long long n_cols, hipStream_t st) {
+    NIW_REQUIRE(n_pixels == (int64_t)H * W && R > 0 && R <= n_pixels && n_pixels <= (1ll << 40), "niw_train_step (pixel draw): %lld rays of %lld pixels", R, (long long)n_pixels);
+    NIW_REQUIRE(intr && ray_idx && stacked && depth && n_rays > 0 && S > 0, "niw_train_step (front): null pointer or empty input");
+    NIW_REQUIRE((!packed0 && !packed1) || index, "niw_train_step (front): weight images need the pack index");
+    FrontArgs a{};
+    int bits = 1;
+    while ((1ll << bits) < n_pixels) ++bits;
+    a.n_pixels = n_pixels; a.seed = seed; a.draw = draw; a.draw_dev = reinterpret_cast<const unsigned long long*>(draw_dev);
+    a.half = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+    a.intr = intr; a.pose = pose; a.B = n_views; a.R = R; a.W = W; a.ray_idx = ray_idx; a.stacked = stacked;
+    a.depth_seed = depth_seed; a.n_depth = n_rays * S; a.S = S; a.dmin = (float)depth_min; a.span = (float)(depth_max - depth_min);
+    a.inverse = inverse; a.stratified = stratified; a.depth = depth;
+    a.params[0] = params0; a.params[1] = params1; a.index = reinterpret_cast<const int4*>(index);
+    a.packed[0] = reinterpret_cast<f32x4*>(packed0); a.packed[1] = reinterpret_cast<f32x4*>(packed1);
+    const int n_pad = pad_ws ? (int)(ppad - n_cols) : 0;
+    a.pad_ws = pad_ws; a.pad_rows = pad_rows; a.ppad = ppad; a.first_pad = (int)n_cols; a.n_pad = n_pad;
+    const long long work[5] = {(long long)n_views * R, (a.n_depth + 3) / 4, packed0 ? niw::kPackedFloats / 4 : 0, packed1 ? niw::kPackedFloats / 4 : 0,
+                               pad_rows * n_pad};
+    int blocks = 0;
+    for (int k = 0; k < 5; ++k) {
+        a.first_block[k] = blocks;
+        blocks += (int)((work[k] + 255) / 256);
+    }
+    a.end_block = blocks;
+    step_front_kernel<<<blocks, 256, 0, st>>>(a);
+    NIW_LAUNCH_CHECK("niw_train_step (front)");
+    return NIW_OK;
+}
+
+// niw_draw_ray_idx (first = 0, stride = 1) + the stacked mode-0 ray generation below as ONE launch
+int niw_launch_draw_raygen_stacked(int64_t n_pixels, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, const float* intr, const float* pose,
+                                   int n_views, long long R, int H, int W, int64_t* ray_idx, float* stacked, hipStream_t st) {
+    NIW_REQUIRE(n_pixels == (int64_t)H * W && R > 0 && R <= n_pixels && n_pixels <= (1ll << 40), "niw_train_step (pixel draw): %lld rays of %lld pixels", R, (long long)n_pixels);
+    int bits = 1;
+    while ((1ll << bits) < n_pixels) ++bits;
+    const int half = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+    const long long n = (long long)n_views * R;
+    draw_raygen_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(n_pixels, seed, draw, reinterpret_cast<const unsigned long long*>(draw_dev), half, intr, pose,
+                                                               n_views, R, W, ray_idx, stacked);
+    NIW_LAUNCH_CHECK("niw_train_step (pixel draw + ray generation)");
     return NIW_OK;
 }
 

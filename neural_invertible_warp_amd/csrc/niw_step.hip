@@ -15,8 +15,22 @@
 // separately rounded), so the engine's parameters agree bit for bit with the autograd mirror on the same inputs.
 #include "niw_common.h"
 
-int niw_launch_raygen_stacked(const float* intr, const float* pose, const int64_t* ray_idx, int n_views, long long R, int H, int W,
-                              float* stacked, hipStream_t st);
+// launches that exist for this sequencer only (each = two launches of the public entry points in one, same arithmetic)
+int niw_launch_step_front(int64_t n_pixels, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, const float* intr, const float* pose, int n_views,
+                          long long R, int H, int W, int64_t* ray_idx, float* stacked,
+                          uint64_t depth_seed, int stratified, long long n_rays, int S, double depth_min, double depth_max, int inverse, float* depth,
+                          const float* params0, const float* params1, const int32_t* index, float* packed0, float* packed1,
+                          float* pad_ws, long long pad_rows, long long ppad, long long n_cols, hipStream_t st);
+void niw_warp_bwd_pad_geometry(int n_views, int64_t n_pts, long long* rows, long long* ppad, long long* n_cols);
+int niw_launch_align_register(const float* target, const float* source, int n_views, int64_t n_points, double* moments, float* poses, hipStream_t st);
+int niw_launch_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
+                             const float* d_w_head, float* workspace, const float* codeb_ready, float* d_params, float* d_code, hipStream_t st);
+int niw_launch_warp_bwd_pad(float* workspace, int n_views, int64_t n_pts, hipStream_t st);
+int niw_launch_warp_bwd_main(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                             int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                             int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* xin_saved,
+                             const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                             hipStream_t st);
 
 namespace {
 
@@ -143,6 +157,47 @@ __global__ void adam_multi_kernel(AdamBatch b, const float* __restrict__ hyper_d
     G.p[i] = pi; G.m[i] = mi; G.v[i] = vi;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- second stream
+// The small stages that do not depend on each other run beside the field-MLP kernels (niw.h: niw_train_desc.overlap).  One
+// high-priority non-blocking stream and three events per device, created on first use and kept for the life of the process (like the
+// kernel-attribute cache of niw_common.h: process-global, write-once per device).
+struct SideLane {
+    hipStream_t s = nullptr;
+    hipEvent_t warped = nullptr, dx = nullptr, join = nullptr;
+};
+
+SideLane* side_lane() {
+    static SideLane lanes[64];
+    static std::atomic<unsigned long long> ready{0ull};
+    static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    const unsigned long long bit = 1ull << dev;
+    if (ready.load(std::memory_order_acquire) & bit) return &lanes[dev];
+    while (busy.test_and_set(std::memory_order_acquire)) {}
+    bool ok = true;
+    if (!(ready.load(std::memory_order_acquire) & bit)) {
+        SideLane& L = lanes[dev];
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // hi = numerically lowest = greatest priority
+        ok = hipStreamCreateWithPriority(&L.s, hipStreamNonBlocking, hi) == hipSuccess;
+        for (hipEvent_t* e : {&L.warped, &L.dx, &L.join})
+            ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        if (ok) ready.fetch_or(bit, std::memory_order_release);
+    }
+    busy.clear(std::memory_order_release);
+    return ok ? &lanes[dev] : nullptr;
+}
+
+#define NIW_HIP(call, what)                                                            \
+    do {                                                                               \
+        const hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                        \
+            niw_set_error("niw_train_step: %s: %s", what, hipGetErrorString(e_));      \
+            return NIW_ERR_LAUNCH;                                                     \
+        }                                                                              \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------------------------- workspace layout
 struct Layout {
     long long V, R, n, S, T, mpad_c, mpad_f;
@@ -266,10 +321,24 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     const long long own_off = d->own0 - d->view0;
     auto in = [&](int s) { return stage_begin <= s && s < stage_end; };
 
-    if (in(NIW_STAGE_RAYS)) {
-        NIW_RUN(niw_draw_ray_idx((int64_t)d->H * d->W, R, d->pixel_seed, d->draw, d->draw_dev, 0, 1, reinterpret_cast<int64_t*>(L.ray_idx), stream));
-        NIW_RUN(niw_launch_raygen_stacked(d->intr + 9ll * d->view0, d->pose_init ? d->pose_init + 12ll * d->view0 : nullptr, ray_idx, (int)V, R, d->H, d->W,
-                                          L.stacked_in, st));
+    // second stream (niw.h: overlap): X carries the small independent stages, `stream` the field-MLP chain
+    SideLane* lane = (d->overlap && stage_begin == 0 && stage_end == NIW_STAGE_END) ? side_lane() : nullptr;
+    hipStream_t X = lane ? lane->s : st;
+    niw_stream_t sx = (niw_stream_t)X;
+    // ---- the front of the iteration, one launch: pixel draw + un-warped points, stratified depths, fp32 weight images, pad columns
+    if (in(NIW_STAGE_FRONT)) {
+        const bool gather = d->precision == NIW_PREC_FP32 && d->pack_index;
+        long long pad_rows = 0, ppad = 0, n_cols = 0;
+        niw_warp_bwd_pad_geometry((int)V, 2 * R, &pad_rows, &ppad, &n_cols);
+        NIW_RUN(niw_launch_step_front((int64_t)d->H * d->W, d->pixel_seed, d->draw, d->draw_dev, d->intr + 9ll * d->view0,
+                                      d->pose_init ? d->pose_init + 12ll * d->view0 : nullptr, (int)V, R, d->H, d->W, reinterpret_cast<int64_t*>(L.ray_idx),
+                                      L.stacked_in, d->depth_seed, d->stratified, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, d->nerf_params,
+                                      fine ? d->nerf_fine_params : nullptr, d->pack_index, gather ? L.packed_c : nullptr, gather && fine ? L.packed_f : nullptr,
+                                      L.warp_ws, pad_rows, ppad, n_cols, st));
+        if (!gather) {                      // split-bf16 images, or no gather table: the packing kernels of the entry points
+            NIW_RUN(pack(d, d->nerf_params, L.packed_c, stream));
+            if (fine) NIW_RUN(pack(d, d->nerf_fine_params, L.packed_f, stream));
+        }
     }
     if (in(NIW_STAGE_WARP_FWD)) {
         NIW_RUN(niw_warp_prep_fwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.prep_ws, L.w_emb, L.view_b, L.w_head, stream));
@@ -278,16 +347,19 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         split_rays_kernel<<<(unsigned)((V * R * 3 + 255) / 256), 256, 0, st>>>(L.warped, V, R, L.ray, L.center);
         NIW_LAUNCH_CHECK("niw_train_step (split rays)");
     }
-    if (in(NIW_STAGE_SAMPLE)) {
-        if (d->stratified)
-            NIW_RUN(niw_sample_stratified_rng(d->depth_seed, d->draw, d->draw_dev, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, nullptr, stream));
-        else
-            NIW_RUN(niw_sample_stratified(nullptr, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, stream));
+    if (lane) {
+        NIW_HIP(hipEventRecord(lane->warped, st), "warped");
+        NIW_HIP(hipStreamWaitEvent(X, lane->warped, 0), "warped");
     }
-    if (in(NIW_STAGE_PACK)) {
-        NIW_RUN(pack(d, d->nerf_params, L.packed_c, stream));
-        if (fine) NIW_RUN(pack(d, d->nerf_fine_params, L.packed_f, stream));
+    // ---- X: rigid registration of the warped onto the un-warped points (whole views: no collective under sharding either) and the
+    // alignment loss -- the part of the LOSS stage that needs only the warp
+    if (in(NIW_STAGE_LOSS)) {
+        if (registration) NIW_RUN(niw_launch_align_register(L.warped, L.stacked_in, (int)V, 2 * R, reinterpret_cast<double*>(L.mom), poses, X));
+        if (align && L.n_own > 0)
+            NIW_RUN(niw_align_loss(L.warped + own_off * 6 * R, L.stacked_in + own_off * 6 * R, poses + own_off * 12, L.n_own, 2 * R, 3.0 * d->n_views * 2.0 * (double)R,
+                                   d->loss + 2, L.d_target + own_off * 6 * R, sx));
     }
+    // ---- main: field forward(s), compositing, photometric loss(es), their backward
     if (in(NIW_STAGE_MLP_FWD))
         NIW_RUN(niw_mlp_fwd(L.packed_c, center, ray, L.z, nullptr, n, S, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_s, L.sigma_s,
                             (loss_c ? L.save_c : nullptr), stream));
@@ -305,14 +377,6 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         const int64_t hw = (int64_t)d->H * d->W;
         if (loss_c) NIW_RUN(niw_mse_fwd_bwd(rgb, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render, d->loss + 0, L.d_rgb, stream));
         if (loss_f) NIW_RUN(niw_mse_fwd_bwd(rgb_fine, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render_fine, d->loss + 1, L.d_rgb_f, stream));
-        if (registration) {
-            // rigid registration of the warped onto the un-warped points, whole views: no collective under sharding either
-            NIW_RUN(niw_align_moments(L.warped, L.stacked_in, (int)V, 2 * R, reinterpret_cast<double*>(L.mom), stream));
-            NIW_RUN(niw_align_solve(reinterpret_cast<const double*>(L.mom), (int)V, poses, stream));
-        }
-        if (align && L.n_own > 0)
-            NIW_RUN(niw_align_loss(L.warped + own_off * 6 * R, L.stacked_in + own_off * 6 * R, poses + own_off * 12, L.n_own, 2 * R, 3.0 * d->n_views * 2.0 * (double)R,
-                                   d->loss + 2, L.d_target + own_off * 6 * R, stream));
     }
     if (fine) {
         if (loss_f) {
@@ -332,6 +396,13 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         if (in(NIW_STAGE_MLP_BWD_DX))
             NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, L.d_rgb_s, L.d_sigma_s, L.save_c, L.gradws, L.mlp_d_c,
                                    L.mlp_d_c + 3 * n, stream));
+    }
+    if (lane) {
+        NIW_HIP(hipEventRecord(lane->dx, st), "dx");
+        NIW_HIP(hipStreamWaitEvent(X, lane->dx, 0), "dx");
+    }
+    // ---- main: the coarse network's dW GEMMs;  X beside them: everything behind the ray gradients
+    if (loss_c) {
         if (in(NIW_STAGE_MLP_BWD_DW)) NIW_RUN(niw_mlp_bwd_dw(L.save_c, L.gradws, n, S, d->precision, L.partial, d->d_nerf, stream));
     } else if (in(NIW_STAGE_MLP_BWD_DW)) {
         NIW_RUN(fill(d->d_nerf, NIW_NERF_PARAM_FLOATS, 0.f, st));
@@ -352,12 +423,17 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         c.w[0] = d->w_render; c.w[1] = d->w_render_fine; c.w[2] = d->w_align;
         c.present[0] = loss_c; c.present[1] = loss_f; c.present[2] = align && L.n_own > 0;
         const long long work = V * R * 3 > c.lat_n ? V * R * 3 : c.lat_n;
-        combine_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(c);
+        combine_kernel<<<(unsigned)((work + 255) / 256), 256, 0, X>>>(c);
         NIW_LAUNCH_CHECK("niw_train_step (combine)");
-        NIW_RUN(niw_warp_bwd(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window, nullptr, nullptr,
-                             L.xin, L.d_warped, L.warp_ws, L.d_w_emb, L.d_view_b, L.d_w_head, nullptr, stream));
-        NIW_RUN(niw_warp_prep_bwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.d_w_emb, L.d_view_b, L.d_w_head, L.prep_bwd_ws, d->d_warp,
-                                  d->d_latent + 128ll * d->view0, stream));
+        NIW_RUN(niw_launch_warp_bwd_main(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window,
+                                         nullptr, nullptr, L.xin, L.d_warped, L.warp_ws, L.d_w_emb, L.d_view_b, L.d_w_head, nullptr, X));
+        // (the code projection of the forward's operand preparation is still at the head of its workspace)
+        NIW_RUN(niw_launch_warp_prep_bwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.d_w_emb, L.d_view_b, L.d_w_head, L.prep_bwd_ws, L.prep_ws,
+                                         d->d_warp, d->d_latent + 128ll * d->view0, X));
+    }
+    if (lane) {
+        NIW_HIP(hipEventRecord(lane->join, X), "join");
+        NIW_HIP(hipStreamWaitEvent(st, lane->join, 0), "join");
     }
     return NIW_OK;
 }

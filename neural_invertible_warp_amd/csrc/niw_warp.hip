@@ -546,25 +546,37 @@ extern "C" int64_t niw_warp_bwd_workspace_floats(int n_views, int64_t n_pts) {
     return 3ll * kRowsPerBlock * ppad + 3ll * 256 * (256 * 256 + 256) + 3ll * 256 * (256 * 64 + 256);
 }
 
-extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
-                            int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
-                            int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* xin_saved,
-                            const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
-                            niw_stream_t stream) {
-    WarpArgs a{};
-    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b);
-    if (rc != NIW_OK) return rc;
-    NIW_REQUIRE(d_out && workspace && d_w_emb && d_view_b && d_w_head, "niw_warp_bwd: null pointer");
-    NIW_REQUIRE(n_views <= 64, "niw_warp_bwd: at most 64 views per call (got %d)", n_views);
-    hipStream_t st = (hipStream_t)stream;
+// pad columns of the factor rows of niw_warp_bwd's workspace: rows, row pitch, first pad column (niw_step.hip zeroes them in its front kernel)
+void niw_warp_bwd_pad_geometry(int n_views, int64_t n_pts, long long* rows, long long* ppad, long long* n_cols) {
+    *rows = 3ll * kRowsPerBlock;
+    *ppad = warp_ppad(n_views, n_pts);
+    *n_cols = (long long)n_views * n_pts;
+}
+
+// the two halves of niw_warp_bwd, for a caller that keeps the workspace across calls (niw_step.hip): the pad columns of the factor rows
+// can be zeroed off the critical path (nothing else ever writes them)
+int niw_launch_warp_bwd_pad(float* workspace, int n_views, int64_t n_pts, hipStream_t st) {
     const long long ppad = warp_ppad(n_views, n_pts);
-    a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad; a.xin_in = xin_saved;
-    // padded columns of the factor rows must be zero
     if (const int n_pad = (int)(ppad - (long long)n_views * n_pts)) {
         const long long n_rows = 3ll * kRowsPerBlock;
         warp_zero_pad_kernel<<<(unsigned)((n_rows * n_pad + 255) / 256), 256, 0, st>>>(workspace, n_rows, ppad, (int)(ppad - n_pad), n_pad);
         NIW_LAUNCH_CHECK("niw_warp_bwd (pad)");
     }
+    return NIW_OK;
+}
+
+int niw_launch_warp_bwd_main(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                             int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                             int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* xin_saved,
+                             const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                             hipStream_t st) {
+    WarpArgs a{};
+    int rc = fill_args(a, w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b);
+    if (rc != NIW_OK) return rc;
+    NIW_REQUIRE(d_out && workspace && d_w_emb && d_view_b && d_w_head, "niw_warp_bwd: null pointer");
+    NIW_REQUIRE(n_views <= 64, "niw_warp_bwd: at most 64 views per call (got %d)", n_views);
+    const long long ppad = warp_ppad(n_views, n_pts);
+    a.d_out = d_out; a.d_pts = d_pts; a.ws = workspace; a.ppad = ppad; a.xin_in = xin_saved;
     static std::atomic<unsigned long long> attr_set{0ull};
     if (int rc2 = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(warp_bwd_kernel), kWarpLds, attr_set, "niw_warp_bwd")) return rc2;
     warp_bwd_kernel<<<dim3((unsigned)((n_pts + kPtsPerWg - 1) / kPtsPerWg), n_views), 256, kWarpLds, st>>>(a);
@@ -582,4 +594,16 @@ extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float
     warp_reduce_kernel<<<dim3((256 * 256 + 256 * 64 + 256 + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, n_views, d_w_emb, d_view_b, d_w_head);
     NIW_LAUNCH_CHECK("niw_warp_bwd (reduce)");
     return NIW_OK;
+}
+
+extern "C" int niw_warp_bwd(const float* w_emb, const float* view_b, const float* w_head, const float* pts,
+                            int n_views, int64_t n_pts, const float* chan_w, const float* index_window, const float* window_dev,
+                            int use_index_window, const float* pt_scale_a, const float* pt_scale_b, const float* xin_saved,
+                            const float* d_out, float* workspace, float* d_w_emb, float* d_view_b, float* d_w_head, float* d_pts,
+                            niw_stream_t stream) {
+    NIW_REQUIRE(workspace && n_views > 0 && n_pts > 0, "niw_warp_bwd: null workspace or empty input");
+    // padded columns of the factor rows must be zero
+    if (int rc = niw_launch_warp_bwd_pad(workspace, n_views, n_pts, (hipStream_t)stream)) return rc;
+    return niw_launch_warp_bwd_main(w_emb, view_b, w_head, pts, n_views, n_pts, chan_w, index_window, window_dev, use_index_window, pt_scale_a, pt_scale_b,
+                                    xin_saved, d_out, workspace, d_w_emb, d_view_b, d_w_head, d_pts, (hipStream_t)stream);
 }

@@ -270,18 +270,27 @@ extern "C" int niw_warp_prep_fwd(const float* params, const float* code, int n_v
     return NIW_OK;
 }
 
-extern "C" int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
-                                 const float* d_w_head, float* workspace, float* d_params, float* d_code, niw_stream_t stream) {
+// codeb_ready: the code projection niw_warp_prep_fwd left at the head of ITS workspace for the same params / code (niw_step.hip keeps
+// it across the iteration), or NULL: recomputed into this call's workspace
+int niw_launch_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
+                             const float* d_w_head, float* workspace, const float* codeb_ready, float* d_params, float* d_code, hipStream_t st) {
     NIW_REQUIRE(params && code && d_w_emb && d_view_b && d_w_head && workspace && d_params && d_code, "niw_warp_prep_bwd: null pointer");
     NIW_REQUIRE(n_views > 0 && n_views <= kMaxViews, "niw_warp_prep_bwd: 1..%d views per call (got %d)", kMaxViews, n_views);
-    hipStream_t st = (hipStream_t)stream;
-    float* codeb = workspace;
+    const float* codeb = codeb_ready;
     float* partial = workspace + 3ll * n_views * kLat;
-    warp_prep_code_kernel<<<dim3(3, n_views), 256, 0, st>>>(params, code, n_views, codeb);
-    NIW_LAUNCH_CHECK("niw_warp_prep_bwd (code projection)");
+    if (!codeb) {
+        warp_prep_code_kernel<<<dim3(3, n_views), 256, 0, st>>>(params, code, n_views, workspace);
+        NIW_LAUNCH_CHECK("niw_warp_prep_bwd (code projection)");
+        codeb = workspace;
+    }
     warp_prep_bwd_kernel<<<3 * 2 * kGroups, 256, 0, st>>>(params, codeb, n_views, d_w_emb, d_view_b, d_w_head, d_params, partial);
     NIW_LAUNCH_CHECK("niw_warp_prep_bwd");
     warp_prep_bwd_code_kernel<<<n_views + 24, 256, 0, st>>>(params, code, n_views, partial, d_params, d_code);
     NIW_LAUNCH_CHECK("niw_warp_prep_bwd (code projection backward)");
     return NIW_OK;
+}
+
+extern "C" int niw_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
+                                 const float* d_w_head, float* workspace, float* d_params, float* d_code, niw_stream_t stream) {
+    return niw_launch_warp_prep_bwd(params, code, n_views, d_w_emb, d_view_b, d_w_head, workspace, nullptr, d_params, d_code, (hipStream_t)stream);
 }

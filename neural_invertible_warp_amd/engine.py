@@ -173,6 +173,7 @@ class FusedStep:
         if not Sf:
             d.w_render_fine = -1.0
         d.always_register = 1 if tr.family == "dtu" else 0
+        d.overlap = 1 if tr.overlap else 0
         d.mse_norm = float(getattr(opt, "loss_norm_elements", None) or 3 * B * R)
         if tr.family == "dtu":
             table = tr.pose_net.pose_global.weight
@@ -277,7 +278,7 @@ class FusedStep:
 
 class INNTrainer:
     def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None, ray_sampler=None, hip_graph=False,
-                 fused_step="auto"):
+                 fused_step="auto", overlap=True):
         """ray_sampler: "feistel" (one sort-free launch, default on the GPU) or "randperm" (the reference's torch.randperm call).
         hip_graph: capture the whole iteration (forward, backward, gradient gather, Adam) into a HIP graph after two eager
         steps and replay it from then on -- one graph launch + one 256-byte constants upload per step instead of ~140 launches;
@@ -348,6 +349,7 @@ class INNTrainer:
                 raise NiwError("hip_graph=True needs ray_sampler='feistel' (torch.randperm cannot be replayed with a fresh draw)")
             self.consts = StepConstants(dev, len(self.bucket.groups))
         self._bind_constants(False)                      # outside a train iteration the modules read host state (see _bind_constants)
+        self.overlap = bool(overlap)                      # niw_train_desc.overlap: small independent stages on a second stream
         self.fused = None
         if fused_step:
             why = FusedStep.unsupported(self)

@@ -104,9 +104,28 @@ def test_fused_iteration_stage_by_stage_equals_the_single_call():
         ops.TIMING.enabled = False
     table = ops.TIMING.summary()
     assert la == lb and torch.equal(a.bucket.flat, b.bucket.flat)
-    for name in ("mlp_fwd_train", "mlp_bwd_dx", "mlp_bwd_dw", "composite_fwd", "composite_bwd", "rays", "warp_fwd", "warp_bwd", "loss", "pack", "adam"):
+    for name in ("mlp_fwd_train", "mlp_bwd_dx", "mlp_bwd_dw", "composite_fwd", "composite_bwd", "front", "warp_fwd", "warp_bwd", "loss", "adam"):
         assert name in table and table[name][1] > 0, name
     assert table["mlp_fwd_train"][0] == 6 and table["resample"][0] == 3          # coarse + fine per step
+
+
+@pytest.mark.parametrize("cfg", ["cfg2_nerf_inn_llff_hier", "dtu"])
+def test_fused_iteration_with_and_without_the_second_stream(cfg):
+    """niw_train_desc.overlap: the small independent stages on the library's second stream beside the field-MLP chain -- same kernels,
+    same numbers, eager and captured"""
+    from neural_invertible_warp_amd import engine
+    runs = []
+    for overlap, hip_graph in ((False, False), (True, False), (True, True)):
+        tr, var0 = _trainer(cfg, True, hip_graph=hip_graph)
+        tr.overlap = overlap
+        losses = [{k: float(v.detach()) for k, v in tr.train_iteration(type(var0)(var0)).items()} for _ in range(6)]
+        torch.cuda.synchronize()
+        assert tr.fused.desc.overlap == int(overlap)
+        runs.append((losses, [f.clone() for f in tr._flats()]))
+    for losses, flats in runs[1:]:
+        assert losses == runs[0][0]
+        for x, y in zip(flats, runs[0][1]):
+            assert torch.equal(x, y)
 
 
 def test_fused_iteration_captured_graph_equals_eager():
