@@ -22,10 +22,18 @@ per-GPU ray count fixed (the global draw is N times larger; every rank warps all
 B x R rays); `strong` keeps the reference's GLOBAL batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
 on one GPU: a proxy of what one rank of a K-GPU strong-scaled job executes (no collective).  Prints ONE JSON line on rank 0.
 
-At N = 1 the timed iterations replay ONE captured HIP graph each (engine.INNTrainer(hip_graph=True): forward, backward, gradient
-gather and the Adam updates; the step's scalars -- c2f bands, warp windows, Adam bias corrections, pixel-draw number -- travel in a
-256-byte device buffer refreshed before every replay).  Under N > 1 the default is launch-by-launch (--hip-graph on: two graphs with
-the RCCL all-reduce issued eagerly between them); the step is GPU-bound at every BASELINE size, replay and eager launch time alike.
+An iteration is ONE library call (niw_train_step: forward, losses, backward of every stage, ~26 launches) + the gradient all-reduce
+(N > 1) + ONE Adam launch.  At N = 1 the timed iterations replay a captured HIP graph of it (the step's scalars -- c2f bands, warp
+windows, Adam bias corrections, pixel-draw number -- travel in a 256-byte device buffer refreshed before every replay); under N > 1
+the default is launch by launch, which since round 4 is the FASTER form at every size (the host needs ~0.3 ms per iteration, a rank's
+1/8 share of cfg3 takes 1.0 ms: measured 1.005 ms launched, 1.023 ms replayed).  `--hip-graph on` under N > 1 captures two graphs around
+the eagerly issued RCCL all-reduce; should the capture fail, the rank says so in a marker file and exits, and the launcher parent --
+which never touched the GPU -- starts a fresh set of ranks with `--hip-graph off` (a failed capture is not recoverable in-process).
+
+N > 1 prints ONE line holding both scaling modes: the weak-scaled step is the headline (`value`, `ms_per_step`: 4096 / 2048 rays per
+GPU), and `strong` = the reference's own batch (model/nerf_inn_llff.py:510: one pixel set of rand_rays // B per view) split N ways,
+timed right after it in the same processes; `comm_ms` = device events around the flat gradient all-reduce (max over ranks).  The run
+exits non-zero when a loss is not finite or the ranks' parameters disagree after the last step.
 
 Besides the contract fields the line carries `roofline` (dominant single MLP kernel: algorithmic FLOPs / mean launch time from
 device events on the launch stream vs the fp32-MFMA peak; `traffic` from the PMC passes in profiles/), `kernels` (per-kernel
@@ -49,10 +57,11 @@ PEAK_BF16_MFMA = 2500.0         # TFLOP/s dense (the guide's ~2.5 PF; never the 
 PEAK_HBM = 8000.0               # GB/s spec (6290 GB/s measured streaming copy)
 
 
-def cpu_baseline(B, S, Sf, H, W, ga_weight=None):
+def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to golden vectors) timed on
     this box's host cores on a bounded sample of the same workload: same views / resolution / samples per
-    ray, fewer rays per view."""
+    ray, fewer rays per view; 1 warm-up + 3 timed steps, the median reported.  vanilla: BASELINE configs[0] (ground-truth
+    poses, ReLU density, metric depth [0,1], no warp: model/nerf.py:251-288) instead of the INN step."""
     import torch
     from oracle import niw_oracle as O
     # cores this process may actually run on (a cgroup-limited box reports every host core in cpu_count)
@@ -70,39 +79,50 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None):
     gen = torch.Generator().manual_seed(0)
     image = torch.rand(B, 3, H, W, generator=gen)
     intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(B, 1, 1)
+    pose = torch.eye(3, 4).repeat(B, 1, 1)
     w3, wv = O.c2f_weights(0.3, (0.1, 0.5), 10), O.c2f_weights(0.3, (0.1, 0.5), 4)
     times = []
-    for i in range(3):
+    for i in range(4):
         ray_idx = torch.randperm(H * W, generator=gen)[:R]
         u = torch.rand(B, R, S, 1, generator=gen)
         t0 = time.perf_counter()
-        out = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", 0.3, nerf_fine_p=pf, Sf=Sf,
-                               ga_weight=ga_weight, w3d=w3, wview=wv)
-        out["loss"].backward()
+        if vanilla:
+            center, ray = O.center_and_ray(H, W, pose, intr)
+            out = O.render_rays(pc, center[:, ray_idx], ray[:, ray_idx], u, S, (0, 1), "metric", p_fine=pf, Sf=Sf, density_activ="relu")
+            target = O.gather_pixels(image, ray_idx)
+            loss = O.mse_loss(out["rgb"], target) + (O.mse_loss(out["rgb_fine"], target) if Sf else 0.0)
+        else:
+            out = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", 0.3, nerf_fine_p=pf, Sf=Sf,
+                                   ga_weight=ga_weight, w3d=w3, wview=wv)
+            loss = out["loss"]
+        loss.backward()
         times.append(time.perf_counter() - t0)
     evals = B * R * (S + (S + Sf if Sf else 0))
-    best = min(times[1:])
-    out = dict(value=evals / best, unit="ray-samples/s", cores=threads, kind="port",
+    timed = sorted(times[1:])
+    median = timed[len(timed) // 2]
+    out = dict(value=evals / median, unit="ray-samples/s", cores=threads, kind="port",
                sample=f"{B} views x {R} rays x ({S}" + (f"+{S + Sf}" if Sf else "") + f") samples = {evals} MLP evals per step, fwd+bwd, "
-                      f"best of 2 after 1 warm-up, torch CPU {threads} threads")
+                      f"median of 3 timed steps after 1 warm-up, torch CPU {threads} threads",
+               seconds_per_step=[round(t, 3) for t in times[1:]], best_value=evals / timed[0])
     # the port must time within +-10 % of the imported reference; measured in the build container it takes 0.895 x
     # the reference's time (it forms the un-warped ray grid once per step where the reference forms it twice), i.e. it flatters the
     # CPU by 10.5 %: the figure the reference itself would reach on these cores is reported beside it
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_oracle_calibration.json")) as f:
-            ratio = float(json.load(f)["oracle_over_reference_time"])
-        out["calibration"] = dict(oracle_over_reference_time=ratio, source="profiles/r2_oracle_calibration.json (tools/calibrate_oracle.py, build container)",
-                                  reference_equivalent_value=round(out["value"] * ratio, 1))
-    except (OSError, KeyError, ValueError):
-        pass
+    if not vanilla:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2_oracle_calibration.json")) as f:
+                ratio = float(json.load(f)["oracle_over_reference_time"])
+            out["calibration"] = dict(oracle_over_reference_time=ratio, source="profiles/r2_oracle_calibration.json (tools/calibrate_oracle.py, build container)",
+                                      reference_equivalent_value=round(out["value"] * ratio, 1))
+        except (OSError, KeyError, ValueError):
+            pass
     return out
 
 
 def rocprof_row(config, kernel):
-    """The committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/r3_kernel_stats_<config>.csv, else
-    round 2's): the row of `kernel`, so that the device-event average of this run stands next to the profiler's."""
+    """The committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/r4_kernel_stats_<config>.csv, else an
+    earlier round's): the row of `kernel`, so that the device-event average of this run stands next to the profiler's."""
     import csv
-    for rnd in ("r3", "r2"):
+    for rnd in ("r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{config}.csv")
         try:
             with open(path, newline="") as f:
@@ -217,7 +237,7 @@ def composite_scan(dev, iters=20):
                 traffic_source="profiles/r3_composite_traffic.json (rocprofv3 FETCH_SIZE x2 / WRITE_SIZE of the same launches)")
 
 
-def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, precision="fp32"):
+def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, precision="fp32", overlap=True):
     """-> (list of (trainer, var0, B, R_local, S, Sf), description, rays of the global batch per scene)"""
     from neural_invertible_warp_amd import configs, engine
     eff_world, eff_rank = (shard_of, 0) if shard_of else (world, rank)
@@ -228,10 +248,10 @@ def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, p
         opt.nerf.rand_rays = rays * (eff_world if scaling == "weak" else 1)        # global draw; each rank keeps idx[rank::world]
         if dtu:
             var0, init = engine.synthetic_dtu_scene(opt, B)
-            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, initial_poses_w2c=init, hip_graph=hip_graph)
+            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, initial_poses_w2c=init, hip_graph=hip_graph, overlap=overlap)
         else:
             var0 = engine.synthetic_scene(opt, B)
-            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, hip_graph=hip_graph)
+            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, hip_graph=hip_graph, overlap=overlap)
         from neural_invertible_warp_amd import parallel
         lo, hi = parallel.flat_share(B * (opt.nerf.rand_rays // B), eff_rank, eff_world)   # this rank's contiguous share of the B x R rays
         S = opt.nerf.sample_intvs
@@ -239,7 +259,19 @@ def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, p
         out.append((tr, var0, B, (hi - lo) / B, S, Sf))                              # (rays per view: fractional for a share)
         return opt
 
-    if name == "cfg2":
+    if name == "cfg1":
+        # BASELINE configs[0]: the vanilla model on ground-truth poses (no warp, no ray gradients); its engine is NeRFTrainer
+        opt = configs.cfg1_nerf_llff_repr(device=dev)
+        opt.arch.precision = precision
+        if eff_world > 1:
+            raise SystemExit("cfg1 (vanilla NeRF, configs[0]) is a single-GPU line")
+        B = 18
+        var0 = engine.synthetic_scene(opt, B)
+        tr = engine.NeRFTrainer(opt, B)
+        out.append((tr, var0, B, opt.nerf.rand_rays // B, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0))
+        desc = ("cfg1: nerf_llff_repr.yaml 300x400 (configs[0]), 18 views x 56 rays x (64 coarse + 192 fine), ReLU density + noise, metric depth [0,1], "
+                "ground-truth poses (no warp, no ray gradients), fwd+bwd+Adam")
+    elif name == "cfg2":
         mk(configs.cfg2_nerf_inn_llff_hier(device=dev), 18, 4096)
         desc = "cfg2: nerf_inn_llff.yaml fern 300x400, 18 views x 227 rays x (64 coarse + 192 fine), NVP-warped rays, fwd+bwd+Adam"
     elif name == "cfg3":
@@ -275,18 +307,42 @@ def launcher_command(gpus, argv, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+CAPTURE_MARKER_ENV = "NIW_CAPTURE_FAILED_FILE"      # a rank whose HIP-graph capture failed touches this file before it exits
+
+
 def launch_ranks_if_needed(gpus, argv):
     """`python bench.py --gpus N` (N > 1) with no rank environment: start the N ranks as a CHILD process and exit with its return code.
     The parent has not imported torch or touched HIP at this point and never does (a GPU-initialised process must not exec or fork
-    rank processes); a failing rank makes torch.distributed.run -- and therefore this process -- exit non-zero."""
+    rank processes); a failing rank makes torch.distributed.run -- and therefore this process -- exit non-zero.  One recovery is the
+    parent's to make: a rank whose graph capture failed (HIP's capture error is sticky in-process) leaves a marker file, and the
+    parent then starts a FRESH set of ranks with `--hip-graph off` appended."""
     if not needs_launcher(gpus, os.environ):
         return False
     import subprocess
+    import tempfile
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool (RCCL needs it across processes)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    marker = os.path.join(tempfile.gettempdir(), f"niw_capture_failed_{os.getpid()}")
+    env[CAPTURE_MARKER_ENV] = marker
     rc = subprocess.call(launcher_command(gpus, argv), env=env)
+    if rc != 0 and os.path.exists(marker):
+        os.remove(marker)
+        print("bench.py: HIP-graph capture failed on a rank; starting fresh ranks with --hip-graph off", file=sys.stderr, flush=True)
+        rc = subprocess.call(launcher_command(gpus, list(argv) + ["--hip-graph", "off"], port=29500 + (os.getpid() + 977) % 2000), env=env)
     sys.exit(rc)
+
+
+def report_capture_failure_and_exit(err):
+    """called by a rank: leave the marker for the launcher parent (if there is one) and exit with a distinct code"""
+    marker = os.environ.get(CAPTURE_MARKER_ENV)
+    if marker:
+        try:
+            open(marker, "w").write(str(err)[:500])
+        except OSError:
+            pass
+    print(f"bench.py: {err}", file=sys.stderr, flush=True)
+    os._exit(75)                                             # no destructors: the process's HIP state is unusable after a failed capture
 
 
 def main():
@@ -295,7 +351,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak (strong with --shard-of)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: N = 1 weak (strong with --shard-of); N > 1 BOTH -- the weak-scaled step is the headline, `strong` holds the other")
     ap.add_argument("--shard-of", type=int, default=0, help="N=1 only: run rank 0's 1/K share of the global batch on this GPU: the work of one rank of a "
                                                             "K-GPU job (strong scaling: the reference's batch split K ways; with --scaling weak: a K times larger batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -305,15 +362,18 @@ def main():
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the oracle's step under PyTorch-ROCm on this GPU (torch_rocm_baseline)")
     ap.add_argument("--lean", action="store_true", help="train step only: all four --no-* switches")
     ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the captured HIP graph of the iteration (on) or launch its kernels one by one (off); auto = on for one GPU, off under "
-                         "torch.distributed (measured: no throughput difference at any BASELINE size -- the step is GPU-bound -- so the multi-rank "
-                         "default avoids capturing next to a live RCCL communicator)")
+                    help="replay the captured HIP graph of the iteration (on) or launch it call by call (off); auto = on for one GPU, off under "
+                         "torch.distributed (round 4: launched is the faster form at every size, also for a 1/8 share -- 1.005 vs 1.023 ms).  With "
+                         "`on` under N > 1 a failed capture makes the launcher parent start fresh ranks with `off`")
     ap.add_argument("--no-hip-graph", action="store_true", help="same as --hip-graph off")
     ap.add_argument("--kernel-steps", type=int, default=3, help="extra eager steps after the timed region for the per-kernel device-event table (0: skip)")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="arithmetic of the field MLP.  fp32 (default, the headline): exact fp32 MFMA.  bf16x3 / bf16: the opt-in fast modes "
                          "(split-bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- a SEPARATE line with its own parity row "
                          "(tests/test_gpu_fast_precision.py), never comparable with the reference's fp32 tolerance")
+    ap.add_argument("--overlap", choices=["on", "off"], default="on",
+                    help="niw_train_desc.overlap: the small independent stages of an iteration on the library's second stream beside the field-MLP kernels (default) "
+                         "or everything on one stream in stage order")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the torch.distributed process group even for ONE rank, so that the gradient all-reduce really goes through RCCL "
                          "(hardware evidence of the N > 1 code path on a 1-GPU box)")
@@ -348,50 +408,99 @@ def main():
     dev = f"cuda:{local}"
     scaling = args.scaling or ("strong" if args.shard_of else "weak")
 
+    from neural_invertible_warp_amd import engine
     use_graph = False if args.no_hip_graph else ((world == 1 and not args.force_dist) if args.hip_graph == "auto" else args.hip_graph == "on")
-    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph, precision=args.precision)
     exact = args.precision == "fp32"
     peak_mfma = PEAK_FP32_MFMA if exact else PEAK_BF16_MFMA
-    evals_local = sum(int(round(B * R)) * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads)
-
-    # the batch tensors stay resident at fixed addresses (the captured graph reads them in place)
-    def step(replay=True):
-        loss = None
-        for tr, var0, *_ in loads:
-            loss = tr.train_iteration(type(var0)(var0), replay=replay)
-        return loss
+    n_evals = lambda loads_: sum(int(round(B * R)) * (S + (S + Sf if Sf else 0)) for _, _, B, R, S, Sf in loads_)
 
     def fence():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3)):              # >= 3: two eager steps, then the capture
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    loss_value = float(loss.all.detach())
-    if not math.isfinite(loss_value):
-        raise SystemExit(f"bench.py: the training loss is {loss_value} after {max(args.warmup, 3) + args.steps} iterations -- a timing of a diverged "
-                         "run is not a measurement")
-    graphed = all(tr._captured is not None for tr, *_ in loads)
-    # per-kernel device events: a few more iterations launched one by one (events cannot be recorded inside a replayed graph);
-    # outside the timed region, same kernels, same shapes.  Two untimed launch-by-launch iterations come first: the eager path draws
-    # its 19 GB of transient buffers from the caching allocator's general pool, not from the graph's private one, and the first
-    # iterations there pay for fresh blocks (round 2: a table measured without them summed to MORE than the step it decomposes).
-    # The table is checked before it is believed: its launches must sum to no more than the eager iteration they were recorded in,
-    # and that iteration must take what a timed (replayed) one takes.
+    # untimed iterations in front of the timed ones: --warmup, at least 3 (two launch-by-launch iterations, then the capture), and at
+    # least 16 when the iterations are LAUNCHED rather than replayed: the cross-stream events of the launched form (the second stream
+    # of niw_train_step, the collective's stream) make the HIP runtime grow an internal pool ONCE -- a 50-100 ms host stall on about the
+    # seventh iteration after start-up (tools/rccl_probe.py, round 4) that would otherwise sit inside the timed region
+    n_warm = max(args.warmup, 3 if use_graph else 16)
+
+    def timed_run(loads_):
+        """warm-up + `--steps` timed iterations of one workload -> (seconds, final loss, replayed?, mean all-reduce ms | None, step fn)"""
+        # the batch tensors stay resident at fixed addresses (a captured graph reads private copies of them, in place)
+        def step(replay=True):
+            loss_ = None
+            for tr, var0, *_ in loads_:
+                loss_ = tr.train_iteration(type(var0)(var0), replay=replay)
+            return loss_
+        try:
+            for _ in range(n_warm):                       # >= 3: two launch-by-launch iterations, then the capture
+                step()
+        except engine.CaptureError as e:
+            report_capture_failure_and_exit(e)
+        for tr, *_ in loads_:
+            if hasattr(tr, "comm_events"):
+                tr.comm_events = []
+        fence()
+        trace = [] if os.environ.get("NIW_BENCH_TRACE") else None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_ = step()
+            if trace is not None:
+                trace.append(time.perf_counter())
+        if trace is not None:
+            torch.cuda.synchronize()
+            trace.append(time.perf_counter())
+        fence()
+        dt_ = time.perf_counter() - t0
+        if trace is not None:
+            print("bench.py trace (ms): host per step " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + trace[:-2], trace[:-1])) +
+                  f" | drain {1e3 * (trace[-1] - trace[-2]):.2f} | fence {1e3 * (t0 + dt_ - trace[-1]):.2f}", file=sys.stderr, flush=True)
+        comm = [a.elapsed_time(b) for tr, *_ in loads_ for a, b in (getattr(tr, "comm_events", None) or [])]
+        for tr, *_ in loads_:
+            if hasattr(tr, "comm_events"):
+                tr.comm_events = None
+        value_ = float(loss_.all.detach())
+        if not math.isfinite(value_):
+            raise SystemExit(f"bench.py: the training loss is {value_} after {n_warm + args.steps} iterations -- a timing of a diverged "
+                             "run is not a measurement")
+        return dt_, value_, all(getattr(tr, "_captured", None) is not None for tr, *_ in loads_), (sum(comm) / len(comm) if comm else None), step
+
+    def over_ranks(dt_, evals_, comm_, loads_):
+        """max / min over ranks of the timed seconds, sum of the evaluations, max of the all-reduce time; and the ranks' parameters must
+        agree after the last step (same reduced gradients, same Adam): a checksum of every flat parameter buffer, min == max"""
+        if world == 1:
+            return dt_, dt_, float(evals_), comm_
+        check = sum(float(f.double().sum()) for tr, *_ in loads_ for f in tr._flats())
+        t = torch.tensor([dt_, -dt_, comm_ or 0.0, check, -check], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e = torch.tensor([float(evals_)], device=dev, dtype=torch.float64)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        if float(t[3]) != -float(t[4]):
+            raise SystemExit(f"bench.py: the ranks' parameters disagree after the timed steps (checksum max {float(t[3])!r}, min {-float(t[4])!r})")
+        return float(t[0]), -float(t[1]), float(e[0]), (float(t[2]) if comm_ is not None else None)
+
+    # under N > 1 (and no explicit --scaling) BOTH modes are timed, weak first: its numbers are the headline
+    modes = [args.scaling or ("strong" if args.shard_of else "weak")]
+    if world > 1 and args.scaling is None:
+        modes = ["weak", "strong"]
+    scaling = modes[0]
+    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on")
+    evals_local = n_evals(loads)
+    dt, loss_value, graphed, comm_ms, step = timed_run(loads)
+    ms_rank = dt / args.steps * 1e3
+    # per-kernel device events: a few more iterations launched STAGE BY STAGE (niw_train_step(stage, stage + 1): events cannot be recorded
+    # inside a replayed graph, nor between the stages of one call), on one stream, outside the timed region; same kernels, same shapes.
+    # Two untimed iterations of that kind come first.  The table is checked before it is believed: its launches must sum to no more than
+    # the serial iteration they were recorded in, and the field-MLP kernels -- which never overlap one another -- to no more than a timed
+    # iteration (the small stages may: the timed iteration runs them on a second stream beside the MLP kernels, niw_train_desc.overlap).
     kern, eager_ms, kernel_check = {}, None, None
     if args.kernel_steps > 0:
         for attempt in range(2):
+            ops.TIMING.enabled = True
             for _ in range(2):
                 step(replay=False)
             fence()
-            ops.TIMING.enabled = True
             ops.TIMING.reset()
             t1 = time.perf_counter()
             for _ in range(args.kernel_steps):
@@ -401,28 +510,38 @@ def main():
             ops.TIMING.enabled = False
             kern = ops.TIMING.summary()
             kernel_sum_ms = sum(n * ms for n, ms, _ in kern.values()) / args.kernel_steps
-            ms_timed = dt / args.steps * 1e3
-            # (launch by launch the host can be the limit -- ~50 launches per iteration against a 1.2 ms shard step -- so the eager
-            # iteration may take longer than a replayed one; what must hold is that the kernels fit inside both)
-            kernel_check = dict(kernel_sum_ms=round(kernel_sum_ms, 4), eager_ms_per_step=round(eager_ms, 4), timed_ms_per_step=round(ms_timed, 4),
-                                eager_host_bound=bool(eager_ms > 1.05 * ms_timed),
-                                consistent=bool(kernel_sum_ms <= eager_ms and kernel_sum_ms <= 1.01 * ms_timed))
+            mlp_sum_ms = sum(n * ms for k, (n, ms, _) in kern.items() if k.startswith("mlp_")) / args.kernel_steps
+            kernel_check = dict(kernel_sum_ms=round(kernel_sum_ms, 4), mlp_kernel_sum_ms=round(mlp_sum_ms, 4), serial_ms_per_step=round(eager_ms, 4),
+                                timed_ms_per_step=round(ms_rank, 4), hidden_by_overlap_ms=round(max(0.0, kernel_sum_ms - ms_rank), 4),
+                                consistent=bool(kernel_sum_ms <= eager_ms and mlp_sum_ms <= ms_rank))
             if kernel_check["consistent"]:
                 break
         if not kernel_check["consistent"]:
             # a table that does not add up is not evidence: keep the record of the failed check, drop the table
             print(f"bench.py: per-kernel table rejected {kernel_check}", file=sys.stderr, flush=True)
             kern = {}
+    dt, dt_min, evals_total, comm_ms = over_ranks(dt, evals_local, comm_ms, loads)
+    rays_per_gpu = sum(int(round(B * R)) for _, _, B, R, _, _ in loads)
+    S0, Sf0 = loads[0][4], loads[0][5]
 
-    tt = torch.tensor([dt, float(evals_local)], device=dev, dtype=torch.float64)
-    if world > 1:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, evals_total = float(tmax[0]), float(tsum[1])
-    else:
-        evals_total = float(evals_local)
+    # the other scaling mode, same processes, right after (N > 1): the reference's own batch split over the ranks
+    strong = None
+    if len(modes) > 1:
+        del step
+        for tr, *_ in loads:
+            if getattr(tr, "fused", None) is not None:
+                tr.fused.ws = None
+        loads2, desc2 = build_workloads(args.config, dev, rank, world, modes[1], 0, hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on")
+        e2 = n_evals(loads2)
+        dt2, loss2, graphed2, comm2, _ = timed_run(loads2)
+        dt2, dt2_min, e2_total, comm2 = over_ranks(dt2, e2, comm2, loads2)
+        v2 = e2_total * args.steps / dt2
+        strong = dict(scaling=modes[1], ms_per_step=dt2 / args.steps * 1e3, ms_per_step_fastest_rank=dt2_min / args.steps * 1e3, value=v2, unit="ray-samples/s",
+                      mlp_evals_per_step_per_gpu=e2, rays_per_gpu=sum(int(round(B * R)) for _, _, B, R, _, _ in loads2),
+                      frac_of_train_roofline=round(v2 / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4), comm_ms=None if comm2 is None else round(comm2, 4),
+                      loss=loss2, hip_graph=graphed2, workload=desc2 + f"; the reference's batch split over {world} ranks")
+        del loads2
+
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -451,7 +570,7 @@ def main():
         # HBM bytes per launch of that kernel: rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE, bytes per
         # sample) times the samples one launch processes; a pointer to the committed measurement, not measured in this run
         traffic = None
-        for fname in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for fname in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     t = json.load(f)["bytes_per_sample"].get(dom)
@@ -476,15 +595,19 @@ def main():
     out = dict(metric="ray-samples/sec (warp+MLP+composite) on LLFF-fern, 1/2/4/8 GPUs + PSNR parity",
                value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32" if exact else args.precision, data="synthetic",
-               config=dict(workload=desc, name=args.config, rays_per_gpu=sum(int(round(B * R)) for _, _, B, R, _, _ in loads),
-                           samples_per_ray="+".join(str(x) for x in ((loads[0][4], loads[0][4] + loads[0][5]) if loads[0][5] else (loads[0][4],))),
+               config=dict(workload=desc, name=args.config, rays_per_gpu=rays_per_gpu,
+                           samples_per_ray="+".join(str(x) for x in ((S0, S0 + Sf0) if Sf0 else (S0,))),
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=par,
                            precision="exact fp32 MFMA" if exact else
                            f"{args.precision}: OPT-IN fast mode, split-bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation ("
                            + ("hi*hi + hi*mid + mid*hi, 16 significand bits per operand" if args.precision == "bf16x3" else "leading plane only, 8 bits") +
                            "); not the headline, own parity row in tests/test_gpu_fast_precision.py"),
                frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4),
-               loss=loss_value, hip_graph=graphed, ranks_seen=ranks_seen, backend=dist_backend, roofline=roofline, kernel_check=kernel_check, kernels=kernels)
+               loss=loss_value, hip_graph=graphed, ranks_seen=ranks_seen, backend=dist_backend, warmup_run=n_warm,
+               ms_per_step_fastest_rank=dt_min / args.steps * 1e3, comm_ms=None if comm_ms is None else round(comm_ms, 4), strong=strong,
+               launches_per_step="one niw_train_step call (~26 kernel launches for a single-pass config, ~35 with the fine pass) + gradient all-reduce + one Adam launch"
+               if getattr(loads[0][0], "fused", None) is not None else "autograd mirror over the per-stage entry points",
+               roofline=roofline, kernel_check=kernel_check, kernels=kernels)
     g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]
     S, Sf = loads[0][4], loads[0][5]
     if world == 1 and not args.no_composite_scan:
@@ -516,7 +639,7 @@ def main():
                                    frac_of_fwd_roofline=frac(t_img),
                                    stage_by_stage=dict(value=n_eval / t_sweep, ms_per_image=round(t_sweep * 1e3, 2), frac_of_fwd_roofline=frac(t_sweep),
                                                        slices=f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} of {opt.nerf.rand_rays} rays"))
-    if world == 1 and not args.no_psnr_parity:
+    if world == 1 and not args.no_psnr_parity and args.config != "cfg1":
         # the "+ PSNR parity" half of the metric, bounded: 10 identical optimisation steps on the HIP path and on the CPU oracle
         from oracle import parity
         pg, pc = parity.psnr_trajectories(dev, steps=10, precision=args.precision)
@@ -525,7 +648,7 @@ def main():
                                   sample="barf_inn_llff, 3 views x 16 rays x 32 samples on 12x16 images, identical weights / pixel draws / stratified draws, "
                                          "photometric PSNR of every step, HIP engine vs CPU oracle (autograd + torch.optim.Adam)")
     ga = {"cfg3": 4, "cfg5": 3}.get(args.config, 4 if args.config.startswith("cfg4") else None)
-    if world == 1 and not args.no_torch_baseline and not args.shard_of:
+    if world == 1 and not args.no_torch_baseline and not args.shard_of and args.config != "cfg1":
         rng_kw = dict(depth_range=(1.2, 5.2), param="metric") if args.config == "cfg5" else {}
         try:
             out["torch_rocm_baseline"] = torch_rocm_baseline(dev, loads[0][2], int(round(loads[0][3])), S, Sf, opt.H, opt.W, ga_weight=ga, **rng_kw)
@@ -533,7 +656,7 @@ def main():
         except torch.cuda.OutOfMemoryError as e:          # a reported side figure must not cost the line
             out["torch_rocm_baseline"] = dict(error=f"out of memory: {e}"[:200])
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(loads[0][2], S, Sf, opt.H, opt.W, ga_weight=ga)
+        out["cpu_baseline"] = cpu_baseline(loads[0][2], S, Sf, opt.H, opt.W, ga_weight=ga, vanilla=args.config == "cfg1")
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -92,6 +92,7 @@ SIGNATURES = {
     "niw_render_fwd": (_i, [ctypes.POINTER(RenderDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "niw_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _vp, _vp]),
     "niw_adam_step_multi": (_i, [ctypes.POINTER(AdamGroup), _i, _d, _d, _d, _vp, _vp]),
+    "niw_train_step_prepare": (_i, []),
     "niw_train_step_workspace_floats": (_i64, [ctypes.POINTER(TrainDesc)]),
     "niw_train_step": (_i, [ctypes.POINTER(TrainDesc), _vp, _i, _i, _vp]),
 }

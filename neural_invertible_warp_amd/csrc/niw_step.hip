@@ -14,6 +14,7 @@
 // Route sums are formed in the order autograd's accumulation would (fine compositing, fine field, coarse compositing, coarse field;
 // separately rounded), so the engine's parameters agree bit for bit with the autograd mirror on the same inputs.
 #include "niw_common.h"
+#include <stdlib.h>
 
 // launches that exist for this sequencer only (each = two launches of the public entry points in one, same arithmetic)
 int niw_launch_step_front(int64_t n_pixels, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, const float* intr, const float* pose, int n_views,
@@ -159,7 +160,7 @@ __global__ void adam_multi_kernel(AdamBatch b, const float* __restrict__ hyper_d
 
 // ---------------------------------------------------------------------------------------------------------------- second stream
 // The small stages that do not depend on each other run beside the field-MLP kernels (niw.h: niw_train_desc.overlap).  One
-// high-priority non-blocking stream and three events per device, created on first use and kept for the life of the process (like the
+// non-blocking stream and three events per device, created on first use and kept for the life of the process (like the
 // kernel-attribute cache of niw_common.h: process-global, write-once per device).
 struct SideLane {
     hipStream_t s = nullptr;
@@ -178,9 +179,14 @@ SideLane* side_lane() {
     bool ok = true;
     if (!(ready.load(std::memory_order_acquire) & bit)) {
         SideLane& L = lanes[dev];
+        // NORMAL priority.  Measured (round 4, cfg3 through a one-rank RCCL group): a high-priority second stream created AFTER the
+        // communicator's own (high-priority) stream cost the iteration 0.65 ms (7.08 vs 6.41 ms; created before it, or with normal
+        // priority either way: 6.41-6.44 ms); without a communicator the two priorities time alike (NIW_SIDE_PRIORITY=h|l: diagnostic)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // hi = numerically lowest = greatest priority
-        ok = hipStreamCreateWithPriority(&L.s, hipStreamNonBlocking, hi) == hipSuccess;
+        const char* pr = getenv("NIW_SIDE_PRIORITY");
+        const int prio = (pr && pr[0] == 'h') ? hi : (pr && pr[0] == 'l') ? lo : 0;
+        ok = hipStreamCreateWithPriority(&L.s, hipStreamNonBlocking, prio) == hipSuccess;
         for (hipEvent_t* e : {&L.warped, &L.dx, &L.join})
             ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         if (ok) ready.fetch_or(bit, std::memory_order_release);
@@ -288,6 +294,14 @@ int pack(const niw_train_desc* d, const float* params, float* image, niw_stream_
 }
 
 }  // namespace
+
+extern "C" int niw_train_step_prepare(void) {
+    if (!side_lane()) {
+        niw_set_error("niw_train_step_prepare: cannot create the second stream");
+        return NIW_ERR_LAUNCH;
+    }
+    return NIW_OK;
+}
 
 extern "C" int64_t niw_train_step_workspace_floats(const niw_train_desc* d) {
     if (check_desc(d) != NIW_OK) return 0;

@@ -22,6 +22,11 @@ from ._lib import NiwError
 from .util import edict
 
 
+class CaptureError(NiwError):
+    """HIP-graph capture of the train iteration failed: not recoverable in this process (HIP's capture error is sticky); a launcher
+    starts a fresh process with hip_graph=False (bench.py does)"""
+
+
 class StepConstants:
     """Every step-dependent SCALAR of a train iteration in one small device buffer, refreshed by one host-to-device copy per step:
     c2f band weights (10 + 4), the warp's annealing windows (6 + 6), the two step-dependent Adam scalars of every optimizer group
@@ -350,11 +355,14 @@ class INNTrainer:
             self.consts = StepConstants(dev, len(self.bucket.groups))
         self._bind_constants(False)                      # outside a train iteration the modules read host state (see _bind_constants)
         self.overlap = bool(overlap)                      # niw_train_desc.overlap: small independent stages on a second stream
+        self.comm_events = None                          # a list: device events around every gradient all-reduce are appended (bench.py comm_ms)
         self.fused = None
         if fused_step:
             why = FusedStep.unsupported(self)
             if why is None:
                 self.fused = FusedStep(self)
+                if self.overlap:
+                    _lib_mod.call("niw_train_step_prepare")      # the second stream exists before any later stream user creates theirs
             elif fused_step is True:
                 raise NiwError(f"fused_step=True: niw_train_step does not cover this configuration ({why})")
         self.fused_fallback_reason = None if self.fused is not None else (FusedStep.unsupported(self) if fused_step else "fused_step=False")
@@ -443,6 +451,16 @@ class INNTrainer:
         loss.update(all=total)
         torch.autograd.backward([loss[k] for k in keys], [self._loss_w[k][1] for k in keys])
 
+    def _all_reduce(self):
+        """the ONE collective of an iteration: in-place sum of the flat gradient bucket over the ranks (no-op without a live group)"""
+        if self.comm_events is None or not parallel._collectives_live():
+            return self.bucket.all_reduce()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.bucket.all_reduce()
+        b.record()
+        self.comm_events.append((a, b))
+
     def _optimizer_step(self, it):
         """torch.optim.Adam's update of every trained group (reference nerf.py:34-38, barf_inn_llff.py:84-104: two optimizers stepped one
         after the other) as ONE launch over the flat buffers"""
@@ -468,7 +486,7 @@ class INNTrainer:
             loss = self._graph_iteration(var, it, replay)
         else:
             loss = self._forward_backward(var, it)
-            self.bucket.all_reduce()
+            self._all_reduce()
             self._optimizer_step(it)
         self.it = it + 1
         for n in self.nets:
@@ -499,14 +517,14 @@ class INNTrainer:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     loss = self._forward_backward(mine, it)
-                    self.bucket.all_reduce()
+                    self._all_reduce()
                     self._optimizer_step(it)
                 torch.cuda.current_stream().wait_stream(side)
                 return loss
         fb, adam, loss = self._captured
         fb.replay()
         if adam is not None:                           # ranks exchange gradients between the two graphs
-            self.bucket.all_reduce()
+            self._all_reduce()
             adam.replay()
         return loss
 
@@ -574,8 +592,8 @@ class INNTrainer:
             # a capture that was invalidated half-way leaves HIP's capture error sticky on this process (measured: neither a new
             # stream nor CUDAGraph.reset() nor reseeding the generator brings launches back), so there is no eager fall-back to
             # offer: fail loudly and name the switch
-            raise NiwError(f"HIP-graph capture of the train iteration failed ({type(e).__name__}: {e}); "
-                           "run with hip_graph=False (bench.py --hip-graph off)") from e
+            raise CaptureError(f"HIP-graph capture of the train iteration failed ({type(e).__name__}: {e}); "
+                               "run with hip_graph=False (bench.py --hip-graph off)") from e
         self._captured = (fb, adam, loss)
         return True
 
@@ -604,6 +622,58 @@ class INNTrainer:
                 self.pose_net.pose_global.weight.data = parallel.gather_owned_rows(self.pose_net.pose_global.weight.data, win)
             else:
                 self.graph.gather_global_rigid()
+
+
+class NeRFTrainer:
+    """One train iteration of the VANILLA model (reference model/nerf.py:77-100 train_iteration + :251-288 Graph.forward / compute_loss:
+    ground-truth poses, no warp -- BASELINE configs[0], options/nerf_llff_repr.yaml) on the engine's plumbing: the Feistel pixel draw and
+    the in-kernel stratified draw instead of torch.randperm / torch.rand, gradients written straight into a flat bucket, one Adam launch
+    over both networks with the reference's ExponentialLR.  The render itself is the reference-shaped mirror (Graph.render over ..ops:
+    rays of the given poses, field, compositing, resampling, fine field) under autograd; rays carry no gradient here, so the dX chain
+    runs without its ray-gradient tail."""
+
+    def __init__(self, opt, n_views, seed=0):
+        from .model import nerf as nerf_model
+        torch.manual_seed(seed)
+        self.opt, self.n_views, self.it = opt, n_views, 0
+        self.graph = nerf_model.Graph(opt).to(opt.device)
+        self.nets = [self.graph.nerf] + ([self.graph.nerf_fine] if opt.nerf.fine_sampling else [])
+        dev = torch.device(opt.device)
+        self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets], dev)
+        for i, net in enumerate(self.nets):
+            net.grad_sink = self.bucket.segment(i)
+        self.bucket.sunk = set(range(len(self.nets)))
+        self.m = [torch.zeros_like(n.flat_params) for n in self.nets]
+        self.v = [torch.zeros_like(n.flat_params) for n in self.nets]
+        o = opt.optim
+        self.lr0, self.gamma = o.lr, _sched_gamma(o.lr, o.get("lr_end"), o.get("sched", {"type": "ExponentialLR"}), opt.max_iter, "optim.sched")
+        opt.nerf.stratified_rng = opt.nerf.get("stratified_rng") or ("philox" if dev.type == "cuda" else "torch")
+        self._captured = None
+        self.fused = None
+
+    def train_iteration(self, var, replay=True):
+        opt, g, it = self.opt, self.graph, self.it
+        B = len(var.idx)
+        n = opt.nerf.rand_rays // B
+        g._depth_draw, g._depth_call_in_iter = it + 1, 0
+        var.ray_idx = ops.draw_ray_idx(opt.H * opt.W, n, int(getattr(opt, "seed", 0) or 0), it + 1, opt.device)
+        var.update(g.render(opt, g.get_pose(opt, var, mode="train"), intr=var.intr, ray_idx=var.ray_idx, mode="train"))
+        loss = g.compute_loss(opt, var, mode="train")
+        keys = [k for k in loss if opt.loss_weight[k] is not None]
+        total = None
+        with torch.no_grad():
+            for k in keys:
+                w = 10 ** float(opt.loss_weight[k])
+                total = loss[k] * w if total is None else torch.add(total, loss[k], alpha=w)
+        torch.autograd.backward([loss[k] for k in keys], [torch.full_like(loss[k], 10 ** float(opt.loss_weight[k])) for k in keys])
+        loss.update(all=total)
+        lr = self.lr0 * self.gamma ** it
+        ops.adam_step_multi([(n_.flat_params, self.bucket.segment(i), self.m[i], self.v[i], lr, it + 1) for i, n_ in enumerate(self.nets)])
+        self.it = it + 1
+        return loss
+
+    def _flats(self):
+        return [n.flat_params for n in self.nets]
 
 
 def synthetic_scene(opt, n_views, seed=0):

@@ -52,3 +52,47 @@ def test_parent_does_not_import_torch_and_propagates_the_exit_code(tmp_path):
     import json
     argv = json.loads(out.read_text())
     assert "--nproc-per-node=2" in argv and argv[-5:] == ["--gpus", "2", "--steps", "3", "--lean"]
+
+
+def test_parent_restarts_fresh_ranks_without_the_graph_when_a_capture_failed(tmp_path):
+    """`--hip-graph on` under N > 1: a rank whose capture failed leaves the marker file and dies; the parent (which never touched the
+    GPU) must start a SECOND set of ranks with `--hip-graph off` appended and exit with THEIR code.  The stub plays both generations."""
+    stub = tmp_path / "torch" / "distributed"
+    stub.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (stub / "__init__.py").write_text("")
+    (stub / "run.py").write_text("import sys, json, os\n"
+                                 "log = os.environ['NIW_STUB_OUT']\n"
+                                 "runs = json.load(open(log)) if os.path.exists(log) else []\n"
+                                 "runs.append(sys.argv[1:])\n"
+                                 "json.dump(runs, open(log, 'w'))\n"
+                                 "if len(runs) == 1:\n"
+                                 "    open(os.environ['NIW_CAPTURE_FAILED_FILE'], 'w').write('capture failed')\n"
+                                 "    sys.exit(1)\n"
+                                 "sys.exit(0)\n")
+    out = tmp_path / "runs.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(tmp_path), NIW_STUB_OUT=str(out))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--lean", "--hip-graph", "on"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    import json
+    runs = json.loads(out.read_text())
+    assert len(runs) == 2
+    assert runs[0][-2:] == ["--hip-graph", "on"] and runs[1][-4:] == ["--hip-graph", "on", "--hip-graph", "off"]      # argparse: the last one wins
+    port = lambda argv: argv[argv.index("--master-port") + 1]
+    assert port(runs[0]) != port(runs[1])                                 # a fresh rendezvous
+    assert "starting fresh ranks" in r.stderr
+
+
+def test_a_failing_rank_without_the_marker_is_not_retried(tmp_path):
+    stub = tmp_path / "torch" / "distributed"
+    stub.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (stub / "__init__.py").write_text("")
+    (stub / "run.py").write_text("import sys, os\nopen(os.environ['NIW_STUB_OUT'], 'a').write('x')\nsys.exit(3)\n")
+    out = tmp_path / "count"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(tmp_path), NIW_STUB_OUT=str(out))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lean"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and out.read_text() == "x"

@@ -72,7 +72,8 @@ def test_photometric_share_kernel_equals_the_slice_of_the_whole_batch():
 def test_bench_line_through_a_live_rccl_group_eager_and_captured():
     """bench.py --force-dist: a ONE-rank RCCL process group (everything a one-GPU box can exercise of the N > 1 path on hardware): the
     rank check (an all-reduce of ones through RCCL), the flat gradient all-reduce, and -- with --hip-graph on -- capture and replay of
-    the iteration while the communicator is live.  Both runs must print a line with ranks_seen 1, backend nccl and the same loss."""
+    the iteration while the communicator is live.  Both runs must print a line with ranks_seen 1, backend nccl and the same loss
+    (same number of untimed iterations in front: a launched run takes at least 16, bench.py n_warm)."""
     import json
     import os
     import subprocess
@@ -84,7 +85,7 @@ def test_bench_line_through_a_live_rccl_group_eager_and_captured():
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg3", "--lean", "--force-dist", "--hip-graph", mode,
-                            "--steps", "4", "--warmup", "3", "--kernel-steps", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                            "--steps", "4", "--warmup", "16", "--kernel-steps", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["ranks_seen"] == 1 and line["backend"] == "nccl" and line["hip_graph"] == (mode == "on")
