@@ -7,9 +7,15 @@ ROCm kernels (seconds; on the host cores it would take minutes).  It is still th
     cfg3   18 views x 113 rays x 128, c2f encoding at progress 0.3, alignment term x 1e4
     cfg5   3 views x 682 rays x 128, metric depth [1.2, 5.2], poses composed with noisy initial poses (unwarped rays in the world frame)
 
-Forward values at the small-shape tolerances (rgb / opacity atol 3e-5 rtol 2e-4, warped points 2e-5, loss 1e-6); every gradient
-group relative to its own max: NeRF 5e-3, warp latents 1e-2 (the tolerances of tests/test_gpu_parity.py and test_gpu_configs.py,
-unchanged by the 100x larger batch), warp network 2e-2.  Needs a GPU."""
+Forward values at the small-shape tolerances (rgb / opacity atol 3e-5 rtol 2e-4, warped points 2e-5, loss 1e-6) against the oracle's
+fp32 evaluation.  GRADIENTS (round 4) against the oracle evaluated in FLOAT64 on the same GPU at the same full shapes -- the same
+function with 29 more bits, ~25 GB of autograd state at cfg2 -- and held to a conditioning bound instead of rounds 1-3's blanket
+2e-2 / 5e-2 against another fp32 evaluation.  The yardstick is the COMPARATOR'S OWN fp32 evaluation (torch's kernels, same inputs)
+against the same float64 gradients: a tensor of the HIP path may deviate from the float64 gradient by max(3 x what torch's fp32 does
+on THAT tensor, 6 x the median of what it does over the tensors of the group) + 2e-4 of the tensor's scale -- i.e. the HIP path must
+be as good an fp32 evaluation of these gradients as torch's, tensor by tensor (conditioning differs by 20 x between tensors of one
+network: the first layer sees the 2^9 pi band).  Measured worst / bound and worst HIP / comparator ratios are printed per group.
+Needs a GPU."""
 import numpy as np
 import pytest
 import torch
@@ -63,23 +69,65 @@ def _dev_params(seed_c, seed_w, seed_l, B, seed_f=None):
     return pc, pf, wp, lat
 
 
-def _compare_grads(named, ref, tol, report, prefix):
-    """every tensor relative to its own max |g|; the 1- and 3-element head biases of the warp (`*_1.bias`: sums over all points that
-    largely cancel -- 3 % of their layer's weight gradient in places) relative to the max of the same layer's WEIGHT gradient, the
-    scale of the terms they are summed from (tests/util.check_grad_vs_fp64 does the same)"""
-    worst = 0.0
-    named = list(named)
-    for k, prm in named:
-        if k in ref and ref[k].grad is not None:
-            assert prm.grad is not None, f"{prefix}{k}: no gradient on the HIP path"
-            e = _rel(prm.grad, ref[k].grad)
-            if k.endswith("_1.bias") and prm.numel() <= 16:
-                w = ref[k[:-len("bias")] + "weight"].grad
-                e = float((prm.grad.detach() - ref[k].grad.detach()).abs().max() / torch.maximum(w.abs().max(), ref[k].grad.abs().max()))
-            worst = max(worst, e)
-            limit = 3 * tol if (k.endswith("_1.bias") and prm.numel() <= 16) else tol       # 1- / 3-element sums: see the docstring
-            assert e < limit, f"{prefix}{k}: {e:.3e} of max, tolerance {limit}"
-    report.append(f"{prefix}worst gradient error {worst:.2e} of max (tolerance {tol})")
+FACTOR_TENSOR, FACTOR_GROUP, FLOOR = 3.0, 6.0, 2e-4
+
+
+def _err(g, g64, scale64):
+    return float((g.detach().double() - g64).abs().max() / scale64)
+
+
+def _scale64(key, grads64):
+    """max |g64| of the tensor; for the 1- and 3-element head biases of the warp (sums over all points that largely cancel) the max of
+    the same layer's WEIGHT gradient, the scale of the terms they are summed from (tests/util.check_grad_vs_fp64 does the same)"""
+    s = float(grads64[key].abs().max())
+    if key.endswith("_1.bias") and grads64[key].numel() <= 16:
+        s = max(s, float(grads64[key[:-len("bias")] + "weight"].abs().max()))
+    return max(s, 1e-300)
+
+
+def _check_group_vs_fp64(name, hip, torch32, grads64, report):
+    """hip / torch32 / grads64: {key: gradient} of one optimizer group (HIP path, oracle fp32 on the GPU, oracle float64 on the GPU)"""
+    keys = [k for k in grads64 if grads64[k] is not None and float(grads64[k].abs().max()) > 0]
+    cond = {k: _err(torch32[k], grads64[k], _scale64(k, grads64)) for k in keys}
+    mine = {k: _err(hip[k], grads64[k], _scale64(k, grads64)) for k in keys}
+    med = float(np.median(list(cond.values())))
+    bound = {k: max(FACTOR_TENSOR * cond[k], FACTOR_GROUP * med) + FLOOR for k in keys}
+    worst = max(keys, key=lambda k: mine[k] / bound[k])
+    report.append(f"  {name:<14} {len(keys):3d} tensors | comparator fp32 vs fp64: median {med:.2e} worst {max(cond.values()):.2e} | HIP vs fp64: median "
+                  f"{np.median(list(mine.values())):.2e} worst {max(mine.values()):.2e} | worst error / bound {mine[worst] / bound[worst]:.2f} ({worst}: "
+                  f"{mine[worst]:.2e} of {bound[worst]:.2e}) | worst HIP / comparator {max(mine[k] / max(cond[k], 1e-12) for k in keys):.2f}")
+    for k in keys:
+        assert mine[k] <= bound[k], f"{name}.{k}: {mine[k]:.3e} of scale from the float64 gradient, bound {bound[k]:.3e} (comparator's own fp32: {cond[k]:.3e})"
+    return mine[worst] / bound[worst]
+
+
+def _oracle_step64(pc, pf, wp, lat, image, intr, ray_idx, u, S, Sf, depth_range, param, alpha, ga, w3, wv, pose_init=None):
+    """the oracle's INN train step in float64 on the device of its inputs: parameters and inputs cast, the fp32 band tables kept, the
+    un-warped points formed in fp32 and cast -- exactly how tests/golden/make_golden_dtu_fp64.py runs the REFERENCE in float64
+    (tests/test_oracle_golden.py pins that evaluation of the oracle to the reference's float64 gradients to 4e-8)
+    -> {group: {key: gradient}}"""
+    dt = torch.float64
+    d = lambda prm: {k: v.detach().to(dt).requires_grad_(True) for k, v in prm.items()}
+    pc64, wp64 = d(pc), d(wp)
+    pf64 = d(pf) if pf is not None else None
+    lat64 = lat.detach().to(dt).requires_grad_(True)
+    c0, g0 = O.unwarped_center_and_grid(H, W, intr, ray_idx, pose_init)
+    ray, center, grid3 = O.warped_rays(wp64, lat64, c0.to(dt), g0.to(dt), alpha, True)
+    kw = {} if w3 is None else dict(w3d=w3.to(dt).to(image.device), wview=wv.to(dt).to(image.device))
+    out = O.render_rays(pc64, center, ray, u.to(dt), S, depth_range, param, p_fine=pf64, Sf=Sf, **kw)
+    target = O.gather_pixels(image.to(dt), ray_idx)
+    total = O.mse_loss(out["rgb"], target)
+    if pf64 is not None:
+        total = total + O.mse_loss(out["rgb_fine"], target)
+    if ga is not None:
+        total = total + (10.0 ** ga) * O.global_alignment_loss(g0.to(dt), c0.to(dt), grid3, center)[0]
+    total.backward()
+    g = lambda prm: {k: v.grad for k, v in prm.items()}
+    groups = dict(nerf=g(pc64), warp=g(wp64), latent=dict(weight=lat64.grad))
+    if pf64 is not None:
+        groups["nerf_fine"] = g(pf64)
+    del out, total
+    return groups
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
@@ -132,17 +180,16 @@ def test_llff_train_step_at_baseline_shapes_vs_oracle_on_the_gpu(cfg):
         assert abs(float(loss.render_fine.detach()) - float(ref["loss_render_fine"].detach())) < 1e-6
     if ga is not None:
         assert abs(float(loss.global_alignment.detach()) - float(ref["loss_ga"].detach())) <= 1e-4 * float(ref["loss_ga"].detach()) + 1e-9
-    _compare_grads(graph.nerf.named_parameters(), pc, 5e-3, report, "nerf.")
+    # gradients: every optimizer group against the oracle in FLOAT64 at these shapes, bounded by the comparator's own fp32 conditioning
+    ref64 = _oracle_step64(pc, pf, wp, lat, image, intr, ray_idx, u, S, Sf, (1, 0), "inverse", it / opt.inn.real_nvp.max_pe_iter, ga, w3, wv)
+    grads = lambda named: {k: p.grad for k, p in named}
+    tgrads = lambda prm: {k: v.grad for k, v in prm.items()}
+    report.append(f"gradients vs the oracle in float64 (bound per tensor = max({FACTOR_TENSOR} x the comparator's own fp32 deviation on it, {FACTOR_GROUP} x the group's median) + {FLOOR}):")
+    ratios = [_check_group_vs_fp64("nerf", grads(graph.nerf.named_parameters()), tgrads(pc), ref64["nerf"], report)]
     if Sf:
-        _compare_grads(graph.nerf_fine.named_parameters(), pf, 5e-3, report, "nerf_fine.")
-    # (2e-2 where the small-shape tests against the CPU oracle hold 1e-2: the comparator here is itself an fp32 evaluation by other
-    # kernels -- torch's.  cfg3 agrees to 1e-3; in cfg2 the fine pass's sample positions come from torch's parallel fp32 cumulative
-    # sum on one side and the sequential fp64 sum of the CPU reference on the other, and that position noise reaches the ray
-    # gradients: measured 1.0e-2 on one head weight, 1.1e-2 on the latent table)
-    _compare_grads(graph.warp_mlp.named_parameters(), wp, 2e-2, report, "warp_mlp.")
-    e = _rel(graph.warp_latent.weight.grad, lat.grad)
-    report.append(f"warp_latent gradient error {e:.2e} of max")
-    assert e < 2e-2
+        ratios.append(_check_group_vs_fp64("nerf_fine", grads(graph.nerf_fine.named_parameters()), tgrads(pf), ref64["nerf_fine"], report))
+    ratios.append(_check_group_vs_fp64("warp_mlp", grads(graph.warp_mlp.named_parameters()), tgrads(wp), ref64["warp"], report))
+    ratios.append(_check_group_vs_fp64("warp_latent", dict(weight=graph.warp_latent.weight.grad), dict(weight=lat.grad), ref64["latent"], report))
     print("\n".join(report))
 
 
@@ -184,12 +231,14 @@ def test_dtu_train_step_at_baseline_shape_vs_oracle_on_the_gpu():
     torch.testing.assert_close(var.opacity, ref["opacity"], atol=3e-5, rtol=2e-4)
     assert abs(float(loss.render.detach()) - float(ref["loss_render"].detach())) < 1e-6
     report = [f"cfg5: {B} x {R} x {S}, max |rgb - oracle| {float((var.rgb - ref['rgb']).abs().max()):.2e}"]
-    _compare_grads(graph.nerf.named_parameters(), pc, 1e-2, report, "nerf.")
-    # the pose network's gradients at world-scale inputs: two fp32 evaluations (this one, torch's on the GPU) scatter at the percent
-    # level (measured 2.8e-2 on one first-layer bias); the float64 fixture of test_gpu_parity.test_inn_train_step_dtu_c2f_golden pins
-    # the same kernels against the reference's float64 gradients
-    _compare_grads(pose_net.pose_embedding.named_parameters(), wp, 5e-2, report, "pose_embedding.")
-    e = _rel(pose_net.pose_latent.weight.grad, lat.grad)
-    report.append(f"pose_latent gradient error {e:.2e} of max")
-    assert e < 5e-2
+    # gradients against the oracle in FLOAT64 at the full shape (the pose network's gradients at world-scale inputs scatter at the
+    # percent level between ANY two fp32 evaluations: rounds 1-3 held this test to 5e-2 against torch's fp32 kernels)
+    ref64 = _oracle_step64(pc, None, wp, lat, image, intr, ray_idx, u, S, 0, (1.2, 5.2), "metric", it / opt.inn.real_nvp.max_pe_iter, None, w3, wv,
+                           pose_init=init)
+    grads = lambda named: {k: p.grad for k, p in named}
+    tgrads = lambda prm: {k: v.grad for k, v in prm.items()}
+    report.append(f"gradients vs the oracle in float64 (bound per tensor = max({FACTOR_TENSOR} x the comparator's own fp32 deviation on it, {FACTOR_GROUP} x the group's median) + {FLOOR}):")
+    _check_group_vs_fp64("nerf", grads(graph.nerf.named_parameters()), tgrads(pc), ref64["nerf"], report)
+    _check_group_vs_fp64("pose_embedding", grads(pose_net.pose_embedding.named_parameters()), tgrads(wp), ref64["warp"], report)
+    _check_group_vs_fp64("pose_latent", dict(weight=pose_net.pose_latent.weight.grad), dict(weight=lat.grad), ref64["latent"], report)
     print("\n".join(report))
