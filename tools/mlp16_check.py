@@ -1,6 +1,6 @@
-"""EXPERIMENT: the 16-sample-wave forward (csrc/niw_mlp16.hip) against the product forward: same outputs, device-event time.
+"""EXPERIMENT: the 16-sample-wave forward (experiments/niw_mlp16.hip) against the product forward: same outputs, device-event time.
 Build:  make -C neural_invertible_warp_amd/csrc VARIANT=v16 EXPERIMENTS=niw_mlp16.hip;  run with NIW_LIB_PATH=neural_invertible_warp_amd/libniw_hip_v16.so.
-Result (MI355X, round 3): DESIGN.md section 7."""
+Result (MI355X): HISTORY.md (round 3, full size) and profiles/r4_v16_small_launches.json (round 4, a rank's 1/8 share)."""
 import argparse, ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FLOP = 2 * 527872
