@@ -1,10 +1,10 @@
 #!/bin/bash
 # Refresh the rocprofv3 evidence under profiles/ in one go (run on the GPU box from the repo root):
-#   bash tools/collect_profiles.sh r3        -> gpurun_out/profiles_r3/*  (copy what should be judged into profiles/)
+#   bash tools/collect_profiles.sh r4        -> gpurun_out/profiles_r4/*  (copy what should be judged into profiles/)
 # Kernel-trace statistics per config, the three PMC passes over the MLP kernels (separate runs, --kernel-trace only beside --pmc),
 # the two composite traffic passes, and the un-profiled microbenchmarks.  The profiled program itself follows `--`.
 set -u
-tag=${1:-r3}
+tag=${1:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$tag
 mkdir -p $OUT
@@ -39,6 +39,15 @@ for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES GR
   echo "pmc $d: $(ls $W/pmc/$d 2>/dev/null | head -3 | tr '\n' ' ')"
 done
 python3 $ROOT/tools/mlp_traffic.py $W/pmc $OUT/${tag} > $W/mlp_traffic.log 2>&1 || tail -5 $W/mlp_traffic.log
+# the same three passes over the opt-in fast-precision kernels (their roofline is HBM as much as MFMA: bench.py reports both ceilings)
+for prec in bf16x3 bf16; do
+  for c in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    d=${c%%:*}; ctr=${c#*:}
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $W/pmc_$prec/$d -o pm -- python3 $ROOT/tools/mlp_bench.py --iters 2 --sizes 4086x192 --precision $prec > $W/pmc_${prec}_$d.log 2>&1
+  done
+  python3 $ROOT/tools/mlp_traffic.py $W/pmc_$prec $OUT/${tag}_fast_$prec $prec > $W/mlp_traffic_$prec.log 2>&1 || tail -5 $W/mlp_traffic_$prec.log
+  echo "pmc $prec: $(ls $OUT | grep fast_$prec | tr '\n' ' ')"
+done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/pmc/cfetch -o pm -- python3 $ROOT/tools/composite_bench.py --iters 3 --sizes full > $W/cfetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/pmc/cwrite -o pm -- python3 $ROOT/tools/composite_bench.py --iters 3 --sizes full > $W/cwrite.log 2>&1
 python3 $ROOT/tools/composite_traffic.py $W/pmc $OUT/${tag}_composite_traffic.json > $W/ctraffic.log 2>&1 || tail -5 $W/ctraffic.log

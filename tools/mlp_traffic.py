@@ -19,7 +19,13 @@ import sys
 SAMPLES = 4086 * 192
 NAMES = {"mlp_fwd_kernel<true>": "mlp_fwd_train", "mlp_fwd_kernel<false>": "mlp_fwd", "mlp_bwd_dx_kernel": "mlp_bwd_dx",
          "dw_gemm_kernel<4, 2, 2, 4": "mlp_bwd_dw_wide_batch", "dw_gemm_kernel<8, 1, 1, 2": "mlp_bwd_dw_skinny_batch",
-         "dw_gemm_kernel<4, 2, 1, 5": "mlp_bwd_dw_colour", "dw_gemm_kernel<4, 1, 1, 9": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce"}
+         "dw_gemm_kernel<4, 2, 1, 5": "mlp_bwd_dw_colour", "dw_gemm_kernel<4, 1, 1, 9": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce",
+         # the opt-in fast-precision kernels (tools/mlp_bench.py --precision bf16x3 | bf16)
+         "mlp_fwd_fast_kernel<3, true>": "mlp_fwd_train", "mlp_fwd_fast_kernel<3, false>": "mlp_fwd", "mlp_bwd_dx_fast_kernel<3>": "mlp_bwd_dx",
+         "mlp_fwd_fast_kernel<1, true>": "mlp_fwd_train", "mlp_fwd_fast_kernel<1, false>": "mlp_fwd", "mlp_bwd_dx_fast_kernel<1>": "mlp_bwd_dx",
+         "dw_gemm_fast_kernel<4, 2, 2, 4": "mlp_bwd_dw_wide_batch", "dw_gemm_fast_kernel<8, 1, 1, 2": "mlp_bwd_dw_skinny_batch",
+         "dw_gemm_fast_kernel<4, 2, 1, 5": "mlp_bwd_dw_colour", "dw_gemm_half_kernel<4, 2, 2, 4": "mlp_bwd_dw_wide_batch",
+         "dw_gemm_half_kernel<8, 1, 1, 2": "mlp_bwd_dw_skinny_batch", "dw_gemm_half_kernel<4, 2, 1, 5": "mlp_bwd_dw_colour"}
 ALGO = {  # algorithmic bytes per sample: reads / writes of the workspaces, fp32
     "mlp_fwd_train": dict(read=16.0, write=9384.0), "mlp_fwd": dict(read=16.0, write=16.0),
     # dX reads: 288 B sign masks + 384 B parked skip / view gradients (written and read back) + 384 B saved encodings (for d point,
@@ -34,14 +40,31 @@ ALGO = {  # algorithmic bytes per sample: reads / writes o
 def per_kernel(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(mlp_fwd_kernel<\w+>|mlp_bwd_dx_kernel|dw_gemm_kernel<\d, \d, \d, \d|dw_reduce_kernel)", r["Kernel_Name"])
+        m = re.search(r"(mlp_fwd_kernel<\w+>|mlp_bwd_dx_kernel|mlp_fwd_fast_kernel<\d, \w+>|mlp_bwd_dx_fast_kernel<\d>|dw_gemm(?:_fast|_half)?_kernel<\d, \d, \d, \d|"
+                      r"dw_reduce_kernel)", r["Kernel_Name"])
         if m:
             agg[NAMES[m.group(1)]][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[NAMES[m.group(1)]]["dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
-def main(out, prefix):
+def bf16_algo():
+    """NIW_PREC_BF16 keeps every row the dW pass multiplies as bf16 (niw_mlp_fast.hip kHalfWorkspace): activations / dY rows 2 bytes per
+    sample instead of 4; the raw density, the sign masks and the stash rows stay fp32"""
+    a = {k: dict(v) for k, v in ALGO.items()}
+    act_rows = 64 + 7 * 256 + 256 + 32 + 128                                   # enc, h1..h7, feat, venc, hr
+    a["mlp_fwd_train"] = dict(read=16.0, write=act_rows * 2.0 + 2 * 4.0 + 288.0)
+    dy_rows = 7 * 256 + 256 + 4 + 128 + 8                                       # dY0..dY6, dY7 (+ d sigma quad), dYrgb0, dYrgb1 (2 quads)
+    a["mlp_bwd_dx"] = dict(read=288.0 + 384.0 + 192.0 + 12 + 4 + 12 + 4 + 4, write=dy_rows * 2.0 + 96 * 4.0 + 32.0)
+    for k in ("mlp_bwd_dw_wide_batch", "mlp_bwd_dw_skinny_batch", "mlp_bwd_dw_colour"):
+        a[k] = dict(read=ALGO[k]["read"] / 2, write=0.0)
+    return a
+
+
+def main(out, prefix, precision="fp32"):
+    global ALGO
+    if precision == "bf16":
+        ALGO = bf16_algo()
     f, w, m = (per_kernel(f"{out}/{d}/pm_counter_collection.csv") for d in ("fetch", "write", "mfma"))
     traffic = {}
     for k in f:
@@ -54,7 +77,8 @@ def main(out, prefix):
                           read_over_algorithmic=round(2 * fr / ALGO[k]["read"], 3),
                           write_over_algorithmic=round(wr / ALGO[k]["write"], 3) if ALGO[k]["write"] else None,
                           read_excess_bytes_per_sample=round(2 * fr - ALGO[k]["read"], 1))
-    doc = dict(source="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192; "
+    doc = dict(precision=precision,
+               source=f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192 --precision {precision}; "
                       "MI355X; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream), WRITE_SIZE as reported; KiB = 1024 B",
                samples_per_launch=SAMPLES, bytes_per_sample=traffic,
                note="read excess of the register-chained kernels = weight fragments re-fetched through the fabric: the 2.1 MB transposed / forward "
@@ -68,11 +92,11 @@ def main(out, prefix):
         rows.append(dict(kernel=k, avg_ms=round(sec * 1e3, 3), clock_ghz=round(cyc / sec / 1e9, 3),
                          mfma_util=round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc), 4),
                          frac_of_2p4ghz_peak=round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * sec * 2.4e9), 4)))
-    json.dump(dict(source="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192 "
+    json.dump(dict(precision=precision, source=f"rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/mlp_bench.py --iters 2 --sizes 4086x192 --precision {precision} "
                           "(profiled passes run a few per cent slower than un-profiled ones)", kernels=rows), open(prefix + "_mfma_util.json", "w"), indent=1)
     print(json.dumps(traffic, indent=1))
     print(json.dumps(rows, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "fp32")
