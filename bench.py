@@ -590,7 +590,7 @@ def main():
             # bf16 quad rows in bf16); counter traffic of these kernels: profiles/r4_fast_<precision>_traffic.json.
             terms = 3 if args.precision == "bf16x3" else 1
             algo = {"fp32w": {"mlp_fwd_train": 16.0 + 9384.0, "mlp_fwd": 32.0, "mlp_bwd_dx": 1092.0 + 9168.0},
-                    "bf16w": {"mlp_fwd_train": 16.0 + 4864.0, "mlp_fwd": 32.0, "mlp_bwd_dx": 900.0 + 4760.0}}["fp32w" if terms == 3 else "bf16w"][dom]
+                    "bf16w": {"mlp_fwd_train": 16.0 + 4840.0, "mlp_fwd": 32.0, "mlp_bwd_dx": 900.0 + 4792.0}}["fp32w" if terms == 3 else "bf16w"][dom]
             ms, n = kernels[dom]["avg_ms"], kernels[dom]["samples_per_launch"]
             gbps = algo * n / (ms * 1e-3) / 1e9
             issued_tf = a * terms                                     # bf16 MFMA work actually issued

@@ -450,7 +450,7 @@ typedef struct niw_train_desc {
  * call.  Streams share a small number of hardware queues in creation order; a process that also runs RCCL / other stream users calls
  * this first, so that the second stream does not end up sharing a hardware queue with the stream it is meant to run beside. */
 int niw_train_step_prepare(void);
-/* floats of the workspace (16-byte aligned); <= 0 with niw_last_error_string() set when the descriptor is not supported */
+/* floats of the workspace (256-byte aligned); <= 0 with niw_last_error_string() set when the descriptor is not supported */
 int64_t niw_train_step_workspace_floats(const niw_train_desc* desc);
 int niw_train_step(const niw_train_desc* desc, float* workspace, int stage_begin, int stage_end, niw_stream_t stream);
 

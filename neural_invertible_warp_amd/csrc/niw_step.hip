@@ -39,12 +39,17 @@ using niw::add_rn;
 using niw::mul_rn;
 using niw::sub_rn;
 
-struct Carve {             // hands out consecutive 16-byte aligned pieces of the workspace
-    float* p;
-    long long used = 0;
+#ifndef NIW_CARVE_FLOATS
+#define NIW_CARVE_FLOATS 64
+#endif
+constexpr long long kCarveFloats = NIW_CARVE_FLOATS;
+
+struct Carve {             // hands out consecutive pieces of the workspace, each starting on a 256-byte boundary of it (two cache lines: the
+    float* p;              // kernels' 16-byte vector accesses, the LDS-DMA of the fast-precision kernels and whole-line streaming stores all
+    long long used = 0;    // see the alignment separate allocations had)
     float* take(long long n) {
         float* r = p ? p + used : nullptr;
-        used += (n + 3) / 4 * 4;
+        used += (n + kCarveFloats - 1) / kCarveFloats * kCarveFloats;
         return r;
     }
 };
@@ -317,6 +322,7 @@ extern "C" int64_t niw_train_step_workspace_floats(const niw_train_desc* d) {
 extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int stage_begin, int stage_end, niw_stream_t stream) {
     NIW_RUN(check_desc(d));
     NIW_REQUIRE(workspace, "niw_train_step: null workspace");
+    NIW_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "niw_train_step: the workspace must start on a 256-byte boundary");
     NIW_REQUIRE(0 <= stage_begin && stage_begin < stage_end && stage_end <= NIW_STAGE_END, "niw_train_step: stages [%d, %d) of %d", stage_begin, stage_end, (int)NIW_STAGE_END);
     const Layout L = make_layout(d, workspace);
     hipStream_t st = (hipStream_t)stream;
