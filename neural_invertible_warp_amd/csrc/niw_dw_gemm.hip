@@ -13,6 +13,7 @@
 #include "niw_mlp_device.h"
 #include "niw_bf16.h"
 #include <type_traits>
+#include <stdlib.h>
 
 using namespace niw;
 
@@ -51,7 +52,7 @@ constexpr int kColourTK = 288;
 
 // Up to kMaxBatch independent products per launch (blockIdx.y): the seven 256 x 256 weight gradients of a network, or its four
 // skinny pieces -- each with its own operand pair and bias side.
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 28;      // 7 layers x 4 quadrant tiles in the small-batch form of the wide launch (niw_mlp_bwd_dw)
 struct GemmBatch {
     NiwGemmOperand A[kMaxBatch], B[kMaxBatch];
     int bias_side[kMaxBatch];
@@ -69,11 +70,27 @@ struct GemmBatch {
 // QUAD: the operands are quad-row images [row / 4][samples][4] (the field MLP's workspaces, niw_mlp_device.h): a 16-byte load is
 // four rows of one sample and goes to four LDS rows as ds_write_b32 (32 lanes = 32 consecutive samples of a row: conflict free).
 // Plain [row][samples] operands (the warp's factor rows) take the b128 path.
+// Block -> (product, sample range).  Plain launches: grid (nsplit, products).  XCD-grouped launches (map.groups_pad > 0; the small-batch
+// wide launch, whose products come in sets of `map.set` tiles that read the same operand rows): a 1-D grid of set x groups_pad blocks,
+// block = member * groups_pad + group, group = set_index * nsplit + split.  groups_pad is a multiple of 8 and blocks are dealt round-robin
+// over the 8 XCDs, so the members of a set -- same group, ids groups_pad apart -- share an XCD's L2 (placement is speed only).
+struct BlockMap {
+    int groups_pad, groups, nsplit, set;
+};
+
 template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD>
 __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
-                                                               float* __restrict__ partial) {
-    const NiwGemmOperand opA = batch.A[blockIdx.y], opB = batch.B[blockIdx.y];
-    const int bias_side = batch.bias_side[blockIdx.y];
+                                                               float* __restrict__ partial, BlockMap map) {
+    int bx = blockIdx.x, by = blockIdx.y, nx = gridDim.x;
+    if (map.groups_pad > 0) {
+        const int member = (int)blockIdx.x / map.groups_pad, group = (int)blockIdx.x % map.groups_pad;
+        if (group >= map.groups) return;                      // (the whole workgroup leaves before its first barrier)
+        bx = group % map.nsplit;
+        by = (group / map.nsplit) * map.set + member;
+        nx = map.nsplit;
+    }
+    const NiwGemmOperand opA = batch.A[by], opB = batch.B[by];
+    const int bias_side = batch.bias_side[by];
     constexpr int TN = WN * NBW * 32, TK = WK * KBW * 32, NT = 64 * WN * WK;
     constexpr int ROWS = TN + TK;
     constexpr int LOADS = ROWS * 8 / NT;                  // float4 loads per thread per 32-sample step
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WK, wk = wave % WK;
     const int i = lane & 31, h = lane >> 5;
-    const int step0 = blockIdx.x * steps_per_wg;
+    const int step0 = bx * steps_per_wg;
     bool live[NBW][KBW];
 #pragma unroll
     for (int x = 0; x < NBW; ++x)
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
         if (PF >= 3 && s + 2 < nsteps) step_body(s + 2, std::integral_constant<int, 2 % PF>{});
     }
     // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
-    float* out = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (TN * TK + 256);
+    float* out = partial + ((long long)by * nx + bx) * (TN * TK + 256);
 #pragma unroll
     for (int x = 0; x < NBW; ++x)
 #pragma unroll
@@ -556,7 +573,7 @@ struct ReduceArgs {
     int transposed;   // tile is [slot][row] instead of [row][slot]
     int bias;         // 0: none, 1: bias sums indexed by the dY row
 };
-constexpr int kMaxPieces = 16;
+constexpr int kMaxPieces = 40;
 struct ReduceBatch {
     ReduceArgs r[kMaxPieces];
 };
@@ -622,6 +639,8 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     // (two rounds balance better at >= 130 k samples; below, one round halves the partial-tile traffic that then dominates:
     // measured 216 / 350 / 601 us against 252 / 374 / 629 us for the whole dW group at 16 k / 32 k / 65 k samples)
     const int rounds = steps_total <= 4096 ? 1 : 2;
+    // (tried in round 4: 128 workgroups of 8 slices instead of 255 of 4 for the colour layer of a 1/8 share -- half the partial tiles, but the
+    // launch itself took 47 us instead of 36 with half the CUs idle, more than the reducer saved)
     const int cap = batches >= 4 ? (rounds * 256 - 1) / batches : 256;
     // short reductions (the warp's few thousand points, a 1/8 ray shard): fewer slices per workgroup, down to 2, until the
     // launch has a workgroup for every CU -- the partial tile each workgroup writes (<= 256 KB) is the price of a split
@@ -646,7 +665,8 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
             return NIW_ERR_INVALID_ARG;
         }
     }
-    kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(batch, steps_total, per, partial);
+    if constexpr (TERMS == 0) kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(batch, steps_total, per, partial, BlockMap{0, 0, 0, 0});
+    else kern<<<dim3(nsplit, batches), 64 * WN * WK, lds, st>>>(batch, steps_total, per, partial);
     NIW_LAUNCH_CHECK("NT GEMM");
     *nsplit_out = nsplit;
     return NIW_OK;
@@ -662,6 +682,36 @@ int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, 
 #endif
     return wide ? launch_gemm<4, 2, 2, 4, false, 1, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st)
                 : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st);
+}
+
+// The seven 256 x 256 products of a network over a SHORT reduction (<= 131 k samples: a rank's 1/8 share), as 7 x 4 quadrant tiles of
+// 128 x 128 in ONE round of workgroups: 9 sample ranges per tile instead of 36 per product, i.e. a quarter of the partial-tile bytes
+// (16.5 MB instead of 66 MB at 32 k samples, which the reducer then re-reads), while the four tiles of a product and sample range sit on
+// one XCD (BlockMap) and share the operand rows they all read through its L2.
+int launch_wide_quadrants(const GemmBatch& batch, int n_sets, long long mpad, float* partial, int* nsplit_out, hipStream_t st) {
+    constexpr int WN = 4, WK = 2, NBW = 1, KBW = 2, TN = 128, TK = 128;
+    const int steps_total = (int)(mpad / 32);
+    int nsplit = 64 / n_sets;                                  // 7 products: 9 ranges -> 63 groups, padded to 64
+    if (nsplit > (steps_total + 1) / 2) nsplit = (steps_total + 1) / 2;
+    if (nsplit < 1) nsplit = 1;
+    const int per = (steps_total + nsplit - 1) / nsplit;
+    nsplit = (steps_total + per - 1) / per;
+    const int groups = n_sets * nsplit, groups_pad = (groups + 7) / 8 * 8;
+    const size_t lds = 2 * (size_t)(TN + TK) * kLdsStride * sizeof(float);
+    auto kern = dw_gemm_kernel<WN, WK, NBW, KBW, false, 1, true>;
+    static std::atomic<unsigned long long> attr_set{0ull};
+    if (int rc = niw_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, "NT GEMM (quadrants)")) return rc;
+    for (int b = 0; b < 4 * n_sets; ++b) {
+        const long long ea = (long long)batch.A[b].rows * batch.A[b].row_stride * 4, eb = (long long)batch.B[b].rows * batch.B[b].row_stride * 4;
+        if (ea >= (1ll << 31) || eb >= (1ll << 31) || mpad > batch.A[b].row_stride || mpad > batch.B[b].row_stride) {
+            niw_set_error("NT GEMM (quadrants): operand exceeds the 2 GiB reach of a buffer descriptor");
+            return NIW_ERR_INVALID_ARG;
+        }
+    }
+    kern<<<dim3(4 * groups_pad, 1), 64 * WN * WK, lds, st>>>(batch, steps_total, per, partial, BlockMap{groups_pad, groups, nsplit, 4});
+    NIW_LAUNCH_CHECK("NT GEMM (quadrants)");
+    *nsplit_out = nsplit;
+    return NIW_OK;
 }
 
 }  // namespace
@@ -737,7 +787,34 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     ReduceBatch rb{};
     int n_pieces = 0, max_tile = 0;
     long long off = 0;
+    // short reduction (one round of the register-chained kernels, <= 32,768 samples): see launch_wide_quadrants.  NIW_DW_QUADRANTS=<max
+    // slices> moves the threshold (diagnostic; 0 = never)
+    static const long long quad_max = [] { const char* e = getenv("NIW_DW_QUADRANTS"); return e ? atoll(e) : 1024ll; }();
+    const bool quadrants = precision == NIW_PREC_FP32 && mpad / 32 <= quad_max;
     for (const Group& g : groups) {
+        if (quadrants && g.wide == 1) {
+            GemmBatch gb{};
+            for (int b = 0; b < g.n; ++b)
+                for (int q = 0; q < 4; ++q) {
+                    const Piece& p = g.p[b];
+                    const int qn = q >> 1, qk = q & 1;
+                    gb.A[4 * b + q] = NiwGemmOperand{gradws + (long long)(p.a_row + 128 * qn) * mpad, 128, 0, mpad};
+                    gb.B[4 * b + q] = NiwGemmOperand{save + (long long)(p.b_row + 128 * qk) * mpad, 128, 0, mpad};
+                    gb.bias_side[4 * b + q] = (p.bias && qk == 0) ? 1 : 0;
+                }
+            int nsplit = 0;
+            if (int rc = launch_wide_quadrants(gb, g.n, mpad, partial + off, &nsplit, st)) return rc;
+            const long long tile = 128ll * 128 + 256;
+            for (int b = 0; b < g.n; ++b)
+                for (int q = 0; q < 4; ++q) {
+                    const Piece& p = g.p[b];
+                    rb.r[n_pieces++] = ReduceArgs{off + (long long)(4 * b + q) * nsplit * tile, nsplit, 128, 128, p.layer, p.n_off + 128 * (q >> 1),
+                                                  p.k_off + 128 * (q & 1), 0, (p.bias && (q & 1) == 0) ? 1 : 0};
+                }
+            off += 4ll * g.n * nsplit * tile;
+            max_tile = (int)tile > max_tile ? (int)tile : max_tile;
+            continue;
+        }
         GemmBatch gb{};
         for (int b = 0; b < g.n; ++b) {
             const Piece& p = g.p[b];
