@@ -396,7 +396,7 @@ __device__ __forceinline__ float density_act_fast(float x, int kind) {
 
 static_assert((8 * 16 / kStageChunks) % kRingStages == 0, "a 256 -> 256 layer is a whole number of ring turns: the layers of one rolled loop share their ring phase");
 
-// Store-data hazard (round 3, tools/store_war_hazard.hip).  The bf16 (one-term) kernels need fewer than 256
+// Store-data hazard (round 3, tools/store_war_hazard.hip, HISTORY.md).  The bf16 (one-term) kernels need fewer than 256
 // registers, so two of their workgroups share a CU -- and on gfx950 a 16-byte buffer store with an SGPR soffset that is followed AT ONCE by
 // a vector write of its data registers stores the new value when waves share a SIMD.  LLVM inserts the wait state only for stores whose
 // soffset is an immediate, and hipcc did schedule that pair in these epilogues: every launch of more than 256 workgroups stored corrupted

@@ -13,7 +13,7 @@ held to written here:
               inside the exact bar on these inputs)
     bf16      atol 2e-2 (SURVEY 8(c)'s bf16 class)    --                            relative L2 0.2   (measured 0.13)
 
-(The bf16 mode keeps its saved activations and layer gradients as bf16 inside the caller's buffers -- DESIGN.md section 3.7; its weight
+(The bf16 mode keeps its saved activations and layer gradients as bf16 inside the caller's buffers -- HISTORY.md "3.7 Opt-in fast precision"; its weight
 gradients are what the fp32-workspace form of the mode gave, to the bits, except the bias sums; these tests cover it unchanged.)
 
 Needs a GPU."""

@@ -1,7 +1,7 @@
 // Microbenchmark: what does an instruction of each class cost a dependent chain of fp32 MFMAs when it is issued between them?
 // hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_contention.hip -o tools/mfma_valu_contention
 // One wave per SIMD, v_mfma_f32_32x32x2_f32 (64 cycles each); K instructions of class OP per group of 4 MFMAs.
-// Result (MI355X, round 3): see DESIGN.md section 3.1 -- ordinary VALU instructions are NOT free in the shadow of an fp32 MFMA.
+// Result (MI355X, round 3): see HISTORY.md ("What an instruction costs the chain") -- ordinary VALU instructions are NOT free in the shadow of an fp32 MFMA.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
