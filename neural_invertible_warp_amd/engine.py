@@ -189,6 +189,7 @@ class FusedStep:
         self.rgb_fine = torch.empty(n, 3, device=dev) if Sf else None
         d.rgb, d.rgb_fine = self.rgb.data_ptr(), (self.rgb_fine.data_ptr() if Sf else None)
         self.shape = (B, R, S, Sf, n, win)
+        self._built_for = self._batch_signature(var)
         self.desc = d
         self._refresh(var)
         if self.ring is None:
@@ -217,11 +218,19 @@ class FusedStep:
         table = self.pose_table
         d.poses = None if table is None else table.data.data_ptr()
 
-    def _same_batch(self, var):
-        B, R, S, Sf, n, win = self.shape
+    def _batch_signature(self, var):
+        """what the descriptor was built from: the caller's tensors (storage AND content version: the DTU depth range is read to the host
+        when the descriptor is built), the batch shape and the loss weights"""
         opt = self.tr.opt
-        return (len(var.idx) == B and opt.nerf.rand_rays // B == R and opt.nerf.sample_intvs == S and var.image.data_ptr() == self.desc.image
-                and var.intr.data_ptr() == self.desc.intr and self._weights()[2] == self.desc.w_align and self._weights()[0] == self.desc.w_render)
+        sig = [len(var.idx), opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0, self._weights(),
+               bool(opt.nerf.sample_stratified), tuple(opt.nerf.depth.range), opt.nerf.depth.param]
+        for k in ("image", "intr", "depth_range"):
+            t = var.get(k) if hasattr(var, "get") else getattr(var, k, None)
+            sig.append(None if t is None else (t.data_ptr(), tuple(t.shape), t._version if k == "depth_range" else 0))
+        return sig
+
+    def _same_batch(self, var):
+        return self._batch_signature(var) == self._built_for
 
     # ------------------------------------------------------------------ one iteration
     def run(self, var, it):
