@@ -46,6 +46,7 @@ def init_from_env(backend=None, force=False):
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or os.environ.get("NIW_DIST_BACKEND")           # (gloo: several ranks on ONE GPU -- logic tests on a 1-GPU box)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
