@@ -121,7 +121,10 @@ int niw_mlp_bwd(const float* packed, const float* center, const float* ray,
 
 /* The two passes of niw_mlp_bwd as separate entry points (niw_mlp_bwd = dx then dw):
  *   niw_mlp_bwd_dx: the register-chained dX chain; writes every dY into gradws, then d_center / d_ray (a second, small launch);
- *   niw_mlp_bwd_dw: dW = dY . X^T (split-M NT GEMMs on the fp32 MFMA path) + deterministic reduction. */
+ *   niw_mlp_bwd_dw: dW = dY . X^T (split-M NT GEMMs on the fp32 MFMA path) + deterministic reduction.  In exact mode from 131,072
+ *     samples its two matrix-vector pieces (density row, colour rows) run on a library-owned second stream, forked from and joined to
+ *     `stream` by events inside the call (capturable; the stream is created at the first such call or by niw_train_step_prepare(),
+ *     which must therefore come before a stream capture that contains the call).  `stream`-ordered like every other entry point. */
 int niw_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
                    int64_t n_rays, int n_samples, int density_activ, int precision,
                    const float* rgb, const float* d_rgb, const float* d_sigma,
@@ -446,8 +449,8 @@ typedef struct niw_train_desc {
     int32_t reserved;
 } niw_train_desc;
 
-/* Optional: create the library's second stream (niw_train_desc.overlap) for the current device NOW instead of at the first overlapped
- * call.  Streams share a small number of hardware queues in creation order; a process that also runs RCCL / other stream users calls
+/* Optional: create the library's own streams (niw_train_desc.overlap; niw_mlp_bwd_dw's second stream) for the current device NOW instead
+ * of at the first call that uses them.  Streams share a small number of hardware queues in creation order; a process that also runs RCCL / other stream users calls
  * this first, so that the second stream does not end up sharing a hardware queue with the stream it is meant to run beside. */
 int niw_train_step_prepare(void);
 /* floats of the workspace (256-byte aligned); <= 0 with niw_last_error_string() set when the descriptor is not supported */

@@ -14,6 +14,7 @@
 #include "niw_bf16.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <atomic>
 
 using namespace niw;
 
@@ -611,9 +612,190 @@ __global__ void dw_reduce_kernel(ReduceBatch batch, const float* __restrict__ pa
     }
 }
 
+// ---- The two GEMV-shaped pieces of a network's weight gradient -- the density row (dsigma . h7^T: 1 x 256) and the colour rows
+// (d rgb_raw . hr^T: 3 x 128) -- on the vector ALU.  As pieces of the skinny MFMA launch they cost a 256 x 64 tile of matrix work each
+// for 1 / 3 useful columns and 0.35 ms of a cfg2 step (HISTORY.md): they are pure HBM time (1.5 KB per sample) with next to no
+// arithmetic, so they run on a second stream BESIDE the wide launch, which is matrix-bound and leaves 70 % of the HBM rate unused.
+// One wave: Q quads (4 Q rows) of X over one chunk of samples, 64 lanes = 64 consecutive samples of a quad (1 KB per load
+// instruction), R dY rows; partial tiles in the reducer's format ([chunk][tile + 256]: transposed tile [slot][row], then the bias sums).
+struct HeadsArgs {
+    const float* X[2];     // first quad of h7 / hr in the forward's workspace image
+    const float* D[2];     // the quad that holds dsigma (element 0) / the three d rgb_raw rows (elements 0..2)
+    float* partial[2];     // [chunk][256 * 1 + 256] / [chunk][128 * 3 + 256]
+    long long mpad;
+    int per;               // samples per chunk
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += x * d (both halves by the SAME scalar d): the scalar is element SEL of the register pair `dpair` -- selected by op_sel, not
+// copied into a pair first.  The kernel shares its SIMDs with the matrix waves of the wide launch (fp32 MFMA and vector instructions of
+// one SIMD do not overlap, tools/mfma_valu_contention.hip) and has 64 registers, so its loop is written to the minimum: one
+// v_pk_fma_f32 per two products, buffer loads with scalar offsets (no address arithmetic), no moves.
+template <int SEL>
+__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, f32x2 x, f32x2 dpair) {
+    if constexpr (SEL == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(dpair));
+    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(dpair));
+}
+
+// Sum each of N per-lane values over the 64 lanes in ~3 N vector instructions instead of 6 N: at step s the lanes whose bit s is set keep
+// the upper half of the values and hand the lower half to their partner (and vice versa), so the count halves with every exchange.  On
+// return lane l < N holds the total of value bitrev(l) (bit reversal over log2 N bits).
+template <int N, int MASK = 1, int CNT = N>
+__device__ __forceinline__ float reduce_pack(float (&v)[N]) {
+    if constexpr (MASK >= 64) return v[0];
+    else if constexpr (CNT > 1) {
+        constexpr int H = CNT / 2;
+        const bool upper = (threadIdx.x & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const float give = upper ? v[i] : v[i + H], keep = upper ? v[i + H] : v[i];
+            v[i] = keep + __shfl_xor(give, MASK, 64);
+        }
+        return reduce_pack<N, MASK * 2, H>(v);
+    } else {
+        v[0] += __shfl_xor(v[0], MASK, 64);
+        return reduce_pack<N, MASK * 2, 1>(v);
+    }
+}
+template <int BITS>
+__device__ __forceinline__ int bitrev(int x) {
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) r |= ((x >> b) & 1) << (BITS - 1 - b);
+    return r;
+}
+
+// Q quads of X (from quad `quad0`) times R rows of the dY quad over the samples [m0, m1) (a multiple of 128 long), one wave
+template <int Q, int R, bool BIAS>
+__device__ __forceinline__ void heads_body(rsrc_t rsX, rsrc_t rsD, long long mpad, long long m0, long long m1, int quad0, float* __restrict__ out,
+                                           int tile) {
+    const int lane = threadIdx.x & 63;
+    f32x2 acc[Q][R][2];
+    f32x2 bs[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[q][r][0] = acc[q][r][1] = f32x2{0.f, 0.f};
+    const int voff = lane * 16;
+    // 32-bit scalar byte offsets (the host keeps every operand below 2 GiB)
+    const int qstride = (int)(mpad * 16), trips = (int)((m1 - m0) >> 7);
+    int soff = (int)(m0 * 16);
+    for (int trip = 0; trip < trips; ++trip, soff += 2048) {
+        // two 64-sample groups per trip: 2 (Q + 1) loads of 16 bytes in flight per lane
+        f32x4 x[2][Q], d[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            d[t] = buf_load4(rsD, voff, soff + 1024 * t);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) x[t][q] = buf_load4(rsX, voff, (quad0 + q) * qstride + soff + 1024 * t);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (BIAS) {
+                bs[0] += d[t].lo;
+                bs[1] += d[t].hi;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                pk_fma_bcast<0>(acc[q][0][0], x[t][q].lo, d[t].lo);
+                pk_fma_bcast<0>(acc[q][0][1], x[t][q].hi, d[t].lo);
+                if constexpr (R == 3) {
+                    pk_fma_bcast<1>(acc[q][1][0], x[t][q].lo, d[t].lo);
+                    pk_fma_bcast<1>(acc[q][1][1], x[t][q].hi, d[t].lo);
+                    pk_fma_bcast<0>(acc[q][2][0], x[t][q].lo, d[t].hi);
+                    pk_fma_bcast<0>(acc[q][2][1], x[t][q].hi, d[t].hi);
+                }
+            }
+        }
+    }
+    // the tile is [slot][row]: value index (4 q + j) R + r
+    constexpr int N = Q * 4 * R;
+    float v[N];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[(q * 4 + j) * R + r] = acc[q][r][j >> 1][j & 1];
+    float* dst = out + quad0 * 4 * R;
+    if constexpr (N == 16) {
+        const float tot = reduce_pack<16>(v);
+        if (lane < 16) dst[bitrev<4>(lane)] = tot;
+    } else {
+        static_assert(N == 24, "4 quads x 1 row or 2 quads x 3 rows");
+        float lo[16], hi[8];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lo[k] = v[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hi[k] = v[16 + k];
+        const float t0 = reduce_pack<16>(lo), t1 = reduce_pack<8>(hi);
+        if (lane < 16) dst[bitrev<4>(lane)] = t0;
+        if (lane < 8) dst[16 + bitrev<3>(lane)] = t1;
+    }
+    if constexpr (BIAS) {
+        float b[4] = {bs[0][0], bs[0][1], bs[1][0], bs[1][1]};
+        const float tot = reduce_pack<4>(b);
+        if (lane < R) out[tile + bitrev<2>(lane)] = tot;
+    }
+}
+
+// grid (chunks), 4 waves: wave w walks quad groups w, w + 4, w + 8, w + 12 of h7 (4 quads each) and of hr (2 quads each) over the chunk's
+// samples; with <= 256 chunks that is at most one wave per SIMD of the chip.  64 REGISTERS: the wide launch keeps two waves of 222 (224)
+// registers on every SIMD, which leaves exactly 64 -- a heads wave that needs more cannot join them; its workgroups then take CUs of their
+// own between the wide launch's rounds and make that launch's workgroups wait for them (measured with 114 registers: the wide launch
+// +290..390 us, the heads kernel stretched to 2.9 ms, i.e. all of the gain lost).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dw_heads_kernel(HeadsArgs a) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const long long m0 = (long long)blockIdx.x * a.per, m1 = m0 + a.per < a.mpad ? m0 + a.per : a.mpad;
+    float* out0 = a.partial[0] + (long long)blockIdx.x * (256 + 256);
+    float* out1 = a.partial[1] + (long long)blockIdx.x * (384 + 256);
+    // descriptors end with the operand: X = 64 / 32 quads of mpad samples; the dY quad = mpad samples (host: < 2 GiB each)
+    const rsrc_t rsX0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X[0]), 0, (int)(64 * a.mpad * 16), 0x00020000);
+    const rsrc_t rsX1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X[1]), 0, (int)(32 * a.mpad * 16), 0x00020000);
+    const rsrc_t rsD0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D[0]), 0, (int)(a.mpad * 16), 0x00020000);
+    const rsrc_t rsD1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D[1]), 0, (int)(a.mpad * 16), 0x00020000);
+    if (wave == 0) heads_body<4, 1, true>(rsX0, rsD0, a.mpad, m0, m1, 0, out0, 256);
+    else heads_body<4, 1, false>(rsX0, rsD0, a.mpad, m0, m1, wave * 4, out0, 256);
+    for (int g = 1; g < 4; ++g) heads_body<4, 1, false>(rsX0, rsD0, a.mpad, m0, m1, (wave + 4 * g) * 4, out0, 256);
+    if (wave == 0) heads_body<2, 3, true>(rsX1, rsD1, a.mpad, m0, m1, 0, out1, 384);
+    else heads_body<2, 3, false>(rsX1, rsD1, a.mpad, m0, m1, wave * 2, out1, 384);
+    for (int g = 1; g < 4; ++g) heads_body<2, 3, false>(rsX1, rsD1, a.mpad, m0, m1, (wave + 4 * g) * 2, out1, 384);
+}
+
+// the stream the heads kernel runs on, and the two events that fork it from / join it to the caller's stream (all capturable; created on
+// first use, which therefore must not happen under stream capture: niw_train_step_prepare() and any launched warm-up iteration do it)
+struct HeadsLane {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+HeadsLane* heads_lane() {
+    static HeadsLane lanes[64];
+    static std::atomic<unsigned long long> ready{0ull};
+    static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    const unsigned long long bit = 1ull << dev;
+    if (ready.load(std::memory_order_acquire) & bit) return &lanes[dev];
+    while (busy.test_and_set(std::memory_order_acquire)) {}
+    bool ok = true;
+    if (!(ready.load(std::memory_order_acquire) & bit)) {
+        HeadsLane& L = lanes[dev];
+        ok = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;       // normal priority (niw_step.hip: SideLane)
+        ok = ok && hipEventCreateWithFlags(&L.fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&L.join, hipEventDisableTiming) == hipSuccess;
+        if (ok) ready.fetch_or(bit, std::memory_order_release);
+    }
+    busy.clear(std::memory_order_release);
+    return ok ? &lanes[dev] : nullptr;
+}
+
 // every group's partial tiles live side by side until the single reduction: <= 511 tiles of 256 x 256 (7 x 73 splits),
 // <= 508 of 256 x 64 (4 x 127), <= 256 of 128 x 320
-constexpr long long kPartialTileFloats = 511ll * (256 * 256 + 256) + 508ll * (256 * 64 + 256) + 256ll * (128 * 320 + 256);
+// + the vector-ALU head pieces: <= 256 chunks of (256 x 1 + 256) and (128 x 3 + 256)
+constexpr int kHeadChunks = 256;
+constexpr long long kPartialTileFloats = 511ll * (256 * 256 + 256) + 512ll * (256 * 64 + 256) + 256ll * (128 * 320 + 256) + kHeadChunks * (512ll + 640ll);
 
 struct Piece {
     int layer;
@@ -641,7 +823,7 @@ int launch_gemm(const GemmBatch& batch, long long mpad, int batches, float* part
     const int rounds = steps_total <= 4096 ? 1 : 2;
     // (tried in round 4: 128 workgroups of 8 slices instead of 255 of 4 for the colour layer of a 1/8 share -- half the partial tiles, but the
     // launch itself took 47 us instead of 36 with half the CUs idle, more than the reducer saved)
-    const int cap = batches >= 4 ? (rounds * 256 - 1) / batches : 256;
+    const int cap = batches >= 2 ? (rounds * 256 - 1) / batches : 256;
     // short reductions (the warp's few thousand points, a 1/8 ray shard): fewer slices per workgroup, down to 2, until the
     // launch has a workgroup for every CU -- the partial tile each workgroup writes (<= 256 KB) is the price of a split
     int min_slices = 8;
@@ -732,6 +914,8 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
     return launch_shape<false>(wide, gb, mpad, batches, partial, nsplit_out, st);
 }
 
+int niw_dw_heads_prepare() { return heads_lane() ? NIW_OK : NIW_ERR_LAUNCH; }
+
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {
     (void)n_rays; (void)n_samples;
     return kPartialTileFloats;
@@ -763,10 +947,12 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     hipStream_t st = (hipStream_t)stream;
     // dW pieces.  Non-transposed: tile rows = dY rows (gradws), tile columns = X slots (save).
     // Transposed (skinny dY: the density row, the 3 colour rows): tile rows = X slots, columns = dY rows.
-    // Four launches per network: [layers 1..7: seven 256 x 256 products] [four 256 x 64 pieces] [the colour layer, 128 x 288 in a
-    // 128 x 320 tile] [one reduction of all twelve partial-tile sets].  (Tried: the density row as a 257th row of layer 7's
-    // product, formed on the vector ALU from the staged h6 slice -- the skinny launch lost 75 us of 506 at 523 k samples, but the
-    // wide kernel paid 80 us for the mere presence of the code and 50 more for running it.)
+    // Launches per network: [layers 1..7: seven 256 x 256 products] [256 x 64 pieces: the encoding columns of layers 0 and 4 -- in the
+    // fast-precision modes and below 131 k samples also the density row and the colour rows] [the colour layer, 128 x 288 in a 128 x 320
+    // tile] [one reduction of all partial-tile sets]; from 131 k samples in exact mode the density row and the colour rows are
+    // dw_heads_kernel's, on a second stream beside the first launch.  (Tried: the density row as a 257th row of layer 7's product,
+    // formed on the vector ALU from the staged h6 slice -- the skinny launch lost 75 us of 506 at 523 k samples, but the wide kernel paid
+    // 80 us for the mere presence of the code and 50 more for running it; as an MFMA row block of that product: HISTORY.md.)
     static_assert(kGradY7 == 7 * 256, "dY blocks of layers 0..7 are uniformly strided");
     static_assert(kSaveEnc % 4 == 0 && kSaveH1 % 4 == 0 && kSaveFeat % 4 == 0 && kSaveHr % 4 == 0 && kGradY7 % 4 == 0 &&
                   kGradRgb0 % 4 == 0 && kGradRgb1 % 4 == 0 && kSaveSigma % 4 == 0, "operands of the quad-row images start on whole quads");
@@ -782,11 +968,61 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         {7, save_h(7), 256, kGradY7 + 256, 1, 256, 0, 1, 1, 0},          // density row (transposed)
         {9, kSaveHr, 128, kGradRgb1, 3, 0, 0, 1, 1, 0}};                 // colour rows (transposed)
     const Piece colour[1] = {{8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2}};   // feat rows and the 32 view-slot rows are contiguous
+    // exact mode: the density row and the colour rows leave the skinny launch for dw_heads_kernel on a second stream (NIW_DW_HEADS=0: the
+    // four-piece skinny launch as in the fast-precision modes, whose workspaces are bf16 images; =1: heads kernel on the caller's stream)
+    // from 131 k samples (NIW_DW_HEADS_MIN slices of 32): below, fork + join cost more than the two pieces (cfg3 1/8 share, 65 k samples:
+    // 1.02 ms with the heads kernel, 0.99 without)
+    static const int heads_mode = [] { const char* e = getenv("NIW_DW_HEADS"); return e ? atoi(e) : 2; }();
+    static const long long heads_min = [] { const char* e = getenv("NIW_DW_HEADS_MIN"); return e ? atoll(e) : 4096ll; }();
+    const bool heads = precision == NIW_PREC_FP32 && heads_mode > 0 && mpad / 32 >= heads_min;
     struct Group { const Piece* p; int n, wide, TN, TK; };
-    const Group groups[3] = {{wide, 7, 1, 256, 256}, {skinny, 4, 0, 256, 64}, {colour, 1, 2, 128, kColourTK}};
+    const Group groups[3] = {{wide, 7, 1, 256, 256}, {skinny, heads ? 2 : 4, 0, 256, 64}, {colour, 1, 2, 128, kColourTK}};
     ReduceBatch rb{};
     int n_pieces = 0, max_tile = 0;
     long long off = 0;
+    HeadsLane* lane = nullptr;
+    if (heads) {
+        static const int head_chunks = [] { const char* e = getenv("NIW_DW_HEAD_CHUNKS"); const int v = e ? atoi(e) : kHeadChunks; return v < 1 ? 1 : (v > kHeadChunks ? kHeadChunks : v); }();
+        int per = (int)(((mpad + head_chunks - 1) / head_chunks + 127) / 128 * 128);
+        per = per < 512 ? 512 : per;
+        const int chunks = (int)((mpad + per - 1) / per);
+        if (64 * mpad * 16 >= (1ll << 31)) {
+            niw_set_error("niw_mlp_bwd_dw: %lld samples exceed the 2 GiB reach of a buffer descriptor", mpad);
+            return NIW_ERR_INVALID_ARG;
+        }
+        HeadsArgs ha{};
+        ha.X[0] = save + (long long)save_h(7) * mpad;
+        ha.D[0] = gradws + (long long)(kGradY7 + 256) * mpad;
+        ha.X[1] = save + (long long)kSaveHr * mpad;
+        ha.D[1] = gradws + (long long)kGradRgb1 * mpad;
+        ha.partial[0] = partial + off;
+        ha.partial[1] = partial + off + (long long)chunks * 512;
+        ha.mpad = mpad;
+        ha.per = per;
+        rb.r[n_pieces++] = ReduceArgs{off, chunks, 256, 1, 7, 256, 0, 1, 1};
+        rb.r[n_pieces++] = ReduceArgs{off + (long long)chunks * 512, chunks, 128, 3, 9, 0, 0, 1, 1};
+        off += (long long)chunks * (512 + 640);
+        max_tile = 384 + 256;
+        hipStream_t hs = st;
+        if (heads_mode >= 2) {
+            lane = heads_lane();
+            if (!lane) {
+                niw_set_error("niw_mlp_bwd_dw: cannot create the second stream");
+                return NIW_ERR_LAUNCH;
+            }
+            if (hipEventRecord(lane->fork, st) != hipSuccess || hipStreamWaitEvent(lane->s, lane->fork, 0) != hipSuccess) {
+                niw_set_error("niw_mlp_bwd_dw: cannot fork the second stream");
+                return NIW_ERR_LAUNCH;
+            }
+            hs = lane->s;
+        }
+        dw_heads_kernel<<<chunks, 256, 0, hs>>>(ha);
+        NIW_LAUNCH_CHECK("niw_mlp_bwd (dW heads)");
+        if (lane && hipEventRecord(lane->join, hs) != hipSuccess) {
+            niw_set_error("niw_mlp_bwd_dw: cannot record the join of the second stream");
+            return NIW_ERR_LAUNCH;
+        }
+    }
     // short reduction (one round of the register-chained kernels, <= 32,768 samples): see launch_wide_quadrants.  NIW_DW_QUADRANTS=<max
     // slices> moves the threshold (diagnostic; 0 = never)
     static const long long quad_max = [] { const char* e = getenv("NIW_DW_QUADRANTS"); return e ? atoll(e) : 1024ll; }();
@@ -837,6 +1073,10 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         }
         off += (long long)g.n * nsplit * tile;
         max_tile = (int)tile > max_tile ? (int)tile : max_tile;
+    }
+    if (lane && hipStreamWaitEvent(st, lane->join, 0) != hipSuccess) {
+        niw_set_error("niw_mlp_bwd_dw: cannot join the second stream");
+        return NIW_ERR_LAUNCH;
     }
     dw_reduce_kernel<<<dim3((max_tile + 255) / 256, n_pieces), 256, 0, st>>>(rb, partial, d_params);
     NIW_LAUNCH_CHECK("niw_mlp_bwd (dW reduce)");

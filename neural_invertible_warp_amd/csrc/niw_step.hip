@@ -300,8 +300,10 @@ int pack(const niw_train_desc* d, const float* params, float* image, niw_stream_
 
 }  // namespace
 
+int niw_dw_heads_prepare();   // niw_dw_gemm.hip: the stream of the vector-ALU head pieces of the weight gradient
+
 extern "C" int niw_train_step_prepare(void) {
-    if (!side_lane()) {
+    if (!side_lane() || niw_dw_heads_prepare() != NIW_OK) {
         niw_set_error("niw_train_step_prepare: cannot create the second stream");
         return NIW_ERR_LAUNCH;
     }

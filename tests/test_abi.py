@@ -125,5 +125,5 @@ def test_every_entry_point_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.niw_render_fwd_workspace_floats(2, 10, 8, 4) == 4 * 60 + 3 * 160 + 480 + 2 * 240 + 720
     # workspace queries are pure host arithmetic
     assert lib.niw_warp_prep_fwd_workspace_floats(18) == 3 * 18 * 128
-    assert lib.niw_mlp_bwd_workspace_floats(4, 8) == 511 * (256 * 256 + 256) + 508 * (256 * 64 + 256) + 256 * (128 * 320 + 256)
+    assert lib.niw_mlp_bwd_workspace_floats(4, 8) == 511 * (256 * 256 + 256) + 512 * (256 * 64 + 256) + 256 * (128 * 320 + 256) + 256 * (512 + 640)
     assert lib.niw_mlp_packed_floats() > 2 * 527872
