@@ -22,7 +22,7 @@ per-GPU ray count fixed (the global draw is N times larger; every rank warps all
 B x R rays); `strong` keeps the reference's GLOBAL batch (4096 / 2048 rays) and splits it over the ranks.  `--shard-of K` (N = 1 only) runs rank 0's 1/K shard of the global batch
 on one GPU: a proxy of what one rank of a K-GPU strong-scaled job executes (no collective).  Prints ONE JSON line on rank 0.
 
-An iteration is ONE library call (niw_train_step: forward, losses, backward of every stage, ~26 launches) + the gradient all-reduce
+An iteration is ONE library call (niw_train_step: forward, losses, backward of every stage, 25 launches) + the gradient all-reduce
 (N > 1) + ONE Adam launch.  At N = 1 the timed iterations replay a captured HIP graph of it (the step's scalars -- c2f bands, warp
 windows, Adam bias corrections, pixel-draw number -- travel in a 256-byte device buffer refreshed before every replay); under N > 1
 the default is launch by launch, which since round 4 is the FASTER form at every size (the host needs ~0.3 ms per iteration, a rank's
@@ -637,7 +637,7 @@ def main():
                frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4),
                loss=loss_value, hip_graph=graphed, ranks_seen=ranks_seen, backend=dist_backend, warmup_run=n_warm,
                ms_per_step_fastest_rank=dt_min / args.steps * 1e3, comm_ms=None if comm_ms is None else round(comm_ms, 4), strong=strong,
-               launches_per_step="one niw_train_step call (~26 kernel launches for a single-pass config, ~35 with the fine pass) + gradient all-reduce + one Adam launch"
+               launches_per_step="one niw_train_step call (25 kernel launches for a single-pass config, 35 with the fine pass) + gradient all-reduce + one Adam launch"
                if getattr(loads[0][0], "fused", None) is not None else "autograd mirror over the per-stage entry points",
                roofline=roofline, kernel_check=kernel_check, kernels=kernels)
     g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]

@@ -190,6 +190,44 @@ def test_mlp_backward_vs_oracle(S, activ):
     relclose(c2.grad, center.grad, 2e-3); relclose(r2.grad, ray.grad, 2e-3)
 
 
+def test_mlp_weight_gradient_at_a_batch_that_takes_the_vector_head_pieces():
+    """From 131,072 samples the exact-mode weight gradient forms the density row and the colour rows in dw_heads_kernel (vector ALU, second
+    stream beside the wide MFMA launch) instead of as two pieces of the skinny MFMA launch.  1100 rays x 128 samples = 140,800 samples
+    take that path; comparator = the oracle in FLOAT64 on the GPU (exact to the digits shown), so the bound is the fp32 kernels' own
+    rounding over a 140 k-term sum: 2e-4 of each tensor's max."""
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(23)
+    N, S, activ = 1100, 128, "softplus"
+    p32 = O.make_nerf_params(8)
+    p = {k: v.double().to(DEV).requires_grad_(True) for k, v in p32.items()}
+    center, ray, depth = _mlp_inputs(rng, N, S)
+    w3, wv = O.c2f_weights(0.3, (0.1, 0.5), 10), O.c2f_weights(0.3, (0.1, 0.5), 4)
+    rgb_ref, sig_ref = O.forward_samples(p, g(center).double()[None], g(ray).double()[None], g(depth).double()[None, :, :, None], density_activ=activ,
+                                         w3d=w3.double().to(DEV), wview=wv.double().to(DEV))
+    g_rgb, g_sig = g(t(rng.standard_normal((N, S, 3)))), g(t(rng.standard_normal((N, S))))
+    ((rgb_ref[0] * g_rgb.double()).sum() + (sig_ref[0] * g_sig.double()).sum()).backward()
+    names = [f"{n}.{k}" for n, _, _ in O.nerf_layer_shapes() for k in ("weight", "bias")]
+    flat = torch.cat([p32[n].reshape(-1) for n in names]).to(DEV)
+    st = ops.FieldState(flat)
+    params, off = [], 0
+    for n in names:
+        params.append(flat[off:off + p32[n].numel()].view(p32[n].shape).requires_grad_(True))
+        off += p32[n].numel()
+    rgb, sig = ops.field_mlp(st, params, g(center), g(ray), g(depth), w3.tolist(), wv.tolist(), activ)
+    close(rgb, rgb_ref[0]); close(sig, sig_ref[0], atol=5e-5, rtol=2e-4)
+    ((rgb * g_rgb).sum() + (sig * g_sig).sum()).backward()
+    worst = {}
+    for n, prm in zip(names, params):
+        ref = p[n].grad.float()
+        worst[n] = float((prm.grad - ref).abs().max() / ref.abs().max())
+    print("worst relative deviation per tensor:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) <= 2e-4, worst
+    # the two tensors the heads kernel owns, and their biases
+    for n in ("mlp_feat.7.weight", "mlp_rgb.1.weight", "mlp_rgb.1.bias"):
+        if n in worst:
+            assert worst[n] <= 2e-4
+
+
 def test_mlp_backward_with_exactly_zero_preactivations():
     """ReLU'(0) = 0, as in torch (reference model/nerf.py:422-447 uses torch_F.relu): a layer whose weight and bias are zero has the
     pre-activation +0.0 on every sample; no gradient may pass it.  The kernels record (activation > 0) -- not the sign bit of the

@@ -20,6 +20,7 @@ SAMPLES = 4086 * 192
 NAMES = {"mlp_fwd_kernel<true>": "mlp_fwd_train", "mlp_fwd_kernel<false>": "mlp_fwd", "mlp_bwd_dx_kernel": "mlp_bwd_dx",
          "dw_gemm_kernel<4, 2, 2, 4": "mlp_bwd_dw_wide_batch", "dw_gemm_kernel<8, 1, 1, 2": "mlp_bwd_dw_skinny_batch",
          "dw_gemm_kernel<4, 2, 1, 5": "mlp_bwd_dw_colour", "dw_gemm_kernel<4, 1, 1, 9": "mlp_bwd_dw_colour", "dw_reduce_kernel": "mlp_bwd_dw_reduce",
+         "dw_heads_kernel": "mlp_bwd_dw_heads",
          # the opt-in fast-precision kernels (tools/mlp_bench.py --precision bf16x3 | bf16)
          "mlp_fwd_fast_kernel<3, true>": "mlp_fwd_train", "mlp_fwd_fast_kernel<3, false>": "mlp_fwd", "mlp_bwd_dx_fast_kernel<3>": "mlp_bwd_dx",
          "mlp_fwd_fast_kernel<1, true>": "mlp_fwd_train", "mlp_fwd_fast_kernel<1, false>": "mlp_fwd", "mlp_bwd_dx_fast_kernel<1>": "mlp_bwd_dx",
@@ -34,14 +35,18 @@ ALGO = {  # algorithmic bytes per sample: reads / writes o
     # 592 B and hid a read excess behind a "combined ratio 1.0"): dY0..dY6 7*256 rows + dY7 256 rows + 1 quad (d sigma_raw) + dYrgb0 128
     # rows + dYrgb1 2 quads + stash 96 rows = 2284 rows * 4 B = 9136 B, + 32 B of parked per-sample ray gradients.
     "mlp_bwd_dx": dict(read=1092.0, write=9136.0 + 32.0), "mlp_bwd_dw_wide_batch": dict(read=7 * 2 * 256 * 4.0, write=0.0),
-    "mlp_bwd_dw_skinny_batch": dict(read=(320 + 320 + 257 + 131) * 4.0, write=0.0), "mlp_bwd_dw_colour": dict(read=(128 + 288) * 4.0, write=0.0)}
+    # exact mode from 131 k samples: the skinny launch holds the two encoding-column pieces; the density row and the colour rows are
+    # dw_heads_kernel's (h7 256 rows + hr 128 rows + the two dY quads).  Fast modes: four-piece skinny launch, no heads kernel.
+    "mlp_bwd_dw_skinny_batch": dict(read=(320 + 320) * 4.0, write=0.0), "mlp_bwd_dw_heads": dict(read=(256 + 128 + 4 + 4) * 4.0, write=0.0),
+    "mlp_bwd_dw_colour": dict(read=(128 + 288) * 4.0, write=0.0)}
+SKINNY_FOUR_PIECES = (320 + 320 + 257 + 131) * 4.0
 
 
 def per_kernel(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         m = re.search(r"(mlp_fwd_kernel<\w+>|mlp_bwd_dx_kernel|mlp_fwd_fast_kernel<\d, \w+>|mlp_bwd_dx_fast_kernel<\d>|dw_gemm(?:_fast|_half)?_kernel<\d, \d, \d, \d|"
-                      r"dw_reduce_kernel)", r["Kernel_Name"])
+                      r"dw_reduce_kernel|dw_heads_kernel)", r["Kernel_Name"])
         if m:
             agg[NAMES[m.group(1)]][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[NAMES[m.group(1)]]["dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -63,6 +68,8 @@ def bf16_algo():
 
 def main(out, prefix, precision="fp32"):
     global ALGO
+    if precision != "fp32":
+        ALGO["mlp_bwd_dw_skinny_batch"] = dict(read=SKINNY_FOUR_PIECES, write=0.0)
     if precision == "bf16":
         ALGO = bf16_algo()
     f, w, m = (per_kernel(f"{out}/{d}/pm_counter_collection.csv") for d in ("fetch", "write", "mfma"))
