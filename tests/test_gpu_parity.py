@@ -220,12 +220,20 @@ def test_mlp_weight_gradient_at_a_batch_that_takes_the_vector_head_pieces():
     for n, prm in zip(names, params):
         ref = p[n].grad.float()
         worst[n] = float((prm.grad - ref).abs().max() / ref.abs().max())
-    print("worst relative deviation per tensor:", {k: f"{v:.1e}" for k, v in worst.items()})
-    assert max(worst.values()) <= 2e-4, worst
-    # the two tensors the heads kernel owns, and their biases
-    for n in ("mlp_feat.7.weight", "mlp_rgb.1.weight", "mlp_rgb.1.bias"):
-        if n in worst:
-            assert worst[n] <= 2e-4
+    grads = dict(zip(names, params))
+    # what the heads kernel owns: the colour rows with their biases, and the density row (row 0 of the eighth layer: nerf.py:427) with its bias.  Their
+    # operands (h7, hr, d sigma, d rgb_raw) are forward values and head gradients: no ReLU mask between them and the float64 reference.
+    w7, b7 = grads["mlp_feat.7.weight"].grad, grads["mlp_feat.7.bias"].grad
+    r7, rb7 = p["mlp_feat.7.weight"].grad.float(), p["mlp_feat.7.bias"].grad.float()
+    heads = {"mlp_rgb.1.weight": worst["mlp_rgb.1.weight"], "mlp_rgb.1.bias": worst["mlp_rgb.1.bias"],
+             "density row": float((w7[0] - r7[0]).abs().max() / r7[0].abs().max()),
+             "density bias": float((b7[0] - rb7[0]).abs() / rb7[0].abs())}
+    print("heads kernel, worst relative deviation:", {k: f"{v:.1e}" for k, v in heads.items()})
+    print("all tensors:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(heads.values()) <= 5e-5, heads
+    # the trunk's gradients pass eight ReLU masks evaluated in fp32 (a pre-activation within rounding of zero flips its mask against the
+    # float64 reference): conditioning, bounded like tests/test_gpu_baseline_shapes.py bounds it at full shapes
+    assert max(worst.values()) <= 2e-2, worst
 
 
 def test_mlp_backward_with_exactly_zero_preactivations():
