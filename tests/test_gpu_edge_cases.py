@@ -408,3 +408,31 @@ def test_ray_split_node_matches_plain_autograd():
         for o, r in zip(outs, ref):
             assert torch.equal(o, r)
         close(a.grad, b.grad, atol=1e-7)
+
+
+@pytest.mark.parametrize("N", [1024, 1025, 1023])
+def test_weight_gradient_is_the_same_on_both_sides_of_the_heads_threshold(N):
+    """niw_mlp_bwd_dw forms the density row and the colour rows in dw_heads_kernel (vector ALU, second stream) from 131,072 samples and as two
+    pieces of the skinny MFMA launch below.  The same rays evaluated in ONE call (N x 128 samples: 131,072 at N = 1024 -- the first size on
+    the heads path -- 131,200 with a ragged last chunk, and 130,944 just below the threshold) and as two half batches (always below) must
+    give the same parameter gradients up to the order of an fp32 sum over the samples."""
+    from neural_invertible_warp_amd import ops
+    rng = np.random.default_rng(N)
+    S = 128
+    center, ray = g(t(rng.uniform(-1, 1, (N, 3)))), g(t(rng.standard_normal((N, 3))))
+    depth = g(t(np.sort(rng.uniform(0.5, 4, (N, S)), axis=1)))
+    g_rgb, g_sig = g(t(rng.standard_normal((N, S, 3)))), g(t(rng.standard_normal((N, S))))
+    ones3, ones4 = [1.0] * 10, [1.0] * 4
+
+    def grads(parts):
+        _, names, st, params = _field(8)
+        for lo, hi in parts:
+            rgb, sig = ops.field_mlp(st, params, center[lo:hi].contiguous(), ray[lo:hi].contiguous(), depth[lo:hi].contiguous(), ones3, ones4, "softplus")
+            ((rgb * g_rgb[lo:hi]).sum() + (sig * g_sig[lo:hi]).sum()).backward()
+        return names, [prm.grad.clone() for prm in params]
+
+    names, whole = grads([(0, N)])
+    _, halves = grads([(0, N // 2), (N // 2, N)])
+    for n, a, b in zip(names, whole, halves):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (n, float((a - b).abs().max()) / scale)
