@@ -514,7 +514,15 @@ def main():
             kernel_check = dict(kernel_sum_ms=round(kernel_sum_ms, 4), mlp_kernel_sum_ms=round(mlp_sum_ms, 4), serial_ms_per_step=round(eager_ms, 4),
                                 timed_ms_per_step=round(ms_rank, 4), hidden_by_overlap_ms=round(max(0.0, kernel_sum_ms - ms_rank), 4),
                                 consistent=bool(kernel_sum_ms <= eager_ms and mlp_sum_ms <= ms_rank))
-            if kernel_check["consistent"]:
+            # the retry is a COLLECTIVE decision under N > 1: every untimed iteration all-reduces the gradients, so a rank that retried alone
+            # would leave its peers in the next collective (seen with two ranks time-slicing one GPU: one rank's table failed its check,
+            # the other's did not)
+            again = not kernel_check["consistent"]
+            if world > 1:
+                flag = torch.tensor([1.0 if again else 0.0], device=dev, dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                again = bool(flag.item() > 0)
+            if not again:
                 break
         if not kernel_check["consistent"]:
             # a table that does not add up is not evidence: keep the record of the failed check, drop the table
