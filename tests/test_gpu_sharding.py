@@ -132,3 +132,27 @@ def test_two_ranks_train_validate_and_checkpoint_through_the_command_line(tmp_pa
     table = ck["graph"]["global_rigid.weight"]
     eye = torch.eye(3, 4).reshape(1, 12)
     assert ck["iter"] == 4 and bool(((table.cpu() - eye).abs().amax(dim=1) > 0).all()), "a view's row was never refreshed by its owning rank"
+
+
+def test_bench_line_under_torchrun_with_two_ranks():
+    """The driver's N > 1 invocation (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with two gloo ranks on this
+    one GPU: weak + strong step, the per-kernel table (whose retry must be a collective decision: round 4 found a rank retrying alone and
+    its peer in the next collective), parameter checksums equal across ranks, one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIW_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29683",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg3", "--lean", "--steps", "2", "--warmup", "1", "--kernel-steps", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["strong"] and line["strong"]["scaling"] == "strong" and line["comm_ms"] is not None
+    assert line["kernel_check"] is not None
