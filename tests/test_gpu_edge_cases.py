@@ -410,15 +410,15 @@ def test_ray_split_node_matches_plain_autograd():
         close(a.grad, b.grad, atol=1e-7)
 
 
-@pytest.mark.parametrize("N", [1024, 1025, 1023])
-def test_weight_gradient_is_the_same_on_both_sides_of_the_heads_threshold(N):
+@pytest.mark.parametrize("N,S", [(1024, 128), (1025, 128), (1023, 128), (1101, 120)])
+def test_weight_gradient_is_the_same_on_both_sides_of_the_heads_threshold(N, S):
     """niw_mlp_bwd_dw forms the density row and the colour rows in dw_heads_kernel (vector ALU, second stream) from 131,072 samples and as two
     pieces of the skinny MFMA launch below.  The same rays evaluated in ONE call (N x 128 samples: 131,072 at N = 1024 -- the first size on
-    the heads path -- 131,200 with a ragged last chunk, and 130,944 just below the threshold) and as two half batches (always below) must
-    give the same parameter gradients up to the order of an fp32 sum over the samples."""
+    the heads path -- 131,200 with a ragged last chunk, 130,944 just below the threshold, and 1101 x 120 = 132,120 samples, which the
+    workspaces pad to 132,224: the kernel reads the padding columns too) and as two half batches (always below) must give the same
+    parameter gradients up to the order of an fp32 sum over the samples."""
     from neural_invertible_warp_amd import ops
     rng = np.random.default_rng(N)
-    S = 128
     center, ray = g(t(rng.uniform(-1, 1, (N, 3)))), g(t(rng.standard_normal((N, 3))))
     depth = g(t(np.sort(rng.uniform(0.5, 4, (N, S)), axis=1)))
     g_rgb, g_sig = g(t(rng.standard_normal((N, S, 3)))), g(t(rng.standard_normal((N, S))))
