@@ -2,17 +2,20 @@
 // closed-form backward.  HBM-bound: 20 B/sample in (+4 B/sample prob out) forward,
 // 20 (+4) B in and 16 B out per sample backward.
 //
-// Vector kernels (S % 4 == 0, 16-byte aligned rows -- every shipped configuration): a ray is owned by a GROUP of
-// G = 8 / 16 / 32 / 64 lanes (G = S/4 rounded up to a power of two), so a wave carries 64/G rays at once (four rays of
-// 64 samples, two of 128, one of 192 ...).  Every lane owns FOUR consecutive samples: sigma, depth and prob move as one
-// 16-byte access per lane, rgb as three at a lane stride of 48 B (every byte of a fetched line is used by the same wave within
-// three instructions; measured on MI355X against a variant that moved the colours as three fully coalesced wave accesses
-// transposed through LDS: equal forward, the LDS variant 5-10 % slower backward -- the direct form is kept).
-// The transmittance T_i = exp(-sum_{j<i} sigma_j delta_j) is a segmented wave scan: a serial exclusive prefix over the
-// lane's four samples plus a shuffle ladder of width G over the lane totals (shift-then-scan: an inclusive-minus-self
-// form would cancel catastrophically against the 1e10 closing interval); rays longer than 4G = 256 samples run in
-// chunks with a running carry.  The backward is the mirrored suffix scan of g_k w_k.
+// Vector kernels (S % 4 == 0, 16-byte aligned rows -- every shipped configuration).  A lane owns QUADS of four consecutive samples
+// (sigma, depth, prob: one 16-byte access per quad); the transmittance T_i = exp(-sum_{j<i} sigma_j delta_j) is a segmented wave scan:
+// a serial exclusive prefix over the quad plus a ladder over the quad totals of the ray's lane group (shift-then-scan: an
+// inclusive-minus-self form would cancel catastrophically against the 1e10 closing interval); the backward is the mirrored suffix
+// scan of g_k w_k.
+//   S <= 32        8 lanes per ray, one quad per lane (composite_*_kernel<8>, shuffle ladder)
+//   33 .. 256     16 lanes per ray -- one DPP row -- and 1 .. 4 quads per lane: the SPAN kernels below (round 5)
+//   > 256         64 lanes per ray, chunks of 256 samples with a running carry (composite_*_kernel<64>)
 // Any other shape (S % 4 != 0, unaligned views) takes the scalar one-wave-per-ray kernels at the end of the file.
+// What bounds the span kernels is the HBM rate of their read : write mix, and the mix only streams at the rate of a copy when every
+// access instruction covers whole cache lines and carries the non-temporal hint (tools/composite_variants.hip, 120,000 x 192:
+// plain streaming kernels of the forward's 5 : 1 mix 5.1 TB/s with default loads, 6.0 non-temporal; a copy 5.1 / 6.5).  The colours
+// (12 B per sample: a lane's quad is 48 B) therefore move as fully coalesced 16-byte accesses and are transposed through LDS
+// (forward 111 -> 88 us, backward 163 -> 137 us; with 48-byte lane strides the hint costs 40 %: partial lines are fetched again).
 #include "niw_common.h"
 
 namespace {
@@ -224,6 +227,286 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Span kernels (round 5): rays of 65..256 samples keep the SIXTEEN-lane group of the 64-sample form -- four rays per wave,
+// one DPP row per ray -- and give every lane Q = 2 / 3 / 4 quads instead of widening the group to 32 / 64 lanes: no idle
+// lanes at S = 192 (the 64-lane group left 16 of 64 idle), four-step ladders instead of six, the closing sums amortised
+// over four rays, every load of the wave issued before the first use.  Within a 16-lane group the ladder steps are DPP row
+// shifts on the vector ALU (row_shr / row_shl / row_ror with zero fill; the same sums in the same order as the shuffle
+// ladder), not ds_bpermute round trips through the LDS crossbar.
+// Quads are INTERLEAVED over the lanes: lane gl owns quads gl, gl + 16, gl + 32, .. -- every 16-byte access of a group is 256
+// contiguous bytes (768 for the colours); Q ladders and Q - 1 broadcasts carry the sum from one row of quads into the next.
+// (Measured against the consecutive assignment -- lane gl owns quads gl Q .. gl Q + Q - 1, one ladder, no broadcast: 202 us
+// against 108 forward at 120,000 x 192, 217 against 155 backward; its loads put every lane of a wave on a cache line of
+// its own, 9 instructions long: bound by the L1's tag rate, not by HBM.)
+// WAVES: waves per workgroup (the kernels have no LDS and no barrier: a workgroup is just the unit CUs are refilled in).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero_fill(float v) {      // lanes whose source lies outside their 16-lane row read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kRowShr = 0x110, kRowShl = 0x100, kRowRor = 0x120;
+__device__ __forceinline__ float row16_excl_scan_up(float v) {
+    float s = dpp_zero_fill<kRowShr | 1>(v);
+    s += dpp_zero_fill<kRowShr | 1>(s);
+    s += dpp_zero_fill<kRowShr | 2>(s);
+    s += dpp_zero_fill<kRowShr | 4>(s);
+    s += dpp_zero_fill<kRowShr | 8>(s);
+    return s;
+}
+__device__ __forceinline__ float row16_excl_scan_down(float v) {
+    float s = dpp_zero_fill<kRowShl | 1>(v);
+    s += dpp_zero_fill<kRowShl | 1>(s);
+    s += dpp_zero_fill<kRowShl | 2>(s);
+    s += dpp_zero_fill<kRowShl | 4>(s);
+    s += dpp_zero_fill<kRowShl | 8>(s);
+    return s;
+}
+__device__ __forceinline__ float row16_sum(float v) {           // the row's total in every lane (lane 0's order is the one used)
+    v += dpp_zero_fill<kRowRor | 8>(v);
+    v += dpp_zero_fill<kRowRor | 4>(v);
+    v += dpp_zero_fill<kRowRor | 2>(v);
+    v += dpp_zero_fill<kRowRor | 1>(v);
+    return v;
+}
+
+// diagnostic switches of tools/composite_variants.hip (the product instantiates <.., false, false>)
+template <bool NT>
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* p, f32x4 v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <bool FAST>
+__device__ __forceinline__ float exp_neg(float x) { return FAST ? __expf(-x) : expf(-x); }
+
+template <int Q>
+struct Span {
+    float sig[4 * Q], dep[4 * Q], itv[4 * Q], sd[4 * Q], col[4 * Q][3];
+    bool v[Q];
+    int s0[Q];
+};
+
+// The lane's Q quads of its ray: sigma, depth, the interval to the next sample (1e10 after the ray's last one), sigma *
+// (interval * |ray|) and the colours.  Invalid quads (beyond S) read as zero and contribute nothing.
+// XP: the colours arrive as coalesced 16-byte accesses -- lane gl takes float4 16 j + gl of the 48 a row of quads holds, whole cache
+// lines per instruction, which is what lets them be non-temporal -- and reach the lane that owns their samples through `stage` (this
+// ray's [Q][192] floats of LDS; written and read by the same wave, in order).
+template <int Q, bool NT, bool XP = false>
+__device__ __forceinline__ void load_span(Span<Q>& p, const float* __restrict__ sg, const float* __restrict__ d, const float* __restrict__ c,
+                                          int S, int gl, float len, float* stage = nullptr) {
+    constexpr int G = 16;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s4[Q], d4[Q], c4[Q][3];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        p.s0[q] = 4 * (q * G + gl);
+        p.v[q] = p.s0[q] < S;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        s4[q] = p.v[q] ? ld4<NT>(sg + p.s0[q]) : zero;
+        d4[q] = p.v[q] ? ld4<NT>(d + p.s0[q]) : zero;
+    }
+    if (XP) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = 192 * q + 4 * (16 * j + gl);                     // first float of the lane's float4 within the ray's colours
+                c4[q][j] = e < 3 * S ? ld4<NT>(c + e) : zero;
+            }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(stage + 192 * q + 4 * (16 * j + gl)) = c4[q][j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c4[q][j] = *reinterpret_cast<const f32x4*>(stage + 192 * q + 12 * gl + 4 * j);
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c4[q][j] = p.v[q] ? ld4<NT>(c + 3 * p.s0[q] + 4 * j) : zero;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        // depth of the sample after the quad's last one: the next lane's quad of the same row; for the group's last lane, lane 0's quad of the next row
+        float dn = dpp_zero_fill<kRowShl | 1>(d4[q][0]);
+        if (q + 1 < Q) {
+            const float wrap = __shfl(d4[q + 1][0], 0, G);
+            if (gl == G - 1) dn = wrap;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            p.sig[4 * q + t] = s4[q][t];
+            p.dep[4 * q + t] = d4[q][t];
+        }
+        p.itv[4 * q + 0] = d4[q][1] - d4[q][0];
+        p.itv[4 * q + 1] = d4[q][2] - d4[q][1];
+        p.itv[4 * q + 2] = d4[q][3] - d4[q][2];
+        p.itv[4 * q + 3] = (p.s0[q] + 4 >= S) ? 1e10f : dn - d4[q][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) p.sd[4 * q + t] = p.v[q] ? p.sig[4 * q + t] * (p.itv[4 * q + t] * len) : 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) p.col[4 * q + t / 3][t % 3] = c4[q][t / 4][t % 4];
+    }
+}
+
+// sum of sigma * delta in front of each of the lane's samples (the exponent of the transmittance, nerf.py:466)
+template <int Q>
+__device__ __forceinline__ void span_prefix(const Span<Q>& p, float (&ex)[4 * Q]) {
+    float carry = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const float e1 = p.sd[4 * q], e2 = e1 + p.sd[4 * q + 1], e3 = e2 + p.sd[4 * q + 2], tot = e3 + p.sd[4 * q + 3];
+        const float base = carry + row16_excl_scan_up(tot);
+        ex[4 * q] = base; ex[4 * q + 1] = base + e1; ex[4 * q + 2] = base + e2; ex[4 * q + 3] = base + e3;
+        if (q + 1 < Q) carry = __shfl(base + tot, 15, 16);
+    }
+}
+
+template <int Q, int WAVES, bool NT = false, bool FAST = false, bool NTS = NT, bool XP = false>
+__global__ __launch_bounds__(64 * WAVES) void composite_fwd_span_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                                        const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                                        long long n_rays, int S, int has_bg, float bg,
+                                                                        float* __restrict__ rgb, float* __restrict__ depth,
+                                                                        float* __restrict__ opacity, float* __restrict__ prob) {
+    constexpr int G = 16, RPW = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x & 15;
+    const long long r_wave = ((long long)blockIdx.x * WAVES + wave) * RPW;
+    if (r_wave >= n_rays) return;                               // wave-uniform: no ray left for this wave
+    const long long r_raw = r_wave + lane / G;
+    const bool live = r_raw < n_rays;
+    const long long r = live ? r_raw : n_rays - 1;              // idle groups shadow the last ray (no stores)
+    const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
+    const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+    __shared__ float stage[XP ? WAVES * RPW * Q * 192 : 1];
+    Span<Q> p;
+    load_span<Q, NT, XP>(p, sigma_s + r * S, depth_s + r * S, rgb_s + r * S * 3, S, gl, len, stage + (XP ? (wave * RPW + lane / G) * Q * 192 : 0));
+    float ex[4 * Q];
+    span_prefix<Q>(p, ex);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, ao = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f32x4 w4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            const float w = p.v[q] ? exp_neg<FAST>(ex[i]) * (1.f - exp_neg<FAST>(p.sd[i])) : 0.f;
+            w4[t] = w;
+            a0 += w * p.col[i][0];
+            a1 += w * p.col[i][1];
+            a2 += w * p.col[i][2];
+            ad += w * p.dep[i];
+            ao += w;
+        }
+        if (p.v[q] && live && prob) st4<NTS>(prob + r * S + p.s0[q], w4);
+    }
+    a0 = row16_sum(a0); a1 = row16_sum(a1); a2 = row16_sum(a2); ad = row16_sum(ad); ao = row16_sum(ao);
+    if (gl == 0 && live) {
+        if (has_bg) { const float t = bg * (1.f - ao); a0 += t; a1 += t; a2 += t; }
+        rgb[r * 3] = a0; rgb[r * 3 + 1] = a1; rgb[r * 3 + 2] = a2;
+        depth[r] = ad;
+        opacity[r] = ao;
+    }
+}
+
+template <int Q, int WAVES, bool NT = false, bool FAST = false, bool NTS = NT, bool XP = false>
+__global__ __launch_bounds__(64 * WAVES) void composite_bwd_span_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                                        const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                                        long long n_rays, int S, int has_bg, float bg,
+                                                                        const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                                        const float* __restrict__ g_opacity, const float* __restrict__ g_prob,
+                                                                        float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s,
+                                                                        float* __restrict__ d_ray) {
+    constexpr int G = 16, RPW = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x & 15;
+    const long long r_wave = ((long long)blockIdx.x * WAVES + wave) * RPW;
+    if (r_wave >= n_rays) return;
+    const long long r_raw = r_wave + lane / G;
+    const bool live = r_raw < n_rays;
+    const long long r = live ? r_raw : n_rays - 1;
+    const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
+    const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float gr0 = g_rgb ? g_rgb[r * 3] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[r] : 0.f;
+    float go = g_opacity ? g_opacity[r] : 0.f;
+    if (has_bg) go -= bg * (gr0 + gr1 + gr2);
+    __shared__ float stage_all[XP ? WAVES * RPW * Q * 192 : 1];
+    float* stage = stage_all + (XP ? (wave * RPW + lane / G) * Q * 192 : 0);
+    Span<Q> p;
+    load_span<Q, NT, XP>(p, sigma_s + r * S, depth_s + r * S, rgb_s + r * S * 3, S, gl, len, stage);
+    f32x4 gp[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) gp[q] = (p.v[q] && g_prob) ? ld4<NT>(g_prob + r * S + p.s0[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float ex[4 * Q];
+    span_prefix<Q>(p, ex);
+    float TE[4 * Q], w[4 * Q], g[4 * Q], gw[4 * Q];
+#pragma unroll
+    for (int i = 0; i < 4 * Q; ++i) {
+        const float T = exp_neg<FAST>(ex[i]), E = exp_neg<FAST>(p.sd[i]);
+        const bool v = p.v[i / 4];
+        TE[i] = T * E;
+        w[i] = v ? T * (1.f - E) : 0.f;
+        g[i] = v ? gr0 * p.col[i][0] + gr1 * p.col[i][1] + gr2 * p.col[i][2] + gd * p.dep[i] + go + gp[i / 4][i % 4] : 0.f;
+        gw[i] = g[i] * w[i];
+    }
+    // sum_{j>i} g_j w_j = later samples of the quad + later lanes of its row + later rows of quads
+    float aft[4 * Q], suffix = 0.f;
+#pragma unroll
+    for (int q = Q - 1; q >= 0; --q) {
+        const float b2 = gw[4 * q + 3], b1 = b2 + gw[4 * q + 2], b0 = b1 + gw[4 * q + 1], btot = b0 + gw[4 * q];
+        const float after = suffix + row16_excl_scan_down(btot);
+        aft[4 * q] = after + b0; aft[4 * q + 1] = after + b1; aft[4 * q + 2] = after + b2; aft[4 * q + 3] = after;
+        if (q > 0) suffix = __shfl(after + btot, 0, 16);
+    }
+    float dlen = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f32x4 ds4, dc4[3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            const float ds = g[i] * TE[i] - aft[i];                   // dL/d(sigma*delta)
+            ds4[t] = ds * (p.itv[i] * len);
+            if (p.v[q]) dlen += ds * (p.sig[i] * p.itv[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) dc4[t / 4][t % 4] = w[4 * q + t / 3] * (t % 3 == 0 ? gr0 : t % 3 == 1 ? gr1 : gr2);
+        if (p.v[q] && live) st4<NTS>(d_sigma_s + r * S + p.s0[q], ds4);
+        if (XP) {
+            // the colour gradients leave the way the colours came: through the ray's staging rows (all reads of the forward direction
+            // are complete: the wave's LDS accesses execute in order), as whole cache lines per store
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(stage + 192 * q + 12 * gl + 4 * j) = dc4[j];
+        } else if (p.v[q] && live) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) st4<NTS>(d_rgb_s + (r * S + p.s0[q]) * 3 + 4 * j, dc4[j]);
+        }
+    }
+    if (XP) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = 192 * q + 4 * (16 * j + gl);
+                if (e < 3 * S && live) st4<NTS>(d_rgb_s + r * S * 3 + e, *reinterpret_cast<const f32x4*>(stage + e));
+            }
+    }
+    dlen = row16_sum(dlen);
+    if (gl == 0 && live) {
+        const float inv = len > 0.f ? dlen / len : 0.f;
+        d_ray[r * 3] = inv * rx; d_ray[r * 3 + 1] = inv * ry; d_ray[r * 3 + 2] = inv * rz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // scalar fallback: one 64-lane wave per ray, one sample per lane, 64-sample chunks (any S >= 2, any alignment)
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
@@ -365,10 +648,12 @@ __global__ __launch_bounds__(256) void composite_bwd_scalar_kernel(const float* 
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline int group_lanes(int S) {
-    const int need = (S + 3) / 4;
-    return need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+inline int group_lanes(int S) {      // lanes per ray: 8 up to 32 samples, 16 up to 256 (one to four quads per lane), 64 beyond (chunks of 256)
+    return S <= 32 ? 8 : S <= 256 ? 16 : 64;
 }
+// From 2 M samples per launch (a full image: 7.7-23 M) the accesses carry the non-temporal hint: the operands are touched once and
+// exceed the L2s (32 MiB) -- the training launches (<= 0.8 M samples, produced and consumed by the neighbouring kernels) keep the default.
+inline bool streaming_size(long long n_rays, int S) { return n_rays * S >= (2ll << 20); }
 // S = 1, as the reference behaves (nerf.py:461-462): the closing 1e10 interval is built from an EMPTY slice of the (empty) interval
 // tensor, so the single sample gets no interval at all -- every weight tensor is empty and rgb / depth / opacity are sums over nothing.
 __global__ void composite_single_sample_fwd_kernel(long long n_rays, int has_bg, float bg, float* __restrict__ rgb, float* __restrict__ depth,
@@ -404,12 +689,22 @@ extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const flo
     if (S % 4 == 0 && aligned16(rgb_s) && aligned16(sigma_s) && aligned16(depth_s) && (!prob || aligned16(prob))) {
         const int G = group_lanes(S);
         const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
+        const bool nt = streaming_size(n_rays, S);
 #define NIW_CFWD(GG) composite_fwd_kernel<GG><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob)
+        // span kernels: colours through LDS; streaming sizes read non-temporally (prob keeps the default policy: the resampling kernel reads it next)
+#define NIW_CFWD_SPAN(QQ)                                                                                                                              \
+    do {                                                                                                                                               \
+        if (nt) composite_fwd_span_kernel<QQ, 4, true, false, false, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob); \
+        else composite_fwd_span_kernel<QQ, 4, false, false, false, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob);  \
+    } while (0)
         if (G == 8) NIW_CFWD(8);
-        else if (G == 16) NIW_CFWD(16);
-        else if (G == 32) NIW_CFWD(32);
+        else if (S <= 64) NIW_CFWD_SPAN(1);
+        else if (S <= 128) NIW_CFWD_SPAN(2);
+        else if (S <= 192) NIW_CFWD_SPAN(3);
+        else if (S <= 256) NIW_CFWD_SPAN(4);
         else NIW_CFWD(64);
 #undef NIW_CFWD
+#undef NIW_CFWD_SPAN
     } else {
         const int blocks = (int)((n_rays + 3) / 4);
         composite_fwd_scalar_kernel<<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob);
@@ -437,12 +732,21 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
         (!d_prob || aligned16(d_prob))) {
         const int G = group_lanes(S);
         const int blocks = (int)((n_rays + 4 * (64 / G) - 1) / (4 * (64 / G)));
+        const bool nt = streaming_size(n_rays, S);
 #define NIW_CBWD(GG) composite_bwd_kernel<GG><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray)
+#define NIW_CBWD_SPAN(QQ)                                                                                                                              \
+    do {                                                                                                                                               \
+        if (nt) composite_bwd_span_kernel<QQ, 4, true, false, true, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray); \
+        else composite_bwd_span_kernel<QQ, 4, false, false, false, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray); \
+    } while (0)
         if (G == 8) NIW_CBWD(8);
-        else if (G == 16) NIW_CBWD(16);
-        else if (G == 32) NIW_CBWD(32);
+        else if (S <= 64) NIW_CBWD_SPAN(1);
+        else if (S <= 128) NIW_CBWD_SPAN(2);
+        else if (S <= 192) NIW_CBWD_SPAN(3);
+        else if (S <= 256) NIW_CBWD_SPAN(4);
         else NIW_CBWD(64);
 #undef NIW_CBWD
+#undef NIW_CBWD_SPAN
     } else {
         const int blocks = (int)((n_rays + 3) / 4);
         composite_bwd_scalar_kernel<<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity,

@@ -10,6 +10,7 @@
 // kernel sums the partial tiles in a fixed order (deterministic; no float atomics) and
 // scatters the result into the state-dict layout of d_params.
 #include "niw_common.h"
+#include <mutex>
 #include "niw_mlp_device.h"
 #include "niw_bf16.h"
 #include <type_traits>
@@ -768,6 +769,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 struct HeadsLane {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    std::mutex mu;      // one caller at a time between fork and join: the events are shared by every caller of the device
+};
+
+// Between fork and join the lane belongs to ONE call (two host threads, or two trainers on different streams, would otherwise re-record
+// each other's events); and a call that fails after the fork still joins the lane -- an unjoined stream invalidates a capture.
+struct HeadsLaneHold {
+    HeadsLane* lane = nullptr;
+    hipStream_t st = nullptr;
+    bool forked = false;
+    void take(HeadsLane* l, hipStream_t s) { lane = l; st = s; lane->mu.lock(); }
+    hipError_t join() {
+        if (!lane || !forked) return hipSuccess;
+        forked = false;
+        return hipStreamWaitEvent(st, lane->join, 0);
+    }
+    ~HeadsLaneHold() {
+        if (!lane) return;
+        if (forked) {                          // error path: whatever the lane holds joins the caller's stream
+            (void)hipEventRecord(lane->join, lane->s);
+            (void)hipStreamWaitEvent(st, lane->join, 0);
+        }
+        lane->mu.unlock();
+    }
 };
 
 HeadsLane* heads_lane() {
@@ -981,6 +1005,7 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     int n_pieces = 0, max_tile = 0;
     long long off = 0;
     HeadsLane* lane = nullptr;
+    HeadsLaneHold hold;
     if (heads) {
         static const int head_chunks = [] { const char* e = getenv("NIW_DW_HEAD_CHUNKS"); const int v = e ? atoi(e) : kHeadChunks; return v < 1 ? 1 : (v > kHeadChunks ? kHeadChunks : v); }();
         int per = (int)(((mpad + head_chunks - 1) / head_chunks + 127) / 128 * 128);
@@ -1010,10 +1035,12 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
                 niw_set_error("niw_mlp_bwd_dw: cannot create the second stream");
                 return NIW_ERR_LAUNCH;
             }
+            hold.take(lane, st);
             if (hipEventRecord(lane->fork, st) != hipSuccess || hipStreamWaitEvent(lane->s, lane->fork, 0) != hipSuccess) {
                 niw_set_error("niw_mlp_bwd_dw: cannot fork the second stream");
                 return NIW_ERR_LAUNCH;
             }
+            hold.forked = true;
             hs = lane->s;
         }
         dw_heads_kernel<<<chunks, 256, 0, hs>>>(ha);
@@ -1074,7 +1101,7 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
         off += (long long)g.n * nsplit * tile;
         max_tile = (int)tile > max_tile ? (int)tile : max_tile;
     }
-    if (lane && hipStreamWaitEvent(st, lane->join, 0) != hipSuccess) {
+    if (hold.join() != hipSuccess) {
         niw_set_error("niw_mlp_bwd_dw: cannot join the second stream");
         return NIW_ERR_LAUNCH;
     }

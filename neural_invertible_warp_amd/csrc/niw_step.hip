@@ -13,6 +13,7 @@
 //   fill_kernel         zero gradients of a network that receives no loss term
 // Route sums are formed in the order autograd's accumulation would (fine compositing, fine field, coarse compositing, coarse field;
 // separately rounded), so the engine's parameters agree bit for bit with the autograd mirror on the same inputs.
+#include <mutex>
 #include "niw_common.h"
 #include <stdlib.h>
 
@@ -170,6 +171,24 @@ __global__ void adam_multi_kernel(AdamBatch b, const float* __restrict__ hyper_d
 struct SideLane {
     hipStream_t s = nullptr;
     hipEvent_t warped = nullptr, dx = nullptr, join = nullptr;
+    std::mutex mu;      // one niw_train_step at a time per device between its first fork and its join (the events are shared)
+};
+
+// Holds the lane for the length of one call; a call that returns early (a failed launch behind the first fork) still joins the
+// lane to the caller's stream -- a stream left forked invalidates a capture in progress.
+struct SideLaneHold {
+    SideLane* lane;
+    hipStream_t st;
+    bool forked = false;
+    SideLaneHold(SideLane* l, hipStream_t s) : lane(l), st(s) { if (lane) lane->mu.lock(); }
+    ~SideLaneHold() {
+        if (!lane) return;
+        if (forked) {
+            (void)hipEventRecord(lane->join, lane->s);
+            (void)hipStreamWaitEvent(st, lane->join, 0);
+        }
+        lane->mu.unlock();
+    }
 };
 
 SideLane* side_lane() {
@@ -345,6 +364,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
 
     // second stream (niw.h: overlap): X carries the small independent stages, `stream` the field-MLP chain
     SideLane* lane = (d->overlap && stage_begin == 0 && stage_end == NIW_STAGE_END) ? side_lane() : nullptr;
+    SideLaneHold hold(lane, st);
     hipStream_t X = lane ? lane->s : st;
     niw_stream_t sx = (niw_stream_t)X;
     // ---- the front of the iteration, one launch: pixel draw + un-warped points, stratified depths, fp32 weight images, pad columns
@@ -372,6 +392,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     if (lane) {
         NIW_HIP(hipEventRecord(lane->warped, st), "warped");
         NIW_HIP(hipStreamWaitEvent(X, lane->warped, 0), "warped");
+        hold.forked = true;
     }
     // ---- X: rigid registration of the warped onto the un-warped points (whole views: no collective under sharding either) and the
     // alignment loss -- the part of the LOSS stage that needs only the warp
@@ -454,6 +475,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
                                          d->d_warp, d->d_latent + 128ll * d->view0, X));
     }
     if (lane) {
+        hold.forked = false;
         NIW_HIP(hipEventRecord(lane->join, X), "join");
         NIW_HIP(hipStreamWaitEvent(st, lane->join, 0), "join");
     }

@@ -530,6 +530,11 @@ class INNTrainer:
                     self._optimizer_step(it)
                 torch.cuda.current_stream().wait_stream(side)
                 return loss
+        if self._capture_addresses() != self._captured_addresses:
+            # a tensor the captured launches address has moved (parameters re-flattened by .to(), a table re-assigned from outside): the
+            # graph would read and write the old storage -- record the iteration again instead
+            self._captured = None
+            return self._graph_iteration(var, it, replay)
         fb, adam, loss = self._captured
         fb.replay()
         if adam is not None:                           # ranks exchange gradients between the two graphs
@@ -604,7 +609,16 @@ class INNTrainer:
             raise CaptureError(f"HIP-graph capture of the train iteration failed ({type(e).__name__}: {e}); "
                                "run with hip_graph=False (bench.py --hip-graph off)") from e
         self._captured = (fb, adam, loss)
+        self._captured_addresses = self._capture_addresses()
         return True
+
+    def _capture_addresses(self):
+        """device addresses a captured iteration has baked into its launches: parameters, gradient bucket, Adam moments, pose table"""
+        t = [f.data_ptr() for f in self._flats()] + [self.bucket.flat.data_ptr()] + [x.data_ptr() for x in self.m + self.v]
+        table = self.pose_net.pose_global.weight if self.family == "dtu" else getattr(self.graph, "global_rigid", None)
+        if table is not None:
+            t.append((table.weight if hasattr(table, "weight") else table).data.data_ptr())
+        return t
 
     def _give_up_capture(self, why):
         import sys
@@ -628,7 +642,7 @@ class INNTrainer:
             # per-view pose tables: under ray sharding every rank has refreshed the rows of its own views only
             win = getattr(self.graph, "_last_window", None)
             if self.family == "dtu":
-                self.pose_net.pose_global.weight.data = parallel.gather_owned_rows(self.pose_net.pose_global.weight.data, win)
+                parallel.gather_owned_rows(self.pose_net.pose_global.weight.data, win)       # in place: a captured iteration holds the address
             else:
                 self.graph.gather_global_rigid()
 

@@ -163,7 +163,7 @@ class Graph(nerf.Graph):
         whole (validation, checkpoints) every view's row is taken from the rank that owns the view (one small all-reduce)."""
         from .. import parallel
         if hasattr(self, "global_rigid"):
-            self.global_rigid.weight.data = parallel.gather_owned_rows(self.global_rigid.weight.data, getattr(self, "_last_window", None))
+            parallel.gather_owned_rows(self.global_rigid.weight.data, getattr(self, "_last_window", None))      # in place: the storage is stable
 
     def get_pose(self, opt, var, mode=None):
         return var.pose

@@ -101,13 +101,17 @@ def all_reduce_sum_(t):
 
 
 def gather_owned_rows(table, win):
-    """Per-view table [B, k] of which every rank has refreshed the rows of the views it handles: -> the table with every view's row
-    taken from the rank that OWNS the view (zeros elsewhere, summed over ranks).  Identity without a process group or window."""
+    """Per-view table [B, k] of which every rank has refreshed the rows of the views it handles: every view's row is taken from the rank
+    that OWNS the view (zeros elsewhere, summed over ranks) and written back INTO `table` -- the storage stays where it is, because a
+    captured train iteration has the table's device address baked into its launches (engine.FusedStep: `d.poses`); a fresh tensor here
+    would leave every later replay writing the poses into freed memory.  Returns `table`.  Identity without a process group or window."""
     if win is None or not _collectives_live():
         return table
     out = torch.zeros_like(table)
     out[win.own0:win.own1] = table[win.own0:win.own1]
-    return all_reduce_sum_(out)
+    with torch.no_grad():
+        table.copy_(all_reduce_sum_(out))
+    return table
 
 
 def global_loss_elements(n_views, n_rays_global):

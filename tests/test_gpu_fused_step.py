@@ -137,6 +137,44 @@ def test_fused_iteration_captured_graph_equals_eager():
         assert torch.equal(fa, fb)
 
 
+def test_captured_iteration_survives_sync_state_under_ray_sharding():
+    """Round-4 advisor finding: a captured iteration has the pose table's device address baked in (`d.poses`); sync_state() of a sharded
+    job used to REPLACE the table's storage with the gathered rows, after which every replay wrote the registered poses into freed memory
+    and validation / checkpoints read a stale table.  Rank 0 of a 2-way sharded job with a live (one-rank, forced) process group: capture,
+    sync_state between replays -- the table must stay where it is, and equal the launched (hip_graph=False) trainer's after every sync."""
+    import os
+    import torch.distributed as dist
+    from neural_invertible_warp_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677")
+    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    parallel.FORCE_COLLECTIVES = True
+    try:
+        tables = {}
+        for graph in (False, True):
+            tr, var0 = _trainer("cfg3_barf_inn_llff", True, rank=0, world=2, hip_graph=graph)
+            table = tr.graph.global_rigid.weight
+            ptr = table.data.data_ptr()
+            seen = []
+            for k in range(8):
+                tr.train_iteration(type(var0)(var0))
+                if k in (3, 5, 7):
+                    tr.sync_state()
+                    assert table.data.data_ptr() == ptr, "sync_state moved the pose table"
+                    seen.append(table.data.clone())
+            torch.cuda.synchronize()
+            if graph:
+                assert tr._captured is not None
+            tables[graph] = seen
+        win = parallel.ViewWindow(5, 37, 0, 2)
+        for a, b in zip(tables[False], tables[True]):
+            assert torch.equal(a, b)
+            assert float(a[win.own0:win.own1].abs().sum()) > 0 and float(a[win.own1:].abs().sum()) == 0      # owned rows registered, the others summed as zeros
+        assert not torch.equal(tables[True][0], tables[True][-1])            # the replays after a sync_state still refresh the live table
+    finally:
+        parallel.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
+
+
 def test_fused_iteration_is_refused_or_bypassed_where_it_does_not_apply():
     from neural_invertible_warp_amd import configs, engine
     from neural_invertible_warp_amd._lib import NiwError
