@@ -148,6 +148,25 @@ int niw_composite_bwd(const float* ray, const float* rgb_s, const float* sigma_s
                       const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_prob,
                       float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream);
 
+/* Training form of the three calls a train iteration makes around the photometric loss (Graph.render's composite call,
+ * model/nerf.py:305 / nerf_inn_llff.py:602, then compute_loss's MSE, nerf_inn_llff.py:555-559 with base.py:209-211, then autograd of
+ * both): niw_composite_fwd + niw_mse_fwd_bwd + niw_composite_bwd of one ray batch as ONE launch.  The ray's residual against its pixel
+ * is local to the ray (d rgb = grad_scale * 2 (rgb - pixel) / n_norm), so the backward runs on the registers of the forward; the
+ * loss VALUE is the only reduction: every ray leaves its three residuals in resid [n_rays,3], and niw_mse_from_residuals sums their
+ * squares in niw_mse_fwd_bwd's order -- outputs, gradients and loss are bit-identical to the three calls.
+ *   image [n_views,3,hw], ray_idx [n_rays_per_view] or NULL, first_ray, n_norm, grad_scale: as niw_mse_fwd_bwd (below);
+ *   rgb, depth, opacity, prob (may be NULL): as niw_composite_fwd;  d_rgb [n_rays,3] (may be NULL): what niw_mse_fwd_bwd writes;
+ *   d_rgb_s, d_sigma_s, d_ray: as niw_composite_bwd.  No background colour, no incoming depth / opacity / prob gradients (the train
+ *   iteration has none).  NIW_ERR_UNSUPPORTED, nothing launched, unless n_samples % 4 == 0, n_samples <= 256 and rows are 16-byte
+ *   aligned: make the three calls then. */
+int niw_composite_mse_train(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s, int64_t n_rays, int n_samples,
+                            const float* image, const int64_t* ray_idx, int n_views, int64_t n_rays_per_view, int64_t hw, int64_t first_ray,
+                            double n_norm, float grad_scale, float* rgb, float* depth, float* opacity, float* prob, float* resid, float* d_rgb,
+                            float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream);
+
+/* loss[0] = sum(resid^2) / n_norm over resid [n_rays,3] (overwritten; one workgroup, fixed order = niw_mse_fwd_bwd's). */
+int niw_mse_from_residuals(const float* resid, int64_t n_rays, double n_norm, float* loss, niw_stream_t stream);
+
 /* ------------------------------------------------------------------ sampling
  * Graph.sample_depth (model/nerf.py:334-344).  u [n_rays,S] stratified draws or NULL (0.5).
  * The range travels as doubles: the reference forms (depth_max - depth_min) from the yaml's Python floats in double precision and

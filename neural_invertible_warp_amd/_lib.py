@@ -69,6 +69,8 @@ SIGNATURES = {
     "niw_mlp_bwd_dw": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "niw_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "niw_composite_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_composite_mse_train": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i64, _i64, _d, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "niw_mse_from_residuals": (_i, [_vp, _i64, _d, _vp, _vp]),
     "niw_sample_stratified": (_i, [_vp, _i64, _i, _d, _d, _i, _vp, _vp]),
     "niw_sample_stratified_rng": (_i, [_u64, _u64, _vp, _i64, _i, _d, _d, _i, _vp, _vp, _vp]),
     "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),

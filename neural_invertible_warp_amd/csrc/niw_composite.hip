@@ -7,9 +7,8 @@
 // a serial exclusive prefix over the quad plus a ladder over the quad totals of the ray's lane group (shift-then-scan: an
 // inclusive-minus-self form would cancel catastrophically against the 1e10 closing interval); the backward is the mirrored suffix
 // scan of g_k w_k.
-//   S <= 32        8 lanes per ray, one quad per lane (composite_*_kernel<8>, shuffle ladder)
-//   33 .. 256     16 lanes per ray -- one DPP row -- and 1 .. 4 quads per lane: the SPAN kernels below (round 5)
-//   > 256         64 lanes per ray, chunks of 256 samples with a running carry (composite_*_kernel<64>)
+//   S <= 256      16 lanes per ray -- one DPP row -- and 1 .. 4 quads per lane: the SPAN kernels below (round 5)
+//   S  > 256      64 lanes per ray, one quad per lane, chunks of 256 samples with a running carry (composite_*_kernel<64>, shuffle ladder)
 // Any other shape (S % 4 != 0, unaligned views) takes the scalar one-wave-per-ray kernels at the end of the file.
 // What bounds the span kernels is the HBM rate of their read : write mix, and the mix only streams at the rate of a copy when every
 // access instruction covers whole cache lines and carries the non-temporal hint (tools/composite_variants.hip, 120,000 x 192:
@@ -297,6 +296,7 @@ struct Span {
 template <int Q, bool NT, bool XP = false>
 __device__ __forceinline__ void load_span(Span<Q>& p, const float* __restrict__ sg, const float* __restrict__ d, const float* __restrict__ c,
                                           int S, int gl, float len, float* stage = nullptr) {
+#pragma clang fp contract(off)
     constexpr int G = 16;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 s4[Q], d4[Q], c4[Q][3];
@@ -370,6 +370,111 @@ __device__ __forceinline__ void span_prefix(const Span<Q>& p, float (&ex)[4 * Q]
     }
 }
 
+// transmittance in front of each sample, the sample's own attenuation and its weight (nerf.py:465-468) -- ONE definition for the
+// forward, the backward (which recomputes them) and the training kernel (which keeps them), so that the three agree bit for bit
+// (`#pragma clang fp contract(off)` + explicit fmaf in the shared functions: under -ffp-contract=fast LLVM chooses where to fuse per
+// kernel -- T * (1 - E) became fma(-E, T, T) in the forward-only kernel and stayed a subtract and a multiply where T * E is also needed,
+// a 1-ulp difference in prob between kernels that must agree.  Here every rounding is written down.)
+__device__ __forceinline__ float ray_length(float rx, float ry, float rz) {
+#pragma clang fp contract(off)
+    return sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx * rx)));
+}
+template <int Q, bool FAST>
+__device__ __forceinline__ void span_weights(const Span<Q>& p, const float (&ex)[4 * Q], float (&T)[4 * Q], float (&E)[4 * Q], float (&w)[4 * Q]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < 4 * Q; ++i) {
+        T[i] = exp_neg<FAST>(ex[i]);
+        E[i] = exp_neg<FAST>(p.sd[i]);
+        w[i] = p.v[i / 4] ? T[i] * (1.f - E[i]) : 0.f;
+    }
+}
+
+struct RaySums { float a0, a1, a2, ad, ao; };
+
+// weighted sums of a ray (every lane of the group returns the totals; lane 0's summation order is the one that is stored) + prob
+template <int Q, bool NTS>
+__device__ __forceinline__ RaySums span_forward(const Span<Q>& p, const float (&w)[4 * Q], bool live, float* __restrict__ prob_ray) {
+#pragma clang fp contract(off)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, ao = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f32x4 w4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            w4[t] = w[i];
+            a0 = fmaf(w[i], p.col[i][0], a0);
+            a1 = fmaf(w[i], p.col[i][1], a1);
+            a2 = fmaf(w[i], p.col[i][2], a2);
+            ad = fmaf(w[i], p.dep[i], ad);
+            ao += w[i];
+        }
+        if (p.v[q] && live && prob_ray) st4<NTS>(prob_ray + p.s0[q], w4);
+    }
+    return RaySums{row16_sum(a0), row16_sum(a1), row16_sum(a2), row16_sum(ad), row16_sum(ao)};
+}
+
+// closed-form backward of a ray: writes d sigma and d colour of the lane's samples, returns the group's d |ray|
+template <int Q, bool NTS, bool XP>
+__device__ __forceinline__ float span_backward(const Span<Q>& p, const float (&T)[4 * Q], const float (&E)[4 * Q], const float (&w)[4 * Q],
+                                               float gr0, float gr1, float gr2, float gd, float go, const f32x4 (&gp)[Q], float len, bool live, int S,
+                                               int gl, float* stage, float* __restrict__ d_rgb_ray, float* __restrict__ d_sigma_ray) {
+#pragma clang fp contract(off)
+    float TE[4 * Q], g[4 * Q], gw[4 * Q];
+#pragma unroll
+    for (int i = 0; i < 4 * Q; ++i) {
+        TE[i] = T[i] * E[i];
+        const float dot = fmaf(gd, p.dep[i], fmaf(gr2, p.col[i][2], fmaf(gr1, p.col[i][1], gr0 * p.col[i][0])));
+        g[i] = p.v[i / 4] ? (dot + go) + gp[i / 4][i % 4] : 0.f;
+        gw[i] = g[i] * w[i];
+    }
+    // sum_{j>i} g_j w_j = later samples of the quad + later lanes of its row + later rows of quads
+    float aft[4 * Q], suffix = 0.f;
+#pragma unroll
+    for (int q = Q - 1; q >= 0; --q) {
+        const float b2 = gw[4 * q + 3], b1 = b2 + gw[4 * q + 2], b0 = b1 + gw[4 * q + 1], btot = b0 + gw[4 * q];
+        const float after = suffix + row16_excl_scan_down(btot);
+        aft[4 * q] = after + b0; aft[4 * q + 1] = after + b1; aft[4 * q + 2] = after + b2; aft[4 * q + 3] = after;
+        if (q > 0) suffix = __shfl(after + btot, 0, 16);
+    }
+    float dlen = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f32x4 ds4, dc4[3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            const float ds = fmaf(g[i], TE[i], -aft[i]);              // dL/d(sigma*delta)
+            ds4[t] = ds * (p.itv[i] * len);
+            if (p.v[q]) dlen = fmaf(ds, p.sig[i] * p.itv[i], dlen);
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) dc4[t / 4][t % 4] = w[4 * q + t / 3] * (t % 3 == 0 ? gr0 : t % 3 == 1 ? gr1 : gr2);
+        if (p.v[q] && live) st4<NTS>(d_sigma_ray + p.s0[q], ds4);
+        if (XP) {
+            // the colour gradients leave the way the colours came: through the ray's staging rows (every read of the inbound direction
+            // is complete: the wave's LDS accesses execute in order), as whole cache lines per store
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(stage + 192 * q + 12 * gl + 4 * j) = dc4[j];
+        } else if (p.v[q] && live) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) st4<NTS>(d_rgb_ray + 3 * p.s0[q] + 4 * j, dc4[j]);
+        }
+    }
+    if (XP) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = 192 * q + 4 * (16 * j + gl);
+                if (e < 3 * S && live) st4<NTS>(d_rgb_ray + e, *reinterpret_cast<const f32x4*>(stage + e));
+            }
+    }
+    return row16_sum(dlen);
+}
+
 template <int Q, int WAVES, bool NT = false, bool FAST = false, bool NTS = NT, bool XP = false>
 __global__ __launch_bounds__(64 * WAVES) void composite_fwd_span_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
                                                                         const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
@@ -384,35 +489,19 @@ __global__ __launch_bounds__(64 * WAVES) void composite_fwd_span_kernel(const fl
     const bool live = r_raw < n_rays;
     const long long r = live ? r_raw : n_rays - 1;              // idle groups shadow the last ray (no stores)
     const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
-    const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float len = ray_length(rx, ry, rz);
     __shared__ float stage[XP ? WAVES * RPW * Q * 192 : 1];
     Span<Q> p;
     load_span<Q, NT, XP>(p, sigma_s + r * S, depth_s + r * S, rgb_s + r * S * 3, S, gl, len, stage + (XP ? (wave * RPW + lane / G) * Q * 192 : 0));
-    float ex[4 * Q];
+    float ex[4 * Q], T[4 * Q], E[4 * Q], w[4 * Q];
     span_prefix<Q>(p, ex);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, ao = 0.f;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        f32x4 w4;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = 4 * q + t;
-            const float w = p.v[q] ? exp_neg<FAST>(ex[i]) * (1.f - exp_neg<FAST>(p.sd[i])) : 0.f;
-            w4[t] = w;
-            a0 += w * p.col[i][0];
-            a1 += w * p.col[i][1];
-            a2 += w * p.col[i][2];
-            ad += w * p.dep[i];
-            ao += w;
-        }
-        if (p.v[q] && live && prob) st4<NTS>(prob + r * S + p.s0[q], w4);
-    }
-    a0 = row16_sum(a0); a1 = row16_sum(a1); a2 = row16_sum(a2); ad = row16_sum(ad); ao = row16_sum(ao);
+    span_weights<Q, FAST>(p, ex, T, E, w);
+    RaySums a = span_forward<Q, NTS>(p, w, live, prob ? prob + r * S : nullptr);
     if (gl == 0 && live) {
-        if (has_bg) { const float t = bg * (1.f - ao); a0 += t; a1 += t; a2 += t; }
-        rgb[r * 3] = a0; rgb[r * 3 + 1] = a1; rgb[r * 3 + 2] = a2;
-        depth[r] = ad;
-        opacity[r] = ao;
+        if (has_bg) { const float t = bg * (1.f - a.ao); a.a0 += t; a.a1 += t; a.a2 += t; }
+        rgb[r * 3] = a.a0; rgb[r * 3 + 1] = a.a1; rgb[r * 3 + 2] = a.a2;
+        depth[r] = a.ad;
+        opacity[r] = a.ao;
     }
 }
 
@@ -432,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES) void composite_bwd_span_kernel(const fl
     const bool live = r_raw < n_rays;
     const long long r = live ? r_raw : n_rays - 1;
     const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
-    const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float len = ray_length(rx, ry, rz);
     const float gr0 = g_rgb ? g_rgb[r * 3] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
     const float gd = g_depth ? g_depth[r] : 0.f;
     float go = g_opacity ? g_opacity[r] : 0.f;
@@ -444,62 +533,79 @@ __global__ __launch_bounds__(64 * WAVES) void composite_bwd_span_kernel(const fl
     f32x4 gp[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) gp[q] = (p.v[q] && g_prob) ? ld4<NT>(g_prob + r * S + p.s0[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
-    float ex[4 * Q];
+    float ex[4 * Q], T[4 * Q], E[4 * Q], w[4 * Q];
     span_prefix<Q>(p, ex);
-    float TE[4 * Q], w[4 * Q], g[4 * Q], gw[4 * Q];
-#pragma unroll
-    for (int i = 0; i < 4 * Q; ++i) {
-        const float T = exp_neg<FAST>(ex[i]), E = exp_neg<FAST>(p.sd[i]);
-        const bool v = p.v[i / 4];
-        TE[i] = T * E;
-        w[i] = v ? T * (1.f - E) : 0.f;
-        g[i] = v ? gr0 * p.col[i][0] + gr1 * p.col[i][1] + gr2 * p.col[i][2] + gd * p.dep[i] + go + gp[i / 4][i % 4] : 0.f;
-        gw[i] = g[i] * w[i];
+    span_weights<Q, FAST>(p, ex, T, E, w);
+    const float dlen = span_backward<Q, NTS, XP>(p, T, E, w, gr0, gr1, gr2, gd, go, gp, len, live, S, gl, stage, d_rgb_s + r * S * 3, d_sigma_s + r * S);
+    if (gl == 0 && live) {
+        const float inv = len > 0.f ? dlen / len : 0.f;
+        d_ray[r * 3] = inv * rx; d_ray[r * 3 + 1] = inv * ry; d_ray[r * 3 + 2] = inv * rz;
     }
-    // sum_{j>i} g_j w_j = later samples of the quad + later lanes of its row + later rows of quads
-    float aft[4 * Q], suffix = 0.f;
-#pragma unroll
-    for (int q = Q - 1; q >= 0; --q) {
-        const float b2 = gw[4 * q + 3], b1 = b2 + gw[4 * q + 2], b0 = b1 + gw[4 * q + 1], btot = b0 + gw[4 * q];
-        const float after = suffix + row16_excl_scan_down(btot);
-        aft[4 * q] = after + b0; aft[4 * q + 1] = after + b1; aft[4 * q + 2] = after + b2; aft[4 * q + 3] = after;
-        if (q > 0) suffix = __shfl(after + btot, 0, 16);
+}
+
+// The training form (niw_composite_mse_train): compositing, the photometric residual of the ray against its pixel, and the backward of
+// both, in ONE pass over the samples -- the three launches composite_fwd -> mse -> composite_bwd of a train iteration are 5-7 us each
+// around no work at a rank's share of the batch, and the backward re-read what the forward had in registers.  The residual is local
+// to the ray (the mean's normaliser is a constant of the batch: d rgb = 2 (rgb - pixel) / n * weight), so nothing waits for the loss
+// VALUE: every ray leaves its three residuals in `resid`, and niw_mse_from_residuals / the train step's closing kernel sums their
+// squares in mse_kernel's order (bit-identical loss).  Same device functions as the two kernels above: same rgb, same gradients.
+struct TrainPixels {
+    const float* image;           // [B][3][hw]
+    const int64_t* ray_idx;       // [R] pixel of ray r of every view, or NULL (r itself)
+    long long R, hw, first_ray;   // rays per view; pixels per image; the flattened-[B][R] number of ray 0 of this launch
+    double slope;                 // grad_scale * 2 / n_norm, formed like mse_kernel forms it
+};
+
+template <int Q, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void composite_train_span_kernel(const float* __restrict__ ray, const float* __restrict__ rgb_s,
+                                                                          const float* __restrict__ sigma_s, const float* __restrict__ depth_s,
+                                                                          long long n_rays, int S, TrainPixels px,
+                                                                          float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ opacity,
+                                                                          float* __restrict__ prob, float* __restrict__ resid, float* __restrict__ d_rgb,
+                                                                          float* __restrict__ d_rgb_s, float* __restrict__ d_sigma_s, float* __restrict__ d_ray) {
+    constexpr int G = 16, RPW = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x & 15;
+    const long long r_wave = ((long long)blockIdx.x * WAVES + wave) * RPW;
+    if (r_wave >= n_rays) return;
+    const long long r_raw = r_wave + lane / G;
+    const bool live = r_raw < n_rays;
+    const long long r = live ? r_raw : n_rays - 1;
+    // the ray's pixel: lanes 0..2 of the group fetch one colour channel each (two dependent cold reads, issued before everything else)
+    float pixel = 0.f;
+    if (gl < 3) {
+        const long long br = px.first_ray + r, b = br / px.R, rr = br - b * px.R;
+        const long long pix = px.ray_idx ? px.ray_idx[rr] : rr;
+        pixel = px.image[(b * 3 + gl) * px.hw + pix];
     }
-    float dlen = 0.f;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        f32x4 ds4, dc4[3];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = 4 * q + t;
-            const float ds = g[i] * TE[i] - aft[i];                   // dL/d(sigma*delta)
-            ds4[t] = ds * (p.itv[i] * len);
-            if (p.v[q]) dlen += ds * (p.sig[i] * p.itv[i]);
+    const float rx = ray[r * 3], ry = ray[r * 3 + 1], rz = ray[r * 3 + 2];
+    const float len = ray_length(rx, ry, rz);
+    __shared__ float stage_all[WAVES * RPW * Q * 192];
+    float* stage = stage_all + (wave * RPW + lane / G) * Q * 192;
+    Span<Q> p;
+    load_span<Q, false, true>(p, sigma_s + r * S, depth_s + r * S, rgb_s + r * S * 3, S, gl, len, stage);
+    float ex[4 * Q], T[4 * Q], E[4 * Q], w[4 * Q];
+    span_prefix<Q>(p, ex);
+    span_weights<Q, false>(p, ex, T, E, w);
+    const RaySums a = span_forward<Q, false>(p, w, live, prob ? prob + r * S : nullptr);
+    // lane 0 holds the stored colour; the residuals and the colour's gradient are formed there exactly as mse_kernel forms them
+    const float p1 = dpp_zero_fill<kRowShl | 1>(pixel), p2 = dpp_zero_fill<kRowShl | 2>(pixel);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (gl == 0) {
+        const float e0 = a.a0 - pixel, e1 = a.a1 - p1, e2 = a.a2 - p2;
+        g0 = (float)(px.slope * (double)e0); g1 = (float)(px.slope * (double)e1); g2 = (float)(px.slope * (double)e2);
+        if (live) {
+            rgb[r * 3] = a.a0; rgb[r * 3 + 1] = a.a1; rgb[r * 3 + 2] = a.a2;
+            depth[r] = a.ad;
+            opacity[r] = a.ao;
+            resid[r * 3] = e0; resid[r * 3 + 1] = e1; resid[r * 3 + 2] = e2;
+            if (d_rgb) { d_rgb[r * 3] = g0; d_rgb[r * 3 + 1] = g1; d_rgb[r * 3 + 2] = g2; }
         }
-#pragma unroll
-        for (int t = 0; t < 12; ++t) dc4[t / 4][t % 4] = w[4 * q + t / 3] * (t % 3 == 0 ? gr0 : t % 3 == 1 ? gr1 : gr2);
-        if (p.v[q] && live) st4<NTS>(d_sigma_s + r * S + p.s0[q], ds4);
-        if (XP) {
-            // the colour gradients leave the way the colours came: through the ray's staging rows (all reads of the forward direction
-            // are complete: the wave's LDS accesses execute in order), as whole cache lines per store
-#pragma unroll
-            for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(stage + 192 * q + 12 * gl + 4 * j) = dc4[j];
-        } else if (p.v[q] && live) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) st4<NTS>(d_rgb_s + (r * S + p.s0[q]) * 3 + 4 * j, dc4[j]);
-        }
     }
-    if (XP) {
-        __builtin_amdgcn_wave_barrier();
+    const float gr0 = __shfl(g0, 0, G), gr1 = __shfl(g1, 0, G), gr2 = __shfl(g2, 0, G);
+    f32x4 gp[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = 192 * q + 4 * (16 * j + gl);
-                if (e < 3 * S && live) st4<NTS>(d_rgb_s + r * S * 3 + e, *reinterpret_cast<const f32x4*>(stage + e));
-            }
-    }
-    dlen = row16_sum(dlen);
+    for (int q = 0; q < Q; ++q) gp[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float dlen = span_backward<Q, false, true>(p, T, E, w, gr0, gr1, gr2, 0.f, 0.f, gp, len, live, S, gl, stage, d_rgb_s + r * S * 3, d_sigma_s + r * S);
     if (gl == 0 && live) {
         const float inv = len > 0.f ? dlen / len : 0.f;
         d_ray[r * 3] = inv * rx; d_ray[r * 3 + 1] = inv * ry; d_ray[r * 3 + 2] = inv * rz;
@@ -648,8 +754,8 @@ __global__ __launch_bounds__(256) void composite_bwd_scalar_kernel(const float* 
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline int group_lanes(int S) {      // lanes per ray: 8 up to 32 samples, 16 up to 256 (one to four quads per lane), 64 beyond (chunks of 256)
-    return S <= 32 ? 8 : S <= 256 ? 16 : 64;
+inline int group_lanes(int S) {      // lanes per ray: 16 up to 256 samples (one to four quads per lane), 64 beyond (chunks of 256)
+    return S <= 256 ? 16 : 64;
 }
 // From 2 M samples per launch (a full image: 7.7-23 M) the accesses carry the non-temporal hint: the operands are touched once and
 // exceed the L2s (32 MiB) -- the training launches (<= 0.8 M samples, produced and consumed by the neighbouring kernels) keep the default.
@@ -697,8 +803,7 @@ extern "C" int niw_composite_fwd(const float* ray, const float* rgb_s, const flo
         if (nt) composite_fwd_span_kernel<QQ, 4, true, false, false, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob); \
         else composite_fwd_span_kernel<QQ, 4, false, false, false, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, rgb, depth, opacity, prob);  \
     } while (0)
-        if (G == 8) NIW_CFWD(8);
-        else if (S <= 64) NIW_CFWD_SPAN(1);
+        if (S <= 64) NIW_CFWD_SPAN(1);
         else if (S <= 128) NIW_CFWD_SPAN(2);
         else if (S <= 192) NIW_CFWD_SPAN(3);
         else if (S <= 256) NIW_CFWD_SPAN(4);
@@ -739,8 +844,7 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
         if (nt) composite_bwd_span_kernel<QQ, 4, true, false, true, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray); \
         else composite_bwd_span_kernel<QQ, 4, false, false, false, true><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, has_bg, bg, d_rgb, d_depth, d_opacity, d_prob, d_rgb_s, d_sigma_s, d_ray); \
     } while (0)
-        if (G == 8) NIW_CBWD(8);
-        else if (S <= 64) NIW_CBWD_SPAN(1);
+        if (S <= 64) NIW_CBWD_SPAN(1);
         else if (S <= 128) NIW_CBWD_SPAN(2);
         else if (S <= 192) NIW_CBWD_SPAN(3);
         else if (S <= 256) NIW_CBWD_SPAN(4);
@@ -753,5 +857,35 @@ extern "C" int niw_composite_bwd(const float* ray, const float* rgb_s, const flo
                                                             d_prob, d_rgb_s, d_sigma_s, d_ray);
     }
     NIW_LAUNCH_CHECK("niw_composite_bwd");
+    return NIW_OK;
+}
+
+// Training form: niw_composite_fwd + niw_mse_fwd_bwd + niw_composite_bwd of one ray batch as ONE launch (composite_train_span_kernel).
+// NIW_ERR_UNSUPPORTED (nothing launched) for shapes outside the span kernels: the caller then makes the three calls.
+extern "C" int niw_composite_mse_train(const float* ray, const float* rgb_s, const float* sigma_s, const float* depth_s, int64_t n_rays, int n_samples,
+                                       const float* image, const int64_t* ray_idx, int n_views, int64_t n_rays_per_view, int64_t hw, int64_t first_ray,
+                                       double n_norm, float grad_scale, float* rgb, float* depth, float* opacity, float* prob, float* resid, float* d_rgb,
+                                       float* d_rgb_s, float* d_sigma_s, float* d_ray, niw_stream_t stream) {
+    NIW_REQUIRE(ray && rgb_s && sigma_s && depth_s && image && rgb && depth && opacity && resid && d_rgb_s && d_sigma_s && d_ray, "niw_composite_mse_train: null pointer");
+    NIW_REQUIRE(n_rays > 0 && n_samples > 0, "niw_composite_mse_train: empty input (n_rays=%lld, S=%d)", (long long)n_rays, n_samples);
+    NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && hw > 0 && n_norm > 0, "niw_composite_mse_train: empty batch");
+    NIW_REQUIRE(first_ray >= 0 && first_ray + n_rays <= (int64_t)n_views * n_rays_per_view, "niw_composite_mse_train: rays [%lld, %lld) leave the %d x %lld batch",
+                (long long)first_ray, (long long)(first_ray + n_rays), n_views, (long long)n_rays_per_view);
+    const int S = n_samples;
+    if (S < 2 || S > 256 || S % 4 != 0 || !aligned16(rgb_s) || !aligned16(sigma_s) || !aligned16(depth_s) || !aligned16(d_rgb_s) || !aligned16(d_sigma_s) ||
+        (prob && !aligned16(prob))) {
+        niw_set_error("niw_composite_mse_train: S=%d or the operands' alignment is outside the one-launch form (S %% 4 == 0, S <= 256, 16-byte rows)", S);
+        return NIW_ERR_UNSUPPORTED;
+    }
+    TrainPixels px{image, ray_idx, (long long)n_rays_per_view, (long long)hw, (long long)first_ray, (double)grad_scale * 2.0 / n_norm};
+    const int blocks = (int)((n_rays + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+#define NIW_CTRAIN(QQ) composite_train_span_kernel<QQ, 4><<<blocks, 256, 0, st>>>(ray, rgb_s, sigma_s, depth_s, n_rays, S, px, rgb, depth, opacity, prob, resid, d_rgb, d_rgb_s, d_sigma_s, d_ray)
+    if (S <= 64) NIW_CTRAIN(1);
+    else if (S <= 128) NIW_CTRAIN(2);
+    else if (S <= 192) NIW_CTRAIN(3);
+    else NIW_CTRAIN(4);
+#undef NIW_CTRAIN
+    NIW_LAUNCH_CHECK("niw_composite_mse_train");
     return NIW_OK;
 }

@@ -2,6 +2,7 @@
 // loss and the Adam update.  All are tiny next to the field MLP; they exist so that the whole
 // step stays on the device without host round trips.
 #include "niw_common.h"
+#include "niw_loss_device.h"
 
 namespace {
 
@@ -218,6 +219,13 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb
         for (int w = 0; w < 16; ++w) t += red[w];
         loss[0] = (float)(t / n_norm);
     }
+}
+
+// the loss value from residuals left by the training form of the compositing kernel (niw_composite_mse_train): same sum, same order
+__global__ __launch_bounds__(256) void mse_from_residuals_kernel(const float* __restrict__ resid, long long total, double n_norm, float* __restrict__ loss) {
+    __shared__ double red[16];
+    const double t = niw::sq_sum_in_mse_order(resid, total, red);
+    if (threadIdx.x == 0) loss[0] = (float)(t / n_norm);
 }
 
 // ---------------------------------------------------------------- torch.optim.Adam (single tensor, no amsgrad / weight decay)
@@ -476,6 +484,14 @@ int niw_launch_raygen_stacked(const float* intr, const float* pose, const int64_
     const long long n = (long long)n_views * R;
     raygen_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(intr, pose, ray_idx, 0, n_views, R, H, W, 0, 2 * R, stacked + 3 * R, stacked);
     NIW_LAUNCH_CHECK("niw_train_step (ray generation)");
+    return NIW_OK;
+}
+
+extern "C" int niw_mse_from_residuals(const float* resid, int64_t n_rays, double n_norm, float* loss, niw_stream_t stream) {
+    NIW_REQUIRE(resid && loss, "niw_mse_from_residuals: null pointer");
+    NIW_REQUIRE(n_rays > 0 && n_norm > 0, "niw_mse_from_residuals: empty input");
+    mse_from_residuals_kernel<<<1, 256, 0, (hipStream_t)stream>>>(resid, (long long)n_rays * 3, n_norm, loss);
+    NIW_LAUNCH_CHECK("niw_mse_from_residuals");
     return NIW_OK;
 }
 

@@ -15,6 +15,7 @@
 // separately rounded), so the engine's parameters agree bit for bit with the autograd mirror on the same inputs.
 #include <mutex>
 #include "niw_common.h"
+#include "niw_loss_device.h"
 #include <stdlib.h>
 
 // launches that exist for this sequencer only (each = two launches of the public entry points in one, same arithmetic)
@@ -81,6 +82,11 @@ struct CombineArgs {
     float* loss;
     float w[3];
     int present[3];             // term k was computed by the LOSS stage (else it is written as 0 here)
+    // photometric terms whose residuals the one-launch compositing kernels left behind: their value is formed HERE (workgroup 0), in
+    // mse_kernel's order -- NULL: the term came from niw_mse_fwd_bwd
+    const float* resid[2];
+    long long resid_n;          // residuals per term (3 per ray)
+    double n_norm;
 };
 
 __global__ void combine_kernel(CombineArgs a) {
@@ -110,6 +116,15 @@ __global__ void combine_kernel(CombineArgs a) {
         a.d_warped[v * 6 * a.R + 3 * a.R + rem] = c;
     }
     if (a.d_latent && i < a.lat_n && (i < a.lat_lo || i >= a.lat_hi)) a.d_latent[i] = 0.f;
+    if (blockIdx.x == 0 && (a.resid[0] || a.resid[1])) {
+        __shared__ double red[16];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (a.resid[k]) {                                             // (uniform over the workgroup)
+                const double t = niw::sq_sum_in_mse_order(a.resid[k], a.resid_n, red);
+                if (threadIdx.x == 0) a.loss[k] = (float)(t / a.n_norm);
+            }
+    }
     if (i == 0) {
         float total = 0.f;
         bool first = true;
@@ -237,6 +252,7 @@ struct Layout {
     float *z_all, *rgb_f, *sigma_f, *rgb_fine, *depth_fine, *opacity_fine;
     float *packed_c, *packed_f, *save_c, *save_f, *gradws, *partial;
     float *d_rgb, *d_rgb_f, *d_rgb_s, *d_sigma_s, *comp_d_ray_c, *comp_d_ray_f, *mlp_d_c, *mlp_d_f;   // mlp_d_*: [2][n][3] = {d_center, d_ray}
+    float *resid_c, *resid_f, *d_rgb_s_c, *d_sigma_s_c;   // one-launch compositing + loss + backward: residuals [n,3]; the coarse pass's own sample gradients
     float *mom, *poses, *d_target, *d_warped, *warp_ws, *d_w_emb, *d_view_b, *d_w_head, *prep_bwd_ws;
     long long total;
 };
@@ -302,6 +318,11 @@ Layout make_layout(const niw_train_desc* d, float* base) {
     L.d_rgb_s = ws.take(3 * n * M); L.d_sigma_s = ws.take(n * M);
     L.comp_d_ray_c = ws.take(3 * n); L.mlp_d_c = ws.take(6 * n);
     if (T) { L.comp_d_ray_f = ws.take(3 * n); L.mlp_d_f = ws.take(6 * n); }
+    // one-launch form: the coarse pass's backward runs with its forward, long before the fine pass's -- with a fine pass it needs sample
+    // gradients of its own (4 MB at cfg2) instead of sharing the fine pass's
+    L.resid_c = ws.take(3 * n);
+    L.d_rgb_s_c = L.d_rgb_s; L.d_sigma_s_c = L.d_sigma_s;
+    if (T) { L.resid_f = ws.take(3 * n); L.d_rgb_s_c = ws.take(3 * n * S); L.d_sigma_s_c = ws.take(n * S); }
     L.mom = ws.take(2 * 16 * L.V);                     // double [V,16]
     L.poses = ws.take(12 * L.V);
     L.d_target = ws.take(3 * P); L.d_warped = ws.take(3 * P);
@@ -406,24 +427,43 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     if (in(NIW_STAGE_MLP_FWD))
         NIW_RUN(niw_mlp_fwd(L.packed_c, center, ray, L.z, nullptr, n, S, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_s, L.sigma_s,
                             (loss_c ? L.save_c : nullptr), stream));
-    if (in(NIW_STAGE_COMPOSITE_FWD))
-        NIW_RUN(niw_composite_fwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, rgb, L.depth, L.opacity, L.prob, stream));
+    // compositing + photometric residual + their backward as ONE launch per pass wherever the span kernels cover the sample count
+    // (niw_composite_mse_train; NIW_TRAIN_ONE_LAUNCH_LOSS=0: the three launches, diagnostic); the loss values are then formed by the
+    // closing kernel of the iteration (combine_kernel) from the residuals
+    static const bool one_launch_env = [] { const char* e = getenv("NIW_TRAIN_ONE_LAUNCH_LOSS"); return !e || atoi(e) != 0; }();
+    const int64_t hw = (int64_t)d->H * d->W;
+    const bool one_c = one_launch_env && loss_c && S % 4 == 0 && S <= 256;
+    const bool one_f = one_launch_env && loss_f && T % 4 == 0 && T <= 256;
+    if (in(NIW_STAGE_COMPOSITE_FWD)) {
+        if (one_c)
+            NIW_RUN(niw_composite_mse_train(ray, L.rgb_s, L.sigma_s, L.z, n, S, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, d->mse_norm, d->w_render, rgb, L.depth,
+                                            L.opacity, L.prob, L.resid_c, nullptr, L.d_rgb_s_c, L.d_sigma_s_c, L.comp_d_ray_c, stream));
+        else
+            NIW_RUN(niw_composite_fwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, rgb, L.depth, L.opacity, L.prob, stream));
+    }
     if (fine) {
         if (in(NIW_STAGE_RESAMPLE)) NIW_RUN(niw_sample_pdf_merge(L.prob, L.z, d->unif, d->bins, n, S, d->n_fine, nullptr, L.z_all, stream));
         if (in(NIW_STAGE_MLP_FWD_FINE))
             NIW_RUN(niw_mlp_fwd(L.packed_f, center, ray, L.z_all, nullptr, n, T, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_f,
                                 L.sigma_f, (loss_f ? L.save_f : nullptr), stream));
-        if (in(NIW_STAGE_COMPOSITE_FWD_FINE))
-            NIW_RUN(niw_composite_fwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, rgb_fine, L.depth_fine, L.opacity_fine, nullptr, stream));
+        if (in(NIW_STAGE_COMPOSITE_FWD_FINE)) {
+            if (one_f)
+                NIW_RUN(niw_composite_mse_train(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, d->mse_norm, d->w_render_fine,
+                                                rgb_fine, L.depth_fine, L.opacity_fine, nullptr, L.resid_f, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
+            else
+                NIW_RUN(niw_composite_fwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, rgb_fine, L.depth_fine, L.opacity_fine, nullptr, stream));
+        }
     }
     if (in(NIW_STAGE_LOSS)) {
-        const int64_t hw = (int64_t)d->H * d->W;
-        if (loss_c) NIW_RUN(niw_mse_fwd_bwd(rgb, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render, d->loss + 0, L.d_rgb, stream));
-        if (loss_f) NIW_RUN(niw_mse_fwd_bwd(rgb_fine, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render_fine, d->loss + 1, L.d_rgb_f, stream));
+        if (loss_c && !one_c) NIW_RUN(niw_mse_fwd_bwd(rgb, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render, d->loss + 0, L.d_rgb, stream));
+        if (loss_f && !one_f) NIW_RUN(niw_mse_fwd_bwd(rgb_fine, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, n, d->mse_norm, d->w_render_fine, d->loss + 1, L.d_rgb_f, stream));
     }
+    // (the coarse pass's sample gradients: its own buffers when its backward ran with its forward, else the shared ones)
+    float* const d_rgb_s_c = one_c ? L.d_rgb_s_c : L.d_rgb_s;
+    float* const d_sigma_s_c = one_c ? L.d_sigma_s_c : L.d_sigma_s;
     if (fine) {
         if (loss_f) {
-            if (in(NIW_STAGE_COMPOSITE_BWD_FINE))
+            if (in(NIW_STAGE_COMPOSITE_BWD_FINE) && !one_f)
                 NIW_RUN(niw_composite_bwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, L.d_rgb_f, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
             if (in(NIW_STAGE_MLP_BWD_DX_FINE))
                 NIW_RUN(niw_mlp_bwd_dx(L.packed_f, center, ray, L.z_all, n, T, d->density_activ, d->precision, L.rgb_f, L.d_rgb_s, L.d_sigma_s, L.save_f, L.gradws,
@@ -434,10 +474,10 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         }
     }
     if (loss_c) {
-        if (in(NIW_STAGE_COMPOSITE_BWD))
+        if (in(NIW_STAGE_COMPOSITE_BWD) && !one_c)
             NIW_RUN(niw_composite_bwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, L.d_rgb, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_c, stream));
         if (in(NIW_STAGE_MLP_BWD_DX))
-            NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, L.d_rgb_s, L.d_sigma_s, L.save_c, L.gradws, L.mlp_d_c,
+            NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, d_rgb_s_c, d_sigma_s_c, L.save_c, L.gradws, L.mlp_d_c,
                                    L.mlp_d_c + 3 * n, stream));
     }
     if (lane) {
@@ -465,6 +505,8 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         c.loss = d->loss;
         c.w[0] = d->w_render; c.w[1] = d->w_render_fine; c.w[2] = d->w_align;
         c.present[0] = loss_c; c.present[1] = loss_f; c.present[2] = align && L.n_own > 0;
+        c.resid[0] = one_c ? L.resid_c : nullptr; c.resid[1] = one_f ? L.resid_f : nullptr;
+        c.resid_n = 3 * n; c.n_norm = d->mse_norm;
         const long long work = V * R * 3 > c.lat_n ? V * R * 3 : c.lat_n;
         combine_kernel<<<(unsigned)((work + 255) / 256), 256, 0, X>>>(c);
         NIW_LAUNCH_CHECK("niw_train_step (combine)");

@@ -375,3 +375,58 @@ def test_training_is_bit_reproducible_and_graph_replay_equals_eager_bit_for_bit(
     assert la == lc
     for x, y in zip(a, c):
         assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: compositing + photometric residual + their backward as ONE launch (niw_composite_mse_train) against the three calls it
+# replaces in a train iteration -- same device functions, same arithmetic order: every output bit for bit, the loss included
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,N,B,R,first", [(16, 37, 3, 20, 5), (64, 45, 5, 9, 0), (128, 254, 18, 113, 508), (192, 101, 4, 60, 17), (200, 33, 3, 11, 0),
+                                          (256, 18, 2, 9, 0)])
+def test_one_launch_compositing_loss_and_backward_equal_the_three_calls(S, N, B, R, first):
+    from neural_invertible_warp_amd import _lib, ops
+    P = ops._p
+    rng = np.random.default_rng(S + N)
+    H, W = 12, 16
+    hw = H * W
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    ray, rgb_s = g(rng.standard_normal((N, 3))), g(rng.uniform(0, 1, (N, S, 3)))
+    sig = g(rng.uniform(0, 3, (N, S)) * (rng.uniform(0, 1, (N, S)) > 0.3))
+    dep = g(np.sort(rng.uniform(0.5, 6, (N, S)), axis=1))
+    image = g(rng.uniform(0, 1, (B, 3, H, W)))
+    ray_idx = torch.from_numpy(rng.permutation(hw)[:R].astype(np.int64)).to(DEV)
+    n_norm, scale = float(3 * B * R), 10.0 ** 0.5
+    st = ops._stream()
+    new = lambda *shape: torch.full(shape, float("nan"), device=DEV)
+
+    a = dict(rgb=new(N, 3), depth=new(N), opa=new(N), prob=new(N, S), d_rgb=new(N, 3), d_rgb_s=new(N, S, 3), d_sig=new(N, S), d_ray=new(N, 3), loss=new(1))
+    _lib.call("niw_composite_fwd", P(ray), P(rgb_s), P(sig), P(dep), N, S, 0, 0.0, P(a["rgb"]), P(a["depth"]), P(a["opa"]), P(a["prob"]), st)
+    _lib.call("niw_mse_fwd_bwd", P(a["rgb"]), P(image), P(ray_idx), B, R, hw, first, N, n_norm, scale, P(a["loss"]), P(a["d_rgb"]), st)
+    _lib.call("niw_composite_bwd", P(ray), P(rgb_s), P(sig), P(dep), N, S, 0, 0.0, P(a["d_rgb"]), None, None, None, P(a["d_rgb_s"]), P(a["d_sig"]), P(a["d_ray"]), st)
+
+    b = dict(rgb=new(N, 3), depth=new(N), opa=new(N), prob=new(N, S), d_rgb=new(N, 3), d_rgb_s=new(N, S, 3), d_sig=new(N, S), d_ray=new(N, 3), loss=new(1))
+    resid = new(N, 3)
+    _lib.call("niw_composite_mse_train", P(ray), P(rgb_s), P(sig), P(dep), N, S, P(image), P(ray_idx), B, R, hw, first, n_norm, scale,
+              P(b["rgb"]), P(b["depth"]), P(b["opa"]), P(b["prob"]), P(resid), P(b["d_rgb"]), P(b["d_rgb_s"]), P(b["d_sig"]), P(b["d_ray"]), st)
+    _lib.call("niw_mse_from_residuals", P(resid), N, n_norm, P(b["loss"]), st)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    assert not torch.isnan(b["d_rgb_s"]).any() and float(b["loss"]) > 0
+    # the residuals are rgb - pixel of the ray's view and pixel
+    br = first + torch.arange(N, device=DEV)
+    pix = image.view(B, 3, hw)[br // R][:, :, ray_idx][torch.arange(N, device=DEV), :, br % R]
+    assert torch.equal(resid, b["rgb"] - pix)
+
+
+def test_one_launch_form_refuses_shapes_outside_the_span_kernels():
+    from neural_invertible_warp_amd import _lib, ops
+    from neural_invertible_warp_amd._lib import NiwError
+    P = ops._p
+    N, B, R, hw = 8, 2, 4, 16
+    z = lambda *shape: torch.zeros(shape, device=DEV)
+    for S in (6, 260):
+        out = [z(N, 3), z(N), z(N), z(N, S), z(N, 3), z(N, 3), z(N, S, 3), z(N, S), z(N, 3)]
+        with pytest.raises(NiwError, match="one-launch form"):
+            _lib.call("niw_composite_mse_train", P(z(N, 3)), P(z(N, S, 3)), P(z(N, S)), P(z(N, S)), N, S, P(z(B, 3, hw)), None, B, R, hw, 0, 24.0, 1.0,
+                      *[P(o) for o in out], ops._stream())
