@@ -57,21 +57,23 @@ PEAK_BF16_MFMA = 2500.0         # TFLOP/s dense (the guide's ~2.5 PF; never the 
 PEAK_HBM = 8000.0               # GB/s spec (6290 GB/s measured streaming copy)
 
 
-def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False):
-    """The CPU oracle (a restatement of the reference's PyTorch path, pinned to golden vectors) timed on
-    this box's host cores on a bounded sample of the same workload: same views / resolution / samples per
-    ray, fewer rays per view; 1 warm-up + 3 timed steps, the median reported.  vanilla: BASELINE configs[0] (ground-truth
-    poses, ReLU density, metric depth [0,1], no warp: model/nerf.py:251-288) instead of the INN step."""
+def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False, budget_s=45.0):
+    """The CPU oracle (a restatement of the reference's PyTorch path, pinned to golden vectors) timed on this box's host cores on a
+    bounded sample of the same workload: same views / resolution / samples per ray, and since round 5 HALF the rays of the batch (113
+    per view at 18 views; the whole 227 when a step fits the budget): at 16 rays per view (rounds 1-4) the fixed per-step work -- the
+    full-resolution ray grid, the warp's parameter preparation -- was a fifth of a step that is 2 % of one at the real size.
+    Threads: torch's CPU path does not speed up monotonically with threads on a box of unknown topology / cgroup quota, so a short
+    step (16 rays per view) is timed at 8 / 16 / 32 / 64 threads (no more than the cores the process may run on) and the best count is used.
+    vanilla: BASELINE configs[0] (ground-truth poses, ReLU density, metric depth [0,1], no warp: model/nerf.py:251-288).
+    The oracle makes the reference's discarded first ray-grid call too (`reference_cost`), so that it costs what the reference costs
+    (profiles/r5_oracle_calibration.json)."""
     import torch
     from oracle import niw_oracle as O
     # cores this process may actually run on (a cgroup-limited box reports every host core in cpu_count)
     try:
-        threads = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        threads = os.cpu_count() or 1
-    threads = max(1, min(threads, 64))
-    torch.set_num_threads(threads)
-    R = max(2, 288 // B)                                    # rays per view in the sample (16 at 18 views)
+        affinity = os.cpu_count() or 1
     req = lambda d: {k: v.requires_grad_(True) for k, v in d.items()}
     pc, wp = req(O.make_nerf_params(1)), req(O.make_warp_params(3, 0.02))
     pf = req(O.make_nerf_params(2)) if Sf else None
@@ -81,10 +83,13 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False):
     intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(B, 1, 1)
     pose = torch.eye(3, 4).repeat(B, 1, 1)
     w3, wv = O.c2f_weights(0.3, (0.1, 0.5), 10), O.c2f_weights(0.3, (0.1, 0.5), 4)
-    times = []
-    for i in range(4):
+    params = list(pc.values()) + list(wp.values()) + (list(pf.values()) if pf else []) + [lat]
+
+    def one_step(R):
         ray_idx = torch.randperm(H * W, generator=gen)[:R]
         u = torch.rand(B, R, S, 1, generator=gen)
+        for prm in params:
+            prm.grad = None
         t0 = time.perf_counter()
         if vanilla:
             center, ray = O.center_and_ray(H, W, pose, intr)
@@ -93,28 +98,57 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False):
             loss = O.mse_loss(out["rgb"], target) + (O.mse_loss(out["rgb_fine"], target) if Sf else 0.0)
         else:
             out = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", 0.3, nerf_fine_p=pf, Sf=Sf,
-                                   ga_weight=ga_weight, w3d=w3, wview=wv)
+                                   ga_weight=ga_weight, w3d=w3, wview=wv, reference_cost=True)
             loss = out["loss"]
         loss.backward()
-        times.append(time.perf_counter() - t0)
-    evals = B * R * (S + (S + Sf if Sf else 0))
+        return time.perf_counter() - t0
+
+    per_ray = S + (S + Sf if Sf else 0)
+    t_begin = time.perf_counter()
+    # 1. thread count: a short step at every candidate, best of two after a warm-up
+    R_small = max(2, 288 // B)
+    sweep = {}
+    for n in sorted({min(n, affinity) for n in (8, 16, 32, 64)}):          # (all 256 hardware threads of a GPU box: 80 s per step, 90 x the best)
+        torch.set_num_threads(n)
+        warm = one_step(R_small)
+        if sweep and warm > 4 * min(sweep.values()):                        # hopeless count: its warm-up step is the record
+            sweep[n] = warm
+            continue
+        sweep[n] = min(one_step(R_small), one_step(R_small))
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    # 2. the figure: half the batch's rays per view (113 of 227 at cfg2 / all 113 of cfg3's), 1 warm-up + 2 timed; the full batch if the
+    # budget allows (estimated from the short step)
+    R_full = None
+    est = sweep[threads] / (B * R_small * per_ray)                    # seconds per evaluation at the short step (an over-estimate)
+    R_half = max(R_small, 2048 // B)
+    rays_of_batch = 4096 // B if Sf and not vanilla else 2048 // B if not vanilla else 1024 // B
+    R = rays_of_batch if est * B * rays_of_batch * per_ray * 3 < budget_s else min(R_half, rays_of_batch)
+    while R > R_small and est * B * R * per_ray * 3 > 2 * budget_s:
+        R = max(R_small, R // 2)
+    times = [one_step(R) for _ in range(3)]
+    evals = B * R * per_ray
     timed = sorted(times[1:])
-    median = timed[len(timed) // 2]
-    out = dict(value=evals / median, unit="ray-samples/s", cores=threads, kind="port",
-               sample=f"{B} views x {R} rays x ({S}" + (f"+{S + Sf}" if Sf else "") + f") samples = {evals} MLP evals per step, fwd+bwd, "
-                      f"median of 3 timed steps after 1 warm-up, torch CPU {threads} threads",
-               seconds_per_step=[round(t, 3) for t in times[1:]], best_value=evals / timed[0])
-    # the port must time within +-10 % of the imported reference; measured in the build container it takes 0.895 x
-    # the reference's time (it forms the un-warped ray grid once per step where the reference forms it twice), i.e. it flatters the
-    # CPU by 10.5 %: the figure the reference itself would reach on these cores is reported beside it
+    best = timed[0]
+    out = dict(value=evals / best, unit="ray-samples/s", cores=threads, kind="port",
+               sample=f"{B} views x {R} rays x ({S}" + (f"+{S + Sf}" if Sf else "") + f") samples = {evals} MLP evals per step (the batch has {rays_of_batch} "
+                      f"rays per view), fwd+bwd, best of 2 timed steps after 1 warm-up, torch CPU {threads} threads",
+               seconds_per_step=[round(t, 3) for t in times[1:]], affinity_cores=affinity, host_cores=os.cpu_count(),
+               thread_sweep={str(n): dict(seconds_per_step=round(t, 4), value=round(B * R_small * per_ray / t, 1)) for n, t in sweep.items()},
+               thread_sweep_sample=f"{B} views x {R_small} rays, best of 2 after 1 warm-up at each count; the count with the shortest step times the figure",
+               wall_s=round(time.perf_counter() - t_begin, 1))
+    # the port must time within +-10 % of the imported reference -- measured in the build container at the cfg3 batch
+    # itself (tools/calibrate_oracle.py); the figure the reference would reach on these cores is reported beside the port's
     if not vanilla:
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2_oracle_calibration.json")) as f:
-                ratio = float(json.load(f)["oracle_over_reference_time"])
-            out["calibration"] = dict(oracle_over_reference_time=ratio, source="profiles/r2_oracle_calibration.json (tools/calibrate_oracle.py, build container)",
-                                      reference_equivalent_value=round(out["value"] * ratio, 1))
-        except (OSError, KeyError, ValueError):
-            pass
+        for fname in ("r5_oracle_calibration.json", "r2_oracle_calibration.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    ratio = float(json.load(f)["oracle_over_reference_time"])
+                out["calibration"] = dict(oracle_over_reference_time=ratio, source=f"profiles/{fname} (tools/calibrate_oracle.py, build container)",
+                                          reference_equivalent_value=round(out["value"] * ratio, 1))
+                break
+            except (OSError, KeyError, ValueError):
+                pass
     return out
 
 
@@ -122,7 +156,7 @@ def rocprof_row(config, kernel):
     """The committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/r4_kernel_stats_<config>.csv, else an
     earlier round's): the row of `kernel`, so that the device-event average of this run stands next to the profiler's."""
     import csv
-    for rnd in ("r4", "r3", "r2"):
+    for rnd in ("r5", "r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{config}.csv")
         try:
             with open(path, newline="") as f:
@@ -228,32 +262,63 @@ def composite_scan(dev, iters=20):
     return dict(workload=f"{N} rays x {S} samples (one 300x400 image, fine pass)", bound="hbm", unit="GB/s", peak=PEAK_HBM, achievable=6290.0,
                 timing="us / achieved: 20 launches back to back (steady state: every launch also pays the write-back of its predecessor's dirty "
                        "lines -- the backward leaves 370 MB); us_isolated: a single launch on a drained device = the kernel's own duration, the "
-                       "figure a profiler's dispatch timestamps give (profiles/r3_composite_traffic.json)",
-                fwd=dict(kernel=f"composite_fwd_kernel<64>", bytes=bf, us=round(tf * 1e3, 1), us_isolated=round(tf1 * 1e3, 1), achieved=round(bf / tf / 1e6, 1), frac_of_peak=round(bf / tf / 1e6 / PEAK_HBM, 4),
+                       "figure a profiler's dispatch timestamps give (profiles/r5_composite_traffic.json)",
+                fwd=dict(kernel="composite_fwd_span_kernel<3, 4, nt>", bytes=bf, us=round(tf * 1e3, 1), us_isolated=round(tf1 * 1e3, 1), achieved=round(bf / tf / 1e6, 1), frac_of_peak=round(bf / tf / 1e6 / PEAK_HBM, 4),
                          frac_of_achievable=round(bf / tf / 1e6 / 6290.0, 4)),
-                bwd=dict(kernel=f"composite_bwd_kernel<64>", bytes=bb, us=round(tb * 1e3, 1), us_isolated=round(tb1 * 1e3, 1), achieved=round(bb / tb / 1e6, 1), frac_of_peak=round(bb / tb / 1e6 / PEAK_HBM, 4),
+                bwd=dict(kernel="composite_bwd_span_kernel<3, 4, nt>", bytes=bb, us=round(tb * 1e3, 1), us_isolated=round(tb1 * 1e3, 1), achieved=round(bb / tb / 1e6, 1), frac_of_peak=round(bb / tb / 1e6 / PEAK_HBM, 4),
                          frac_of_achievable=round(bb / tb / 1e6 / 6290.0, 4)),
                 bytes_per_sample=dict(fwd="12 rgb + 4 sigma + 4 depth in, 4 prob out", bwd="20 in, 12 d_rgb + 4 d_sigma out"),
-                traffic_source="profiles/r3_composite_traffic.json (rocprofv3 FETCH_SIZE x2 / WRITE_SIZE of the same launches)")
+                traffic_source="profiles/r5_composite_traffic.json (rocprofv3 FETCH_SIZE x2 / WRITE_SIZE of the same launches)")
 
 
-def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, precision="fp32", overlap=True):
-    """-> (list of (trainer, var0, B, R_local, S, Sf), description, rays of the global batch per scene)"""
+def scene_from_disk(opt, root, scene, dev):
+    """--llff-root: the resident batch of a REAL LLFF scene, read by the parser that is pinned to the reference's (data/llff.py <->
+    /root/reference data/llff.py:28-72): train split, images resized to opt.H x opt.W, intrinsics and poses from poses_bounds.npy.
+    -> (var0, number of train views)"""
+    from neural_invertible_warp_amd.data import llff
+    from neural_invertible_warp_amd.util import edict
+    opt.data.root, opt.data.scene, opt.data.dataset = root, scene, "llff"
+    batch = llff.Dataset(opt, split="train").prefetch_all_data(opt)
+    return edict({k: batch[k].to(dev) for k in ("idx", "image", "intr", "pose")}), int(batch.image.shape[0])
+
+
+def scenes_of_rank(scenes, rank, world):
+    """replica placement: scene i trains whole on rank i mod N (N = 8: one scene per GPU, scripts/train_llff.sh:1-8 side by side)"""
+    return [sc for i, sc in enumerate(scenes) if i % world == rank]
+
+
+def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, precision="fp32", overlap=True, placement="shard", llff_root=None,
+                    split_exchange="auto"):
+    """-> (list of (trainer, var0, B, R_local, S, Sf), description).  placement (cfg4, all scenes): "shard" = every rank trains every scene on
+    its share of the rays (gradient all-reduce per scene and step); "replicas" = scene i trains WHOLE on rank i mod N, no exchange at all
+    (/root/reference scripts/train_llff.sh:1-8: eight independent runs)."""
     from neural_invertible_warp_amd import configs, engine
     eff_world, eff_rank = (shard_of, 0) if shard_of else (world, rank)
+    replicas = placement == "replicas"
+    tr_world, tr_rank = (1, 0) if replicas else (eff_world, eff_rank)
     out, desc = [], None
+    data = []
 
-    def mk(opt, B, rays, warp_perturb=0.02, dtu=False):
+    def mk(opt, B, rays, warp_perturb=0.02, dtu=False, scene=None):
         opt.arch.precision = precision                                              # arithmetic of the field MLP (include/niw.h enum niw_precision)
-        opt.nerf.rand_rays = rays * (eff_world if scaling == "weak" else 1)        # global draw; each rank keeps idx[rank::world]
+        opt.nerf.rand_rays = rays * (tr_world if scaling == "weak" else 1)         # global draw; each rank renders a contiguous 1/N of it
+        var0 = None
+        if llff_root and scene and not dtu and os.path.isdir(os.path.join(llff_root, scene)):
+            var0, B = scene_from_disk(opt, llff_root, scene, dev)
+            data.append(f"llff:{scene}")
+        else:
+            data.append("synthetic")
+        kw = dict(rank=tr_rank, world=tr_world, warp_perturb=warp_perturb, hip_graph=hip_graph, overlap=overlap, collectives=not replicas,
+                  split_exchange=split_exchange)
         if dtu:
             var0, init = engine.synthetic_dtu_scene(opt, B)
-            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, initial_poses_w2c=init, hip_graph=hip_graph, overlap=overlap)
+            tr = engine.INNTrainer(opt, B, initial_poses_w2c=init, **kw)
         else:
-            var0 = engine.synthetic_scene(opt, B)
-            tr = engine.INNTrainer(opt, B, rank=eff_rank, world=eff_world, warp_perturb=warp_perturb, hip_graph=hip_graph, overlap=overlap)
+            var0 = var0 if var0 is not None else engine.synthetic_scene(opt, B)
+            tr = engine.INNTrainer(opt, B, **kw)
+        tr.scene_name = scene or name
         from neural_invertible_warp_amd import parallel
-        lo, hi = parallel.flat_share(B * (opt.nerf.rand_rays // B), eff_rank, eff_world)   # this rank's contiguous share of the B x R rays
+        lo, hi = parallel.flat_share(B * (opt.nerf.rand_rays // B), tr_rank, tr_world)   # this rank's contiguous share of the B x R rays
         S = opt.nerf.sample_intvs
         Sf = opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0
         out.append((tr, var0, B, (hi - lo) / B, S, Sf))                              # (rays per view: fractional for a share)
@@ -272,24 +337,28 @@ def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, p
         desc = ("cfg1: nerf_llff_repr.yaml 300x400 (configs[0]), 18 views x 56 rays x (64 coarse + 192 fine), ReLU density + noise, metric depth [0,1], "
                 "ground-truth poses (no warp, no ray gradients), fwd+bwd+Adam")
     elif name == "cfg2":
-        mk(configs.cfg2_nerf_inn_llff_hier(device=dev), 18, 4096)
+        mk(configs.cfg2_nerf_inn_llff_hier(device=dev), 18, 4096, scene="fern")
         desc = "cfg2: nerf_inn_llff.yaml fern 300x400, 18 views x 227 rays x (64 coarse + 192 fine), NVP-warped rays, fwd+bwd+Adam"
     elif name == "cfg3":
-        mk(configs.cfg3_barf_inn_llff(device=dev), 18, 2048)
+        mk(configs.cfg3_barf_inn_llff(device=dev), 18, 2048, scene="fern")
         desc = "cfg3: barf_inn_llff.yaml fern 300x400 (scripts/train_llff.sh:1), 18 views x 113 rays x 128, c2f PE, Kabsch alignment 1e4, fwd+bwd+Adam"
     elif name.startswith("cfg4"):
         scenes = list(configs.LLFF_TRAIN_VIEWS) if name == "cfg4" else [name.split("-", 1)[1]]
         for sc in scenes:
             if sc not in configs.LLFF_TRAIN_VIEWS:
                 raise SystemExit(f"unknown LLFF scene {sc!r}; choose from {list(configs.LLFF_TRAIN_VIEWS)}")
-            mk(configs.cfg3_barf_inn_llff(device=dev), configs.LLFF_TRAIN_VIEWS[sc], 2048)
+        mine = scenes_of_rank(scenes, eff_rank, eff_world) if replicas else scenes
+        for sc in mine:
+            mk(configs.cfg3_barf_inn_llff(device=dev), configs.LLFF_TRAIN_VIEWS[sc], 2048, scene=sc)
         desc = ("cfg4: barf_inn_llff.yaml, LLFF scenes " + ",".join(f"{s}({configs.LLFF_TRAIN_VIEWS[s]} views)" for s in scenes) +
-                ", 2048 // views rays per view x 128, one train iteration of every scene per step")
+                ", 2048 // views rays per view x 128, one train iteration of every scene per step" +
+                (f"; placement replicas: scene i whole on rank i mod {eff_world}, no gradient exchange (this rank: {','.join(mine) or 'none'})" if replicas else ""))
     elif name == "cfg5":
         mk(configs.cfg5_barf_inn_dtu(device=dev), 3, 2048, dtu=True)
         desc = "cfg5: barf_inn_dtu.yaml scan65-shaped 300x400 (scripts/train_dtu.sh:6), 3 views x 682 rays x 128, metric depth [1.2,5.2], noisy_gt poses, alignment 1e3"
     else:
         raise SystemExit(f"unknown --config {name}")
+    build_workloads.data = sorted(set(data)) or ["synthetic"]
     return out, desc
 
 
@@ -318,18 +387,27 @@ def launch_ranks_if_needed(gpus, argv):
     parent then starts a FRESH set of ranks with `--hip-graph off` appended."""
     if not needs_launcher(gpus, os.environ):
         return False
+    import shutil
     import subprocess
     import tempfile
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool (RCCL needs it across processes)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
-    marker = os.path.join(tempfile.gettempdir(), f"niw_capture_failed_{os.getpid()}")
+    # the marker lives in a directory of this parent's own (mkdtemp: mode 0700, unguessable name): a stale or foreign file under a
+    # predictable /tmp name could otherwise turn any rank failure into a "capture failure" and mask the original error behind a retry
+    marker_dir = tempfile.mkdtemp(prefix="niw_bench_")
+    marker = os.path.join(marker_dir, "capture_failed")
     env[CAPTURE_MARKER_ENV] = marker
-    rc = subprocess.call(launcher_command(gpus, argv), env=env)
-    if rc != 0 and os.path.exists(marker):
-        os.remove(marker)
-        print("bench.py: HIP-graph capture failed on a rank; starting fresh ranks with --hip-graph off", file=sys.stderr, flush=True)
-        rc = subprocess.call(launcher_command(gpus, list(argv) + ["--hip-graph", "off"], port=29500 + (os.getpid() + 977) % 2000), env=env)
+    try:
+        rc = subprocess.call(launcher_command(gpus, argv), env=env)
+        if rc != 0 and os.path.exists(marker):
+            os.remove(marker)
+            print("bench.py: HIP-graph capture failed on a rank (exit code 75 there); starting fresh ranks with --hip-graph off -- the line will say "
+                  "capture_fallback: true", file=sys.stderr, flush=True)
+            env["NIW_CAPTURE_FALLBACK"] = "1"
+            rc = subprocess.call(launcher_command(gpus, list(argv) + ["--hip-graph", "off"], port=29500 + (os.getpid() + 977) % 2000), env=env)
+    finally:
+        shutil.rmtree(marker_dir, ignore_errors=True)
     sys.exit(rc)
 
 
@@ -374,6 +452,17 @@ def main():
     ap.add_argument("--overlap", choices=["on", "off"], default="on",
                     help="niw_train_desc.overlap: the small independent stages of an iteration on the library's second stream beside the field-MLP kernels (default) "
                          "or everything on one stream in stage order")
+    ap.add_argument("--placement", choices=["both", "shard", "replicas"], default="both",
+                    help="cfg4 (all 8 LLFF scenes) on N GPUs: `shard` = every scene ray-sharded N ways (one gradient all-reduce per scene and step), "
+                         "`replicas` = scene i whole on rank i mod N with no exchange at all (the reference's own way: scripts/train_llff.sh:1-8 are "
+                         "eight independent runs); `both` (default) times the shard placement as the line's headline and the replicas beside it "
+                         "(`replicas` object).  With --shard-of K at N = 1: the scenes / shares of rank 0 of K")
+    ap.add_argument("--llff-root", default=os.environ.get("NIW_LLFF_ROOT"),
+                    help="directory holding real LLFF scenes (<root>/<scene>/images, poses_bounds.npy; also NIW_LLFF_ROOT): a scene found there feeds "
+                         "the trainer instead of the synthetic one (data/llff.py, pinned to /root/reference data/llff.py:28-72) and `data` says so")
+    ap.add_argument("--split-exchange", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1 with a fine network: the gradient exchange as two all-reduces, the fine network's segment on a communication stream "
+                         "while the rest of the backward runs (auto: where the iteration is one launched call); off: one flat all-reduce")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the torch.distributed process group even for ONE rank, so that the gradient all-reduce really goes through RCCL "
                          "(hardware evidence of the N > 1 code path on a 1-GPU box)")
@@ -456,7 +545,11 @@ def main():
         if trace is not None:
             print("bench.py trace (ms): host per step " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + trace[:-2], trace[:-1])) +
                   f" | drain {1e3 * (trace[-1] - trace[-2]):.2f} | fence {1e3 * (t0 + dt_ - trace[-1]):.2f}", file=sys.stderr, flush=True)
-        comm = [a.elapsed_time(b) for tr, *_ in loads_ for a, b in (getattr(tr, "comm_events", None) or [])]
+        # device events of the gradient exchange (engine.INNTrainer._all_reduce): per iteration the collectives' own durations (summed: a split
+        # exchange has two) and the EXPOSED part -- end of the backward on the main stream to the start of the optimizer
+        entries = [e for tr, *_ in loads_ for e in (getattr(tr, "comm_events", None) or [])]
+        comm = [sum(a.elapsed_time(b) for a, b in pairs) for pairs, _ in entries]
+        exposed = [x.elapsed_time(y) for _, (x, y) in entries]
         for tr, *_ in loads_:
             if hasattr(tr, "comm_events"):
                 tr.comm_events = None
@@ -464,30 +557,38 @@ def main():
         if not math.isfinite(value_):
             raise SystemExit(f"bench.py: the training loss is {value_} after {n_warm + args.steps} iterations -- a timing of a diverged "
                              "run is not a measurement")
-        return dt_, value_, all(getattr(tr, "_captured", None) is not None for tr, *_ in loads_), (sum(comm) / len(comm) if comm else None), step
+        mean = lambda v: sum(v) / len(v) if v else None
+        return dt_, value_, all(getattr(tr, "_captured", None) is not None for tr, *_ in loads_), (mean(comm), mean(exposed)), step
 
-    def over_ranks(dt_, evals_, comm_, loads_):
+    def over_ranks(dt_, evals_, comm_, loads_, check_params=True):
         """max / min over ranks of the timed seconds, sum of the evaluations, max of the all-reduce time; and the ranks' parameters must
         agree after the last step (same reduced gradients, same Adam): a checksum of every flat parameter buffer, min == max"""
         if world == 1:
             return dt_, dt_, float(evals_), comm_
-        check = sum(float(f.double().sum()) for tr, *_ in loads_ for f in tr._flats())
-        t = torch.tensor([dt_, -dt_, comm_ or 0.0, check, -check], device=dev, dtype=torch.float64)
+        check = sum(float(f.double().sum()) for tr, *_ in loads_ for f in tr._flats()) if check_params else 0.0
+        t = torch.tensor([dt_, -dt_, comm_[0] or 0.0, check, -check, comm_[1] or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e = torch.tensor([float(evals_)], device=dev, dtype=torch.float64)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
         if float(t[3]) != -float(t[4]):
             raise SystemExit(f"bench.py: the ranks' parameters disagree after the timed steps (checksum max {float(t[3])!r}, min {-float(t[4])!r})")
-        return float(t[0]), -float(t[1]), float(e[0]), (float(t[2]) if comm_ is not None else None)
+        return float(t[0]), -float(t[1]), float(e[0]), ((float(t[2]) if comm_[0] is not None else None), (float(t[5]) if comm_[1] is not None else None))
 
     # under N > 1 (and no explicit --scaling) BOTH modes are timed, weak first: its numbers are the headline
     modes = [args.scaling or ("strong" if args.shard_of else "weak")]
     if world > 1 and args.scaling is None:
         modes = ["weak", "strong"]
     scaling = modes[0]
-    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on")
+    placement = "replicas" if args.placement == "replicas" and args.config == "cfg4" else "shard"
+    if placement == "replicas":
+        modes = ["strong"]                                   # the total work is the eight scenes, whatever N is
+        scaling = "strong"
+    split = {"auto": "auto", "on": True, "off": False}[args.split_exchange]
+    wl = dict(hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on", llff_root=args.llff_root, split_exchange=split)
+    loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, placement=placement, **wl)
+    data_label = "+".join(build_workloads.data)
     evals_local = n_evals(loads)
-    dt, loss_value, graphed, comm_ms, step = timed_run(loads)
+    dt, loss_value, graphed, comm_ms, step = timed_run(loads) if loads else (0.0, 0.0, False, (None, None), None)
     ms_rank = dt / args.steps * 1e3
     # per-kernel device events: a few more iterations launched STAGE BY STAGE (niw_train_step(stage, stage + 1): events cannot be recorded
     # inside a replayed graph, nor between the stages of one call), on one stream, outside the timed region; same kernels, same shapes.
@@ -528,27 +629,78 @@ def main():
             # a table that does not add up is not evidence: keep the record of the failed check, drop the table
             print(f"bench.py: per-kernel table rejected {kernel_check}", file=sys.stderr, flush=True)
             kern = {}
-    dt, dt_min, evals_total, comm_ms = over_ranks(dt, evals_local, comm_ms, loads)
+    dt, dt_min, evals_total, comm_ms = over_ranks(dt, evals_local, comm_ms, loads, check_params=placement != "replicas")
+    comm_ms, comm_exposed_ms = comm_ms
     rays_per_gpu = sum(int(round(B * R)) for _, _, B, R, _, _ in loads)
     S0, Sf0 = loads[0][4], loads[0][5]
 
     # the other scaling mode, same processes, right after (N > 1): the reference's own batch split over the ranks
     strong = None
     if len(modes) > 1:
-        del step
+        step = None                                   # (releases the closure over the first workload's trainers)
         for tr, *_ in loads:
             if getattr(tr, "fused", None) is not None:
                 tr.fused.ws = None
-        loads2, desc2 = build_workloads(args.config, dev, rank, world, modes[1], 0, hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on")
+        loads2, desc2 = build_workloads(args.config, dev, rank, world, modes[1], 0, **wl)
         e2 = n_evals(loads2)
         dt2, loss2, graphed2, comm2, _ = timed_run(loads2)
         dt2, dt2_min, e2_total, comm2 = over_ranks(dt2, e2, comm2, loads2)
+        comm2, comm2_exposed = comm2
         v2 = e2_total * args.steps / dt2
         strong = dict(scaling=modes[1], ms_per_step=dt2 / args.steps * 1e3, ms_per_step_fastest_rank=dt2_min / args.steps * 1e3, value=v2, unit="ray-samples/s",
                       mlp_evals_per_step_per_gpu=e2, rays_per_gpu=sum(int(round(B * R)) for _, _, B, R, _, _ in loads2),
                       frac_of_train_roofline=round(v2 / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4), comm_ms=None if comm2 is None else round(comm2, 4),
-                      loss=loss2, hip_graph=graphed2, workload=desc2 + f"; the reference's batch split over {world} ranks")
+                      comm_exposed_ms=None if comm2_exposed is None else round(comm2_exposed, 4), loss=loss2, hip_graph=graphed2, workload=desc2 + f"; the reference's batch split over {world} ranks")
         del loads2
+
+    # cfg4: the other placement of the eight scenes, same processes, right after -- scene i WHOLE on rank i mod N, no gradient exchange
+    # ("report both").  Also the line's own figures when --placement replicas was asked for.
+    def scene_table(loads_):
+        """per-scene milliseconds of this rank's scenes (a few fenced iterations of each, launched), gathered over the ranks"""
+        rows = []
+        for tr, var0, B, R, S, Sf in loads_:
+            for _ in range(3):
+                tr.train_iteration(type(var0)(var0))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(5, args.steps)):
+                tr.train_iteration(type(var0)(var0))
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / max(5, args.steps) * 1e3
+            ev = int(round(B * R)) * (S + (S + Sf if Sf else 0))
+            rows.append(dict(scene=getattr(tr, "scene_name", None), rank=rank, views=B, rays=int(round(B * R)), mlp_evals=ev, ms_per_step=round(ms, 4),
+                             frac_of_train_roofline=round(ev / (ms * 1e-3) * 3 * FLOP_FWD / 1e12 / peak_mfma, 4)))
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, rows)
+            rows = [r for part in gathered for r in part]
+        return rows
+
+    replicas = None
+    eff_world = args.shard_of or world
+    if args.config == "cfg4" and (placement == "replicas" or (args.placement == "both" and eff_world > 1)):
+        if placement == "replicas":
+            loads_r, desc_r, timing_r = loads, desc, (dt, dt_min, evals_total, loss_value, graphed)
+        else:
+            step = None
+            for tr, *_ in loads:
+                if getattr(tr, "fused", None) is not None:
+                    tr.fused.ws = None
+            loads_r, desc_r = build_workloads(args.config, dev, rank, world, "strong", args.shard_of, placement="replicas", **wl)
+            e_r = n_evals(loads_r)
+            dt_r, loss_r, graphed_r, comm_r, _ = timed_run(loads_r) if loads_r else (0.0, 0.0, False, (None, None), None)
+            dt_r, dt_r_min, e_r_total, _ = over_ranks(dt_r, e_r, comm_r, loads_r, check_params=False)
+            timing_r = (dt_r, dt_r_min, e_r_total, loss_r, graphed_r)
+        dt_r, dt_r_min, e_r_total, loss_r, graphed_r = timing_r
+        v_r = e_r_total * args.steps / dt_r if dt_r > 0 else 0.0
+        replicas = dict(placement="replicas", ms_per_step=dt_r / args.steps * 1e3, ms_per_step_fastest_rank=dt_r_min / args.steps * 1e3, value=v_r,
+                        unit="ray-samples/s", comm_ms=0, comm_exposed_ms=0, gradient_exchange="none: every scene trains whole on one GPU",
+                        frac_of_train_roofline=round(v_r / eff_world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4) if not args.shard_of else
+                        round(v_r * 3 * FLOP_FWD / 1e12 / peak_mfma, 4),
+                        scenes=scene_table(loads_r), hip_graph=graphed_r, workload=desc_r,
+                        note="a step = one train iteration of every scene this rank holds; ranks holding more scenes (N < 8: scene i on rank i mod N) set the pace")
+        if placement != "replicas":
+            del loads_r
 
     if rank != 0:
         if dist.is_initialized():
@@ -578,7 +730,7 @@ def main():
         # HBM bytes per launch of that kernel: rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE, bytes per
         # sample) times the samples one launch processes; a pointer to the committed measurement, not measured in this run
         traffic = None
-        for fname in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for fname in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     t = json.load(f)["bytes_per_sample"].get(dom)
@@ -634,7 +786,7 @@ def main():
     par = f"ray-shard dp{world}" + (f" ({scaling} scaling)" if world > 1 else "") + (f"; 1/{args.shard_of} shard of the global batch" if args.shard_of else "")
     out = dict(metric="ray-samples/sec (warp+MLP+composite) on LLFF-fern, 1/2/4/8 GPUs + PSNR parity",
                value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32" if exact else args.precision, data="synthetic",
+               ms_per_step=ms_step, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32" if exact else args.precision, data=data_label,
                config=dict(workload=desc, name=args.config, rays_per_gpu=rays_per_gpu,
                            samples_per_ray="+".join(str(x) for x in ((S0, S0 + Sf0) if Sf0 else (S0,))),
                            mlp_evals_per_step_per_gpu=evals_local, parallelism=par,
@@ -644,7 +796,9 @@ def main():
                            "); not the headline, own parity row in tests/test_gpu_fast_precision.py"),
                frac_of_train_roofline=round(value / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4),
                loss=loss_value, hip_graph=graphed, ranks_seen=ranks_seen, backend=dist_backend, warmup_run=n_warm,
-               ms_per_step_fastest_rank=dt_min / args.steps * 1e3, comm_ms=None if comm_ms is None else round(comm_ms, 4), strong=strong,
+               ms_per_step_fastest_rank=dt_min / args.steps * 1e3, comm_ms=None if comm_ms is None else round(comm_ms, 4),
+               comm_exposed_ms=None if comm_exposed_ms is None else round(comm_exposed_ms, 4), strong=strong, placement=placement if args.config == "cfg4" else None,
+               replicas=replicas, capture_fallback=bool(os.environ.get("NIW_CAPTURE_FALLBACK")),
                launches_per_step="one niw_train_step call (25 kernel launches for a single-pass config, 35 with the fine pass) + gradient all-reduce + one Adam launch"
                if getattr(loads[0][0], "fused", None) is not None else "autograd mirror over the per-stage entry points",
                roofline=roofline, kernel_check=kernel_check, kernels=kernels)

@@ -466,6 +466,10 @@ typedef struct niw_train_desc {
      * launch on `stream`, in stage order. */
     int32_t overlap;
     int32_t reserved;
+    /* Optional hipEvent_t (as void*), or NULL: recorded on `stream` right behind the launch that completes d_nerf_fine -- the first
+     * optimizer group whose gradients are final, a third of the way into the backward.  A data-parallel caller makes its communication
+     * stream wait for it and exchanges that group while the coarse network's and the warp's backward are still running (engine.py). */
+    void* fine_grads_ready;
 } niw_train_desc;
 
 /* Optional: create the library's own streams (niw_train_desc.overlap; niw_mlp_bwd_dw's second stream) for the current device NOW instead

@@ -44,7 +44,7 @@ class TrainDesc(ctypes.Structure):
                 ("warp_params", _vp), ("latent", _vp), ("chan_w", _fp), ("index_window", _fp), ("window_dev", _vp),
                 ("w_render", _f), ("w_render_fine", _f), ("w_align", _f), ("always_register", _i32), ("mse_norm", _d),
                 ("loss", _vp), ("d_nerf", _vp), ("d_nerf_fine", _vp), ("d_warp", _vp), ("d_latent", _vp), ("poses", _vp),
-                ("rgb", _vp), ("rgb_fine", _vp), ("overlap", _i32), ("reserved", _i32)]
+                ("rgb", _vp), ("rgb_fine", _vp), ("overlap", _i32), ("reserved", _i32), ("fine_grads_ready", _vp)]
 
 
 # train stages (enum niw_train_stage), in execution order

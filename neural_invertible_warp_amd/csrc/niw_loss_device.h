@@ -11,12 +11,23 @@ namespace niw {
 // 256-thread workgroup must call it; `red` is 16 doubles of LDS; the total is returned to thread 0 (others: unspecified).
 __device__ __forceinline__ double sq_sum_in_mse_order(const float* __restrict__ resid, long long total, double* red) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // four rounds of 1024 elements per trip, all sixteen loads of the thread issued before the first use (the kernel that calls this
+    // closes a chain of small dependent launches: a rolled loop paid one cold read per element and played thread); every accumulator
+    // still takes its elements in ascending order, and an element beyond the end adds +0.0, which changes nothing
+    for (long long base = 0; base < total; base += 4096) {
+        float v[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        for (long long i = threadIdx.x + 256 * j; i < total; i += 1024) {
-            const float diff = resid[i];
-            acc[j] += diff * diff;
-        }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long i = base + 1024 * u + threadIdx.x + 256 * j;
+                v[u][j] = i < total ? resid[i] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[u][j] * v[u][j];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll

@@ -472,6 +472,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         } else if (in(NIW_STAGE_MLP_BWD_DW_FINE)) {
             NIW_RUN(fill(d->d_nerf_fine, NIW_NERF_PARAM_FLOATS, 0.f, st));
         }
+        if (d->fine_grads_ready && in(NIW_STAGE_MLP_BWD_DW_FINE)) NIW_HIP(hipEventRecord((hipEvent_t)d->fine_grads_ready, st), "fine_grads_ready");
     }
     if (loss_c) {
         if (in(NIW_STAGE_COMPOSITE_BWD) && !one_c)

@@ -217,6 +217,7 @@ class FusedStep:
         d.latent, d.d_latent = latent.data_ptr(), tr.bucket.segment(n_nets + 1).data_ptr()
         table = self.pose_table
         d.poses = None if table is None else table.data.data_ptr()
+        d.fine_grads_ready = tr.fine_ready_event()
 
     def _batch_signature(self, var):
         """what the descriptor was built from: the caller's tensors (storage AND content version: the DTU depth range is read to the host
@@ -292,13 +293,20 @@ class FusedStep:
 
 class INNTrainer:
     def __init__(self, opt, n_views, rank=0, world=1, warp_perturb=0.0, seed=0, initial_poses_w2c=None, ray_sampler=None, hip_graph=False,
-                 fused_step="auto", overlap=True):
+                 fused_step="auto", overlap=True, split_exchange="auto", collectives=True):
         """ray_sampler: "feistel" (one sort-free launch, default on the GPU) or "randperm" (the reference's torch.randperm call).
         hip_graph: capture the whole iteration (forward, backward, gradient gather, Adam) into a HIP graph after two eager
         steps and replay it from then on -- one graph launch + one 256-byte constants upload per step instead of ~140 launches;
         needs inputs that stay at the same device addresses from step to step (the engine's resident `var` tensors do).
         fused_step: "auto" (default) runs the iteration as one niw_train_step call (FusedStep) wherever that call covers the
-        configuration and through the autograd mirror elsewhere; True insists (NiwError otherwise); False = always the mirror."""
+        configuration and through the autograd mirror elsewhere; True insists (NiwError otherwise); False = always the mirror.
+        split_exchange (ranks > 1, a fine network present): the gradient exchange as TWO all-reduces -- the fine network's segment,
+        final a third of the way into the backward, on a communication stream while the coarse network's and the warp's backward
+        still run; the rest behind the backward.  "auto": where the iteration is one launched niw_train_step call (the library records
+        an event when the segment is final); True: everywhere (without that event the two calls simply follow the backward); False:
+        one flat all-reduce (rounds 1-4).  Same sums either way.
+        collectives=False: this trainer is a REPLICA (one scene per GPU, bench.py --placement replicas): it never exchanges anything,
+        whatever process group is live."""
         self.opt, self.rank, self.world, self.n_views = opt, rank, world, n_views
         o = opt.optim
         if o.get("algo", "Adam") != "Adam":
@@ -331,8 +339,10 @@ class INNTrainer:
         # optimizer groups = the flat buffers the kernels read (NeRF nets, warp network) + the latent table
         latent = self.warp_latent.weight
         dev = latent.device
+        # (the fine network's segment leads the buffer: it is final first, and head / tail are the two pieces of a split exchange)
         self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets] +
-                                          [list(self.warp_mlp.parameters()), [latent]], dev)
+                                          [list(self.warp_mlp.parameters()), [latent]], dev, first=(1,) if len(self.nets) > 1 else ())
+        self.split_exchange, self.collectives = split_exchange, bool(collectives)
         # the backward kernels write every group's gradient straight into its bucket segment (ops grad_sink): no .grad tensors, no
         # per-parameter accumulation copies, no gather
         self._install_grad_sinks()
@@ -375,7 +385,7 @@ class INNTrainer:
             elif fused_step is True:
                 raise NiwError(f"fused_step=True: niw_train_step does not cover this configuration ({why})")
         self.fused_fallback_reason = None if self.fused is not None else (FusedStep.unsupported(self) if fused_step else "fused_step=False")
-        if world > 1 or parallel.FORCE_COLLECTIVES:      # (a forced one-rank group shards 1-way: same arithmetic, collectives issued)
+        if self.collectives and (world > 1 or parallel.FORCE_COLLECTIVES):      # (a forced one-rank group shards 1-way: same arithmetic, collectives issued)
             opt.ray_shard = (rank, world)
             opt.loss_norm_elements = parallel.global_loss_elements(n_views, opt.nerf.rand_rays // n_views)
 
@@ -460,15 +470,87 @@ class INNTrainer:
         loss.update(all=total)
         torch.autograd.backward([loss[k] for k in keys], [self._loss_w[k][1] for k in keys])
 
+    def _collectives_live(self):
+        return self.collectives and parallel._collectives_live()
+
+    def _overlapped_exchange(self):
+        """the fine network's segment travels while the backward is still running: only where the backward is ONE launched library
+        call that records an event when that segment is final (a captured iteration keeps its eager flat all-reduce between graphs)"""
+        return (self.split_exchange in ("auto", True) and self.fused is not None and not self.hip_graph and self.bucket.n_head > 0 and
+                self._collectives_live() and self.bucket.flat.is_cuda)
+
+    def fine_ready_event(self):
+        """-> raw handle of the event niw_train_step records behind the fine network's weight gradient, or None when no split exchange
+        will wait for it.  (A torch event owns a HIP event only once it has been recorded: it is recorded here, once.)"""
+        if not self._overlapped_exchange():
+            return None
+        if getattr(self, "_fine_ready", None) is None:
+            self._fine_ready = torch.cuda.Event()
+            self._fine_ready.record()
+            self._comm = torch.cuda.Stream()
+        return self._fine_ready.cuda_event
+
     def _all_reduce(self):
-        """the ONE collective of an iteration: in-place sum of the flat gradient bucket over the ranks (no-op without a live group)"""
-        if self.comm_events is None or not parallel._collectives_live():
-            return self.bucket.all_reduce()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        self.bucket.all_reduce()
-        b.record()
-        self.comm_events.append((a, b))
+        """The gradient exchange of an iteration: in-place sums of the flat bucket over the ranks (no-op without a live group) -- one
+        all-reduce, or two with the first one overlapped with the backward (split_exchange).  With `comm_events` a list, device events
+        are appended: ([(begin, end) of every collective], (end of the backward, start of the optimizer) = the exposed part)."""
+        if not self._collectives_live():
+            return
+        import torch.distributed as dist
+        bucket, timing = self.bucket, self.comm_events is not None and self.bucket.flat.is_cuda
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        split = bucket.n_head > 0 and (self.split_exchange is True or self._overlapped_exchange())
+        if not split:
+            a, b = (ev(), ev()) if timing else (None, None)
+            if timing:
+                a.record()
+            bucket.all_reduce()
+            if timing:
+                b.record()
+                self.comm_events.append(([(a, b)], (a, b)))
+            return
+        pairs = []
+        if self._overlapped_exchange() and getattr(self, "_fine_ready", None) is not None:
+            main = torch.cuda.current_stream()
+            self._comm.wait_event(self._fine_ready)              # recorded by niw_train_step behind the fine network's dW reduction
+            with torch.cuda.stream(self._comm):
+                a, b = (ev(), ev()) if timing else (None, None)
+                if timing:
+                    a.record()
+                dist.all_reduce(bucket.head(), op=dist.ReduceOp.SUM)      # (stream-ordered on the communication stream)
+                if timing:
+                    b.record()
+                    pairs.append((a, b))
+            e0 = ev() if timing else None
+            if timing:
+                e0.record()                                      # the main stream has finished the backward here
+            a2, b2 = (ev(), ev()) if timing else (None, None)
+            if timing:
+                a2.record()
+            dist.all_reduce(bucket.tail(), op=dist.ReduceOp.SUM)
+            if timing:
+                b2.record()
+                pairs.append((a2, b2))
+            main.wait_stream(self._comm)
+            if timing:
+                e1 = ev()
+                e1.record()
+                self.comm_events.append((pairs, (e0, e1)))
+            return
+        # split, not overlapped (the autograd mirror, CPU ranks): the same two sums behind the backward
+        e0 = ev() if timing else None
+        if timing:
+            e0.record()
+        for piece in (bucket.head(), bucket.tail()):
+            a, b = (ev(), ev()) if timing else (None, None)
+            if timing:
+                a.record()
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+            if timing:
+                b.record()
+                pairs.append((a, b))
+        if timing:
+            self.comm_events.append((pairs, (e0, pairs[-1][1])))
 
     def _optimizer_step(self, it):
         """torch.optim.Adam's update of every trained group (reference nerf.py:34-38, barf_inn_llff.py:84-104: two optimizers stepped one
@@ -638,7 +720,7 @@ class INNTrainer:
         for n in self.nets:
             if hasattr(n, "set_progress"):
                 n.set_progress(self.it / self.opt.max_iter if self.it else float(n.progress_host or 0.0))
-        if self.world > 1 and collective:
+        if self.world > 1 and collective and self.collectives:
             # per-view pose tables: under ray sharding every rank has refreshed the rows of its own views only
             win = getattr(self.graph, "_last_window", None)
             if self.family == "dtu":

@@ -124,16 +124,29 @@ class GradBucket:
 
     gather() copies every .grad into one contiguous fp32 buffer (missing grads count as zero),
     all_reduce() sums it over ranks in place (no-op for world 1), segment(i) returns the slice of
-    group i for the optimizer."""
+    group i for the optimizer.  `first`: groups laid out at the FRONT of the buffer (default: group order) -- the engine puts the
+    group whose gradients are final earliest there (the fine network's), so that `head()` and `tail()` are the two contiguous
+    pieces of a split exchange: the head travels while the backward of the rest is still running."""
 
-    def __init__(self, groups, device):
+    def __init__(self, groups, device, first=()):
         self.groups = [list(g) for g in groups]
         self.sizes = [sum(p.numel() for p in g) for g in self.groups]
-        self.offsets = [0]
-        for s in self.sizes:
-            self.offsets.append(self.offsets[-1] + s)
-        self.flat = torch.zeros(self.offsets[-1], device=device, dtype=torch.float32)
+        self.order = [i for i in first] + [i for i in range(len(self.groups)) if i not in first]      # memory order of the groups
+        self.starts = [0] * len(self.groups)
+        off = 0
+        for i in self.order:
+            self.starts[i] = off
+            off += self.sizes[i]
+        self.n_head = sum(self.sizes[i] for i in first)
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
         self.sunk = set()      # groups whose backward kernels write their segment directly (ops grad_sink): gather() skips them
+
+    def head(self):
+        """the `first` groups' gradients (empty without any)"""
+        return self.flat[:self.n_head]
+
+    def tail(self):
+        return self.flat[self.n_head:]
 
     def gather(self):
         """One concatenation kernel per group (not one copy per parameter: a step is ~100 tensors)."""
@@ -160,12 +173,12 @@ class GradBucket:
         return self.flat
 
     def segment(self, i):
-        return self.flat[self.offsets[i]:self.offsets[i + 1]]
+        return self.flat[self.starts[i]:self.starts[i] + self.sizes[i]]
 
     def scatter(self):
         """Write the (reduced) bucket back into the .grad tensors (for optimizers that read .grad)."""
-        off = 0
-        for g in self.groups:
+        for i, g in enumerate(self.groups):
+            off = self.starts[i]
             for p in g:
                 n = p.numel()
                 if p.grad is None:

@@ -510,10 +510,15 @@ def global_alignment_loss(grid_cam, center_cam, grid_3D, center_3D) -> Tuple[Ten
 def inn_train_step(nerf_p: Params, warp_p: Params, latent: Tensor, image: Tensor, intr: Tensor,
                    ray_idx: Tensor, u, H: int, W: int, S: int, depth_range, param: str, alpha_ratio: float,
                    nerf_fine_p: Optional[Params] = None, Sf: int = 0, reference_exact: bool = True,
-                   pose_init: Optional[Tensor] = None, ga_weight: Optional[float] = None,
+                   pose_init: Optional[Tensor] = None, ga_weight: Optional[float] = None, reference_cost: bool = False,
                    **mlp_kw) -> Dict[str, Tensor]:
     """G0 (INN variant): Graph.forward(mode="train") + compute_loss,
-    model/nerf_inn_llff.py:493-573 with get_pose of model/barf_inn_llff.py:305-364."""
+    model/nerf_inn_llff.py:493-573 with get_pose of model/barf_inn_llff.py:305-364.
+    reference_cost: also make the un-warped ray grid call the reference makes a FIRST time and discards (nerf_inn_llff.py:519, then again
+    inside get_pose, barf_inn_llff.py:325) -- no effect on any result; the timed CPU baseline (bench.py cpu_baseline) sets it so that the
+    restatement costs what the reference costs (tools/calibrate_oracle.py)."""
+    if reference_cost:
+        unwarped_center_and_grid(H, W, intr, ray_idx, pose_init)
     center_cam, grid_cam = unwarped_center_and_grid(H, W, intr, ray_idx, pose_init)
     ray, center, grid3 = warped_rays(warp_p, latent, center_cam, grid_cam, alpha_ratio, reference_exact)
     out = render_rays(nerf_p, center, ray, u, S, depth_range, param, p_fine=nerf_fine_p, Sf=Sf, **mlp_kw)

@@ -96,3 +96,18 @@ def test_a_failing_rank_without_the_marker_is_not_retried(tmp_path):
     env.update(PYTHONPATH=str(tmp_path), NIW_STUB_OUT=str(out))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lean"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and out.read_text() == "x"
+
+
+def test_replica_placement_deals_every_scene_to_exactly_one_rank():
+    """bench.py --config cfg4 --placement replicas: scene i trains whole on rank i mod N (the reference runs the eight
+    scenes as eight independent processes, scripts/train_llff.sh:1-8)"""
+    import bench
+    from neural_invertible_warp_amd import configs
+    scenes = list(configs.LLFF_TRAIN_VIEWS)
+    assert len(scenes) == 8
+    for world in (1, 2, 4, 8):
+        parts = [bench.scenes_of_rank(scenes, r, world) for r in range(world)]
+        assert sorted(sc for p in parts for sc in p) == sorted(scenes)             # exhaustive, disjoint
+        assert {len(p) for p in parts} == {8 // world}                             # balanced
+    assert [bench.scenes_of_rank(scenes, r, 8) for r in range(8)] == [[sc] for sc in scenes]
+    assert bench.scenes_of_rank(scenes, 0, 8) == ["fern"]                          # the single-GPU proxy `--placement replicas --shard-of 8`

@@ -87,7 +87,7 @@ def test_fused_iteration_of_a_rank_equals_the_mirror_under_ray_sharding(cfg, wor
             assert abs(la[k] - lb[k]) <= 1e-6 * max(abs(la[k]), 1e-6), (rank, k, la[k], lb[k])
         assert torch.equal(ga, gb), (rank, float((ga - gb).abs().max()))
         n_nets = len(ta.nets)
-        lat = gb[tb.bucket.offsets[n_nets + 1]:tb.bucket.offsets[n_nets + 2]].view(-1, 128)
+        lat = gb[tb.bucket.starts[n_nets + 1]:tb.bucket.starts[n_nets + 1] + tb.bucket.sizes[n_nets + 1]].view(-1, 128)
         win = tb.graph._last_window
         assert bool((lat[:win.v0] == 0).all()) and bool((lat[win.v1:] == 0).all()) and float(lat[win.v0:win.v1].abs().max()) > 0
 

@@ -44,7 +44,7 @@ def test_sharded_ranks_sum_to_the_unsharded_step(cfg, B, rays, S, world):
     # every optimizer group: NeRF(s), warp network, latent table.  The embedder's index window is live (alpha = 0.3) and the sums still
     # agree: the warp runs on the whole batch on every rank, so its points keep the indices the reference gives them.
     for i in range(len(ref.bucket.groups)):
-        a, b = total_grad[ref.bucket.offsets[i]:ref.bucket.offsets[i + 1]], ref.bucket.segment(i)
+        a, b = total_grad[ref.bucket.starts[i]:ref.bucket.starts[i] + ref.bucket.sizes[i]], ref.bucket.segment(i)
         assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()), (cfg, i, float((a - b).abs().max() / b.abs().max()))
 
 
@@ -156,3 +156,52 @@ def test_bench_line_under_torchrun_with_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
     assert line["strong"] and line["strong"]["scaling"] == "strong" and line["comm_ms"] is not None
     assert line["kernel_check"] is not None
+
+
+def _bench_line(args, env_extra=None, port=29700, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_split_gradient_exchange_through_rccl_and_between_two_ranks():
+    """round 5: the fine network's gradients are all-reduced on a communication stream while the coarse backward still runs (an event
+    recorded inside niw_train_step releases them).  (i) one rank through RCCL (--force-dist), launched: the line reports the collectives' own
+    time and the exposed part, and trains exactly like the flat exchange; (ii) two gloo ranks on this GPU: same parameters on both ranks
+    (bench.py exits non-zero otherwise) and the same loss as the flat exchange (two ranks: a + b either way)."""
+    common = ["--config", "cfg2", "--lean", "--steps", "3", "--warmup", "16", "--kernel-steps", "0", "--hip-graph", "off"]
+    a = _bench_line(common + ["--force-dist", "--split-exchange", "auto"], port=29711)
+    b = _bench_line(common + ["--force-dist", "--split-exchange", "off"], port=29712)
+    assert a["backend"] == "nccl" and a["ranks_seen"] == 1 and a["comm_ms"] is not None and a["comm_exposed_ms"] is not None
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    small = ["--config", "cfg2", "--lean", "--steps", "2", "--warmup", "16", "--kernel-steps", "0", "--gpus", "2", "--scaling", "strong"]
+    c = _bench_line(small + ["--split-exchange", "auto"], env_extra={"NIW_DIST_BACKEND": "gloo"}, port=29713)
+    d = _bench_line(small + ["--split-exchange", "off"], env_extra={"NIW_DIST_BACKEND": "gloo"}, port=29714)
+    assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["comm_exposed_ms"] is not None
+    assert c["loss"] == d["loss"], (c["loss"], d["loss"])
+
+
+def test_cfg4_line_carries_both_placements_with_two_ranks():
+    """bench.py --gpus 2 --config cfg4: the ray-sharded placement (weak + strong, gradient all-reduce per scene) and, beside it, the
+    scene-replica placement -- scene i whole on rank i mod 2, no exchange, comm_ms 0, every one of the eight scenes listed with its rank
+    (SURVEY section 8(e)(3)).  Two gloo ranks on this one GPU; --placement replicas alone gives the replicas as the headline."""
+    from neural_invertible_warp_amd import configs
+    line = _bench_line(["--gpus", "2", "--config", "cfg4", "--lean", "--steps", "2", "--kernel-steps", "0"], env_extra={"NIW_DIST_BACKEND": "gloo"}, port=29721,
+                       timeout=1500)
+    assert line["placement"] == "shard" and line["strong"] is not None and line["comm_ms"] is not None
+    rep = line["replicas"]
+    assert rep["comm_ms"] == 0 and rep["value"] > 0
+    assert sorted(r["scene"] for r in rep["scenes"]) == sorted(configs.LLFF_TRAIN_VIEWS)
+    assert {r["scene"]: r["rank"] for r in rep["scenes"]} == {sc: i % 2 for i, sc in enumerate(configs.LLFF_TRAIN_VIEWS)}
+    assert all(r["views"] == configs.LLFF_TRAIN_VIEWS[r["scene"]] and r["ms_per_step"] > 0 for r in rep["scenes"])
+    solo = _bench_line(["--config", "cfg4", "--placement", "replicas", "--shard-of", "8", "--lean", "--steps", "5", "--kernel-steps", "0"], port=29722)
+    assert solo["placement"] == "replicas" and [r["scene"] for r in solo["replicas"]["scenes"]] == ["fern"]
+    assert solo["config"]["mlp_evals_per_step_per_gpu"] == 18 * 113 * 128 and solo["replicas"]["comm_ms"] == 0

@@ -279,3 +279,52 @@ def test_checkpoint_and_validate_collectives_pair_up_on_every_rank(tmp_path):
     ck = torch.load(tmp_path / "model.ckpt", weights_only=False)
     assert ck["iter"] == 2 and torch.equal(ck["graph"]["global_rigid.weight"], table)
     assert (tmp_path / "model" / "1.ckpt").exists() and (tmp_path / "model" / "2.ckpt").exists()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: the gradient exchange as two all-reduces (the fine network's segment first -- on the GPU it travels while the rest of the
+# backward runs) must give every rank the same sums as the one flat all-reduce
+# ---------------------------------------------------------------------------------------------
+def _split_worker(rank, world, port, q):
+    from neural_invertible_warp_amd import configs, engine, parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_from_env(backend="gloo")
+    opt = configs.cfg2_nerf_inn_llff_hier(device="cpu")
+    opt.nerf.rand_rays = 5 * 8
+    sums = {}
+    for mode in (False, True, "auto"):
+        tr = engine.INNTrainer(opt, 5, rank=rank, world=world, split_exchange=mode)
+        b = tr.bucket
+        assert b.n_head == b.sizes[1] and b.starts[1] == 0 and b.starts[0] == b.sizes[1]          # the fine network's segment leads the buffer
+        assert b.head().numel() + b.tail().numel() == b.flat.numel() and b.segment(1).data_ptr() == b.head().data_ptr()
+        gen = torch.Generator().manual_seed(100 + rank)
+        b.flat.copy_(torch.randn(b.flat.numel(), generator=gen))
+        tr._all_reduce()
+        sums[mode] = b.flat.clone()
+    # a replica never exchanges, whatever group is live
+    opt = configs.cfg2_nerf_inn_llff_hier(device="cpu")
+    opt.nerf.rand_rays = 5 * 8
+    tr = engine.INNTrainer(opt, 5, rank=0, world=1, collectives=False)
+    tr.bucket.flat.fill_(1.0 + rank)
+    tr._all_reduce()
+    assert float(tr.bucket.flat[0]) == 1.0 + rank and tr.opt.get("ray_shard") is None
+    if rank == 0:
+        q.put([sums[False].numpy(), sums[True].numpy(), sums["auto"].numpy()])
+    dist.destroy_process_group()
+
+
+def test_split_gradient_exchange_equals_the_flat_all_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    flat, split, auto = [torch.from_numpy(a) for a in q.get(timeout=240)]
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert torch.equal(flat, split) and torch.equal(flat, auto)                 # two ranks: a + b either way
+    gen0, gen1 = torch.Generator().manual_seed(100), torch.Generator().manual_seed(101)
+    assert torch.equal(flat, torch.randn(flat.numel(), generator=gen0) + torch.randn(flat.numel(), generator=gen1))
