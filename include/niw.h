@@ -9,7 +9,12 @@
  *   - `stream` is a hipStream_t passed as void* (the caller's current stream);
  *   - return value 0 = success, negative = niw_status; the message of the last failure on
  *     the calling thread is returned by niw_last_error_string(); nothing throws;
- *   - outputs are fully overwritten unless the parameter is documented as "accumulated".
+ *   - outputs are fully overwritten unless the parameter is documented as "accumulated";
+ *   - threads: every entry point may be called from any host thread.  The two that use a library-owned second stream
+ *     (niw_mlp_bwd_dw from 131,072 samples, niw_train_step with overlap) share ONE such stream and its fork / join events per
+ *     device; they hold a per-device lock from the fork to the join, so two threads (or two trainers on different streams) take
+ *     turns through that part of the call rather than re-recording each other's events -- and a call that fails behind the
+ *     fork still joins the stream before it returns (a capture in progress stays valid).
  *
  * Each declaration names the reference interface (file:line in the reference repository)
  * whose arithmetic it replaces.  The Python mirror of the reference's classes lives in

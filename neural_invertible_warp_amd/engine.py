@@ -134,6 +134,13 @@ class FusedStep:
         S = opt.nerf.sample_intvs
         Sf = (opt.nerf.sample_intvs_fine or 0) if opt.nerf.fine_sampling else 0
         dev = var.image.device
+        for k in ("image", "intr"):
+            # the descriptor holds the caller's storage (its address is the batch's identity, _batch_signature): a private contiguous copy
+            # would go stale behind an in-place update of the caller's tensor without anything noticing
+            t = var[k]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise NiwError(f"train_iteration: var.{k} must be a contiguous float32 tensor (got {t.dtype}, contiguous={t.is_contiguous()}); "
+                               "the one-call iteration reads the batch in place")
         image, intr = ops._f32(var.image, "var.image"), ops._f32(var.intr, "var.intr")
         if image.shape[0] != B or image.shape[-1] * image.shape[-2] != opt.H * opt.W:
             raise NiwError(f"train_iteration: var.image is {tuple(image.shape)}, expected [{B},3,{opt.H},{opt.W}]")
@@ -438,6 +445,12 @@ class INNTrainer:
     def _forward_backward(self, var, it):
         opt = self.opt
         if self.fused is not None:
+            # what the one-call form does not cover is decided when the trainer is built; a switch flipped afterwards (density noise, an
+            # opaque background, a plugged-in alignment backend, a network moved to another precision) must not be silently ignored
+            why = FusedStep.unsupported(self)
+            if why is not None:
+                raise NiwError(f"train_iteration: the configuration changed after the trainer was built and niw_train_step does not cover it "
+                               f"any more ({why}); build a new trainer (fused_step='auto' then takes the autograd mirror)")
             return self.fused.run(var, it)
         self._install_grad_sinks()
         self._bind_constants(True)
@@ -570,8 +583,9 @@ class INNTrainer:
 
     def train_iteration(self, var, replay=True):
         """One iteration on the resident batch `var` (idx, image, intr[, pose, depth_range]) -> loss edict.  With hip_graph the
-        returned tensors are the graph's static outputs: read them before the next call.  replay=False runs the iteration
-        launch by launch even when a graph exists (per-kernel timing)."""
+        returned tensors are the graph's static outputs: read them before the next call.  Launched, the one-call iteration returns VIEWS
+        of a 64-row ring of loss rows: a loss stays valid for the next 63 iterations -- clone what is kept longer (windowed logging).
+        replay=False runs the iteration launch by launch even when a graph exists (per-kernel timing)."""
         it = self.it                                   # the reference's self.it during the step (0-based)
         if self.hip_graph:
             loss = self._graph_iteration(var, it, replay)

@@ -430,7 +430,11 @@ def sample_depth_from_pdf(pdf: Tensor, S: int, Sf: int, depth_range: Sequence[fl
     """H1: Graph.sample_depth_from_pdf, model/nerf.py:346-365 (un-normalised pdf, mid-point
     quantiles, bins in the parametrised space)."""
     lo, hi = depth_range
-    cdf = pdf.cumsum(dim=-1)
+    # `pdf.cumsum(dim=-1)` of the reference, as torch's CPU kernel evaluates it for float32: ONE sequential pass that accumulates in double
+    # (at::acc_type<float, false>) and rounds every prefix to float.  Written out so that the oracle is the same function on every device
+    # (torch's GPU cumsum is a parallel fp32 scan: other roundings, other fine sample positions, which the 2^9 pi band then amplifies);
+    # bit-identical to pdf.cumsum on the CPU (tests/test_oracle_golden.py); the HIP kernel follows the same sequential double sum.
+    cdf = pdf.double().cumsum(dim=-1).to(pdf.dtype)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
     g = torch.linspace(0, 1, Sf + 1)                                            # (host linspace, then moved: one table on every device)
     unif = (0.5 * (g[:-1] + g[1:])).to(pdf.device).repeat(*cdf.shape[:-1], 1)

@@ -70,7 +70,7 @@ def psnr_trajectories(dev, steps=25, B=3, H=12, W=16, R=16, S=32, seed=7, precis
     return psnr_gpu, psnr_cpu
 
 
-def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4, seed=0, draw_seed=0, oracle=True, log_every=50, precision="fp32"):
+def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4, seed=0, draw_seed=0, oracle=True, log_every=50, precision="fp32", Sf=0):
     """Long-horizon parity on the demo scene (tools/teacher_student_demo.py: analytic density blobs rendered from perturbed poses,
     training starts from identity poses): `steps` chained iterations of barf_inn_llff WITH the alignment term on
       * the HIP engine (engine.INNTrainer: fused kernels, niw_adam_step), and
@@ -78,13 +78,20 @@ def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4
     from identical weights, with identical pixel draws and stratified draws (numpy stream `draw_seed`).  fp32 trajectories of a
     non-convex optimisation separate chaotically, so the yardstick is the spread between HIP runs that differ ONLY in `draw_seed`.
     -> dict(it=[...], hip=dict(psnr=[...], rel_rot=[...]), oracle=dict(...))   (rel_rot: pairwise relative rotation error in degrees of
-    the poses registered from the step's warped points, against the scene's ground truth)"""
+    the poses registered from the step's warped points, against the scene's ground truth)
+    Sf > 0 (round 5): the cfg2 shape instead -- hierarchical resampling and a FINE network (S coarse + Sf resampled positions, both losses,
+    one Adam over both networks: reference model/nerf.py:34-38, 293-319), no alignment term; `psnr` is then the FINE image's, psnr_coarse
+    the coarse one's."""
     from neural_invertible_warp_amd import camera, configs, engine
     from neural_invertible_warp_amd.util import edict
     from tools.teacher_student_demo import render_teacher
     H, W = size
     B = views
-    opt = configs.cfg3_barf_inn_llff(device=dev, global_alignment=ga)
+    if Sf:
+        opt, ga = configs.cfg2_nerf_inn_llff_hier(device=dev), None
+        opt.nerf.sample_intvs_fine = Sf
+    else:
+        opt = configs.cfg3_barf_inn_llff(device=dev, global_alignment=ga)
     opt.H, opt.W, opt.data.image_size = H, W, [H, W]
     opt.max_iter = steps
     opt.nerf.sample_intvs, opt.nerf.rand_rays = S, R * B
@@ -98,9 +105,10 @@ def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4
     # identical initial weights on both sides: the oracle starts from a copy of the engine's (reference initialisation)
     clone = lambda mod: {k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items() if k != "progress"}
     pc, wp = clone(tr.graph.nerf), clone(tr.graph.warp_mlp)
+    pf = clone(tr.graph.nerf_fine) if Sf else None
     lat = tr.graph.warp_latent.weight.detach().clone().requires_grad_(True)
     o = opt.optim
-    opt_nerf = torch.optim.Adam(list(pc.values()), lr=o.lr)
+    opt_nerf = torch.optim.Adam(list(pc.values()) + (list(pf.values()) if Sf else []), lr=o.lr)
     opt_pose = torch.optim.Adam(list(wp.values()) + [lat], lr=o.lr_pose)
     g_nerf = (o.lr_end / o.lr) ** (1.0 / opt.max_iter)
     g_pose = (o.lr_pose_end / o.lr_pose) ** (1.0 / opt.max_iter)
@@ -116,7 +124,7 @@ def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4
 
     rng = np.random.default_rng(1000 + draw_seed)
     var0 = edict(idx=torch.arange(B), image=image, intr=intr)
-    out = dict(it=[], hip=dict(psnr=[], rel_rot=[]), oracle=dict(psnr=[], rel_rot=[]))
+    out = dict(it=[], hip=dict(psnr=[], rel_rot=[], psnr_coarse=[]), oracle=dict(psnr=[], rel_rot=[], psnr_coarse=[]))
     rand, perm = torch.rand, torch.randperm
     try:
         for it in range(steps):
@@ -129,23 +137,25 @@ def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4
             torch.rand, torch.randperm = rand, perm
             if log:
                 out["it"].append(it)
-                out["hip"]["psnr"].append(psnr(float(loss.render.detach())))
+                out["hip"]["psnr"].append(psnr(float((loss.render_fine if Sf else loss.render).detach())))
+                out["hip"]["psnr_coarse"].append(psnr(float(loss.render.detach())))
                 out["hip"]["rel_rot"].append(rel_rot(var.grid_cam, var.center_cam, var.grid_3D, var.center))
             if not oracle:
                 continue
             prog = it / opt.max_iter
             w3, wv = O.c2f_weights(prog, opt.barf_c2f, 10), O.c2f_weights(prog, opt.barf_c2f, 4)
-            for prm in list(pc.values()) + list(wp.values()) + [lat]:
+            for prm in list(pc.values()) + list(wp.values()) + [lat] + (list(pf.values()) if Sf else []):
                 prm.grad = None
             ref = O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", min(max(it / opt.inn.real_nvp.max_pe_iter, 0), 1),
-                                   ga_weight=ga, w3d=w3, wview=wv)
+                                   nerf_fine_p=pf, Sf=Sf, ga_weight=ga, w3d=w3, wview=wv)
             ref["loss"].backward()
             for grp, lr0, gam in ((opt_nerf, o.lr, g_nerf), (opt_pose, o.lr_pose, g_pose)):
                 grp.param_groups[0]["lr"] = lr0 * gam ** it
                 grp.step()
             if log:
                 cc, gc = O.unwarped_center_and_grid(H, W, intr, ray_idx)
-                out["oracle"]["psnr"].append(psnr(float(ref["loss_render"].detach())))
+                out["oracle"]["psnr"].append(psnr(float(ref["loss_render_fine" if Sf else "loss_render"].detach())))
+                out["oracle"]["psnr_coarse"].append(psnr(float(ref["loss_render"].detach())))
                 out["oracle"]["rel_rot"].append(rel_rot(gc, cc, ref["grid_3D"].detach(), ref["center"].detach()))
     finally:
         torch.rand, torch.randperm = rand, perm

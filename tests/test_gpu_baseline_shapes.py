@@ -12,9 +12,14 @@ fp32 evaluation.  GRADIENTS (round 4) against the oracle evaluated in FLOAT64 on
 function with 29 more bits, ~25 GB of autograd state at cfg2 -- and held to a conditioning bound instead of rounds 1-3's blanket
 2e-2 / 5e-2 against another fp32 evaluation.  The yardstick is the COMPARATOR'S OWN fp32 evaluation (torch's kernels, same inputs)
 against the same float64 gradients: a tensor of the HIP path may deviate from the float64 gradient by max(3 x what torch's fp32 does
-on THAT tensor, 6 x the median of what it does over the tensors of the group) + 2e-4 of the tensor's scale -- i.e. the HIP path must
+on THAT tensor, 3 x the median of what it does over the tensors of the group) + 2e-4 of the tensor's scale -- i.e. the HIP path must
 be as good an fp32 evaluation of these gradients as torch's, tensor by tensor (conditioning differs by 20 x between tensors of one
 network: the first layer sees the 2^9 pi band).  Measured worst / bound and worst HIP / comparator ratios are printed per group.
+Why a group-median branch at all (round 5, profiles/r5_fp64_parity_table.txt): the comparator's deviation on ONE tensor is itself a draw
+of rounding noise.  Round 4 reported cfg2 warp_mlp.lin1_c.weight at 5.45 x torch's own deviation; in this round's run the same tensor
+sits at 1.11 x (2.45e-2 against torch's 2.21e-2) and the largest ratio, 5.47, belongs to the one-element lin0_a_1.bias, where torch
+happened to land within 8e-4 of float64 and the HIP path at 0.43 x the group median: the maximum over 36 tensors of a ratio of two
+noisy numbers.  No tensor of any group lies above 2.7 x its group's median, so the group factor is 3 (round 4: 6).
 Needs a GPU."""
 import numpy as np
 import pytest
@@ -69,7 +74,10 @@ def _dev_params(seed_c, seed_w, seed_l, B, seed_f=None):
     return pc, pf, wp, lat
 
 
-FACTOR_TENSOR, FACTOR_GROUP, FLOOR = 3.0, 6.0, 2e-4
+import os
+
+FACTOR_TENSOR, FACTOR_GROUP, FLOOR = 3.0, float(os.environ.get("NIW_PARITY_FACTOR_GROUP", 3.0)), 2e-4
+TABLE = os.environ.get("NIW_PARITY_TABLE")          # a file: every tensor's row is appended (tools/collect_profiles.sh -> profiles/r5_fp64_parity_table.txt)
 
 
 def _err(g, g64, scale64):
@@ -96,6 +104,13 @@ def _check_group_vs_fp64(name, hip, torch32, grads64, report):
     report.append(f"  {name:<14} {len(keys):3d} tensors | comparator fp32 vs fp64: median {med:.2e} worst {max(cond.values()):.2e} | HIP vs fp64: median "
                   f"{np.median(list(mine.values())):.2e} worst {max(mine.values()):.2e} | worst error / bound {mine[worst] / bound[worst]:.2f} ({worst}: "
                   f"{mine[worst]:.2e} of {bound[worst]:.2e}) | worst HIP / comparator {max(mine[k] / max(cond[k], 1e-12) for k in keys):.2f}")
+    if TABLE:
+        with open(TABLE, "a") as f:
+            f.write(f"# {report[0]} | group {name}: median of the comparator's deviations {med:.3e}\n")
+            f.write(f"# {'tensor':<34} {'elements':>9} {'scale (max |g64|)':>18} {'torch fp32 vs fp64':>19} {'HIP vs fp64':>12} {'HIP / torch':>12} {'HIP / median':>13} {'bound':>10} {'HIP / bound':>12}\n")
+            for k in sorted(keys, key=lambda k: -mine[k] / bound[k]):
+                f.write(f"  {k:<34} {grads64[k].numel():9d} {_scale64(k, grads64):18.3e} {cond[k]:19.3e} {mine[k]:12.3e} {mine[k] / max(cond[k], 1e-30):12.2f} "
+                        f"{mine[k] / max(med, 1e-30):13.2f} {bound[k]:10.3e} {mine[k] / bound[k]:12.2f}\n")
     for k in keys:
         assert mine[k] <= bound[k], f"{name}.{k}: {mine[k]:.3e} of scale from the float64 gradient, bound {bound[k]:.3e} (comparator's own fp32: {cond[k]:.3e})"
     return mine[worst] / bound[worst]

@@ -303,3 +303,26 @@ def test_train_entry_point_on_dataset_files(tmp_path, capsys):
     assert "[val it 2]" in capsys.readouterr().out
     with pytest.raises(FileNotFoundError, match="synthetic_fallback"):
         train.main(["--model=barf_inn_llff", "--yaml=barf_inn_llff", f"--data.root={tmp_path}/nowhere", "--name=x"] + common)
+
+
+def test_bench_reads_a_real_llff_directory_when_one_is_there(tmp_path):
+    """bench.py --llff-root DIR (or NIW_LLFF_ROOT): the scene found there feeds the trainer through data/llff.py -- the parser pinned to
+    the reference's (/root/reference data/llff.py:28-72) -- and the line says `data: llff:fern`; without it the line says `synthetic`.
+    The directory is written by the generator of the reference-pinned fixture: 20 frames (18 train views after the 10 % hold-out, like
+    the public fern), 60 x 80 files declared 3024 x 4032 in poses_bounds.npy, resized to the bench's 300 x 400."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    llff_root = str(tmp_path / "llff")
+    _scene_writer("make_golden_data.py", "N, FH, FW, H, W = 20, 60, 80, 300, 400", "def write_scene")["write_scene"](llff_root)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", "cfg3", "--lean", "--steps", "3", "--kernel-steps", "0"]
+    r = subprocess.run(cmd + ["--llff-root", llff_root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["data"] == "llff:fern" and line["config"]["rays_per_gpu"] == 18 * 113 and line["value"] > 0
+    r = subprocess.run(cmd, cwd=root, env=dict(env, NIW_LLFF_ROOT=str(tmp_path / "nowhere")), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["data"] == "synthetic"
