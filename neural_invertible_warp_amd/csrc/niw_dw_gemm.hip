@@ -938,6 +938,20 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
     return launch_shape<false>(wide, gb, mpad, batches, partial, nsplit_out, st);
 }
 
+// `n` products with operand pairs of their own in ONE launch of the 256 x 256 tile with SKIP (32 x 32 blocks beyond an operand's valid rows
+// issue no MFMAs): the warp backward's two GEMM families over a short reduction (niw_warp.hip) -- [G x E] and [H x head gradients], the
+// second with 4 valid columns -- which as two launches of one round each were 2 x 33 us of a second-stream chain that closes the iteration
+int niw_launch_nt_gemm_pairs(int n, const NiwGemmOperand* A, const NiwGemmOperand* B, const int* bias_side, long long mpad, float* partial,
+                             int* nsplit_out, hipStream_t st) {
+    if (n < 1 || n > kMaxBatch) {
+        niw_set_error("NT GEMM: %d products (1..%d)", n, kMaxBatch);
+        return NIW_ERR_INVALID_ARG;
+    }
+    GemmBatch gb{};
+    for (int b = 0; b < n; ++b) { gb.A[b] = A[b]; gb.B[b] = B[b]; gb.bias_side[b] = bias_side[b]; }
+    return launch_gemm<4, 2, 2, 4, true, 1, false>(gb, mpad, n, partial, nsplit_out, st);
+}
+
 int niw_dw_heads_prepare() { return heads_lane() ? NIW_OK : NIW_ERR_LAUNCH; }
 
 extern "C" int64_t niw_mlp_bwd_workspace_floats(int64_t n_rays, int n_samples) {

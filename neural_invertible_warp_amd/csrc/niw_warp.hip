@@ -18,9 +18,12 @@
 // parameter gradients themselves are then three batched NT GEMMs over the points on the
 // fp32 MFMA path (niw_dw_gemm.hip) -- no atomics, deterministic.
 #include "niw_common.h"
+#include <stdlib.h>
 
 int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long mpad, int batches, float* partial,
                        int bias_side, int* nsplit_out, hipStream_t st);
+int niw_launch_nt_gemm_pairs(int n, const NiwGemmOperand* A, const NiwGemmOperand* B, const int* bias_side, long long mpad, float* partial,
+                             int* nsplit_out, hipStream_t st);
 
 namespace {
 
@@ -462,11 +465,13 @@ __device__ __forceinline__ float sum_tiles(const float* __restrict__ p, long lon
 }
 
 // reduce the partial tiles of the two GEMM families and scatter into d_w_emb / d_view_b / d_w_head
-__global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, const float* __restrict__ p2, int nsplit2,
+// tk2: columns of the second family's tiles -- 64 (its own 256 x 64 launch) or 256 (one launch with the first family, niw_launch_nt_gemm_pairs)
+__global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, const float* __restrict__ p2, int nsplit2, int tk2,
                                    int n_views, float* __restrict__ d_w_emb, float* __restrict__ d_view_b, float* __restrict__ d_w_head) {
     const int b = blockIdx.y;                                   // coupling block
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int T1 = 256 * 256 + 256, T2 = 256 * 64 + 256;
+    constexpr int T1 = 256 * 256 + 256;
+    const int T2 = 256 * tk2 + 256;
     if (idx < 256 * 256) {
         const int r = idx >> 8, c = idx & 255;                  // r: [ga 0..127 | gb 128..255], c: [ea 0..31 | eb 32..63 | views 64..127]
         const int part = r >> 7, u = r & 127;
@@ -480,17 +485,20 @@ __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, co
     } else if (idx < 256 * 256 + 256 * 64 + 256) {
         const int j = idx - 256 * 256;                          // tile 2: [ha 0..127 | hb 128..255] x [d delta, d theta, d t0, d t1, ...]
         float* dst = nullptr;
+        int at = 0;                                              // element of the (256 x tk2 + 256)-float tile
         if (j < 256 * 64) {
             const int r = j >> 6, c = j & 63, u = r & 127;
             if (r < 128 && c == 0) dst = d_w_head + b * kHeadBlock + u;
             else if (r >= 128 && c >= 1 && c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + (c - 1) * kHid + u;
+            at = r * tk2 + c;
         } else {
             const int c = j - 256 * 64;                         // row sums of the head gradients = bias gradients
             if (c == 0) dst = d_w_head + b * kHeadBlock + kHid;
             else if (c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + 3 * kHid + (c - 1);
+            at = 256 * tk2 + c;
         }
         if (!dst) return;
-        *dst = sum_tiles(p2 + (long long)b * nsplit2 * T2 + j, T2, nsplit2);
+        *dst = sum_tiles(p2 + (long long)b * nsplit2 * T2 + at, T2, nsplit2);
     }
 }
 
@@ -584,14 +592,34 @@ int niw_launch_warp_bwd_main(const float* w_emb, const float* view_b, const floa
     float* p1 = workspace + 3ll * kRowsPerBlock * ppad;
     float* p2 = p1 + 3ll * 256 * (256 * 256 + 256);
     const long long stride = (long long)kRowsPerBlock * ppad;
-    int ns1 = 0, ns2 = 0;
-    rc = niw_launch_nt_gemm(1, NiwGemmOperand{workspace + kRowGa * ppad, 256, stride, ppad},
-                            NiwGemmOperand{workspace + kRowEa * ppad, 128, stride, ppad}, ppad, 3, p1, 0, &ns1, st);
-    if (rc != NIW_OK) return rc;
-    rc = niw_launch_nt_gemm(0, NiwGemmOperand{workspace + kRowHa * ppad, 256, stride, ppad},
-                            NiwGemmOperand{workspace + kRowGo * ppad, 4, stride, ppad}, ppad, 3, p2, 2, &ns2, st);
-    if (rc != NIW_OK) return rc;
-    warp_reduce_kernel<<<dim3((256 * 256 + 256 * 64 + 256 + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, n_views, d_w_emb, d_view_b, d_w_head);
+    int ns1 = 0, ns2 = 0, tk2 = 64;
+    // up to 2048 points (a rank's window of views): both GEMM families as ONE launch of six products (NIW_WARP_GEMM_PAIRS=<max slices of 32
+    // points>, 0 = never: diagnostic) -- the chain of small launches behind the warp backward closes the iteration of a 1/8 share
+    static const long long pairs_max = [] { const char* e = getenv("NIW_WARP_GEMM_PAIRS"); return e ? atoll(e) : 64ll; }();
+    if (ppad / 32 <= pairs_max) {
+        NiwGemmOperand A[6], B[6];
+        int bias[6];
+        for (int b = 0; b < 3; ++b) {
+            A[b] = NiwGemmOperand{workspace + kRowGa * ppad + b * stride, 256, 0, ppad};
+            B[b] = NiwGemmOperand{workspace + kRowEa * ppad + b * stride, 128, 0, ppad};
+            bias[b] = 0;
+            A[3 + b] = NiwGemmOperand{workspace + kRowHa * ppad + b * stride, 256, 0, ppad};
+            B[3 + b] = NiwGemmOperand{workspace + kRowGo * ppad + b * stride, 4, 0, ppad};
+            bias[3 + b] = 2;
+        }
+        rc = niw_launch_nt_gemm_pairs(6, A, B, bias, ppad, p1, &ns1, st);
+        if (rc != NIW_OK) return rc;
+        ns2 = ns1; tk2 = 256;
+        p2 = p1 + 3ll * ns1 * (256 * 256 + 256);          // (six products x <= 42 ranges: inside the first family's 3 x 256 tiles)
+    } else {
+        rc = niw_launch_nt_gemm(1, NiwGemmOperand{workspace + kRowGa * ppad, 256, stride, ppad},
+                                NiwGemmOperand{workspace + kRowEa * ppad, 128, stride, ppad}, ppad, 3, p1, 0, &ns1, st);
+        if (rc != NIW_OK) return rc;
+        rc = niw_launch_nt_gemm(0, NiwGemmOperand{workspace + kRowHa * ppad, 256, stride, ppad},
+                                NiwGemmOperand{workspace + kRowGo * ppad, 4, stride, ppad}, ppad, 3, p2, 2, &ns2, st);
+        if (rc != NIW_OK) return rc;
+    }
+    warp_reduce_kernel<<<dim3((256 * 256 + 256 * 64 + 256 + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, tk2, n_views, d_w_emb, d_view_b, d_w_head);
     NIW_LAUNCH_CHECK("niw_warp_bwd (reduce)");
     return NIW_OK;
 }

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Refresh the rocprofv3 evidence under profiles/ in one go (run on the GPU box from the repo root):
-#   bash tools/collect_profiles.sh r4        -> gpurun_out/profiles_r4/*  (copy what should be judged into profiles/)
+#   bash tools/collect_profiles.sh r5        -> gpurun_out/profiles_r5/*  (copy what should be judged into profiles/)
 # Kernel-trace statistics per config, the three PMC passes over the MLP kernels (separate runs, --kernel-trace only beside --pmc),
 # the two composite traffic passes, and the un-profiled microbenchmarks.  The profiled program itself follows `--`.
 set -u
-tag=${1:-r4}
+tag=${1:-r5}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$tag
 mkdir -p $OUT
