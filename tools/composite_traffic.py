@@ -20,7 +20,7 @@ import sys
 def per_kernel(path):
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(composite_(?:fwd|bwd)(?:_scalar)?_kernel(?:<\d+(?:, \w+)?>)?)", r["Kernel_Name"])
+        m = re.search(r"(composite_(?:fwd|bwd)(?:_scalar|_span)?_kernel(?:<\d+(?:, \w+)*>)?)", r["Kernel_Name"])
         if not m:
             continue
         a = agg[(m.group(1), int(r["Grid_Size"]))]
@@ -38,8 +38,9 @@ def main(out_dir, dest):
             continue
         _, wb, wt = write[(name, grid)]
         G = int(re.search(r"<(\d+)", name).group(1)) if "<" in name else 64
-        # grid = 256 threads x blocks, 4*(64/G) rays per block; the bench's full-image sizes are 120,000 rays x {64,128,192}
-        S = {16: 64, 32: 128, 64: 192}.get(G)
+        # the bench's full-image sizes are 120,000 rays x {64, 128, 192}: span kernels (round 5) carry the quads per lane Q = S / 64 as their
+        # first template argument, the one-quad kernels of rounds 2-4 the lanes per ray G = S / 4 rounded up to a power of two
+        S = 64 * G if "_span" in name else {16: 64, 32: 128, 64: 192}.get(G)
         N = 120000
         bwd = "bwd" in name
         algo_read = N * S * 20 + N * (24 if bwd else 12)
