@@ -715,6 +715,8 @@ def main():
             entry["tflops"] = units * FLOP_FWD / (ms * 1e-3) / 1e12          # dX chain and dW (incl. its reduce kernels): the forward's MAC count each
         elif name == "composite_fwd":
             entry["gbps"] = units * 24.2 / (ms * 1e-3) / 1e9                  # 20 B/sample in + 4 B/sample prob + 32 B/ray
+        elif name == "composite_train":
+            entry["gbps"] = units * 40.3 / (ms * 1e-3) / 1e9                  # one launch: 20 B in, 4 B prob + 16 B gradients out per sample, 68 B per ray
         elif name == "composite_bwd":
             entry["gbps"] = units * 36.2 / (ms * 1e-3) / 1e9                  # 20 B in, 16 B out per sample
         kernels[name] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in entry.items()}

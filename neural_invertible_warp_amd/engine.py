@@ -275,9 +275,22 @@ class FusedStep:
                      "mlp_fwd_fine": n * (S + Sf), "mlp_bwd_dx_fine": n * (S + Sf), "mlp_bwd_dw_fine": n * (S + Sf), "composite_fwd_fine": n * (S + Sf),
                      "composite_bwd_fine": n * (S + Sf)}
             alias = {"mlp_fwd": "mlp_fwd_train", "mlp_fwd_fine": "mlp_fwd_train"}
+            # passes whose compositing, photometric residual and their backward are ONE launch (niw_composite_mse_train, csrc/niw_step.hip:
+            # the span kernels cover the sample count and the pass has a loss): the launch sits in the composite_fwd stage, the pass's
+            # composite_bwd stage is empty
+            import os
+            one = os.environ.get("NIW_TRAIN_ONE_LAUNCH_LOSS", "1") != "0"
+            fused_pass = {"": one and d.w_render >= 0 and S % 4 == 0 and S <= 256,
+                          "_fine": one and Sf > 0 and d.w_render_fine >= 0 and (S + Sf) % 4 == 0 and S + Sf <= 256}
             for k, name in enumerate(_lib_mod.TRAIN_STAGES):
                 if name.endswith("_fine") and not Sf or name == "resample" and not Sf:
                     continue
+                suffix = "_fine" if name.endswith("_fine") else ""
+                if name.startswith("composite_bwd") and fused_pass[suffix]:
+                    _lib_mod.call("niw_train_step", ctypes.byref(d), ops._p(self.ws), k, k + 1, st)      # (launches nothing)
+                    continue
+                if name.startswith("composite_fwd") and fused_pass[suffix]:
+                    alias[name] = "composite_train"
                 base = name[:-5] if name.endswith("_fine") else name
                 with ops.timed(alias.get(name, base), units.get(name, n)):
                     _lib_mod.call("niw_train_step", ctypes.byref(d), ops._p(self.ws), k, k + 1, st)
