@@ -87,9 +87,9 @@ def test_sampling_mid_points_when_not_stratified():
     close(d, O.sample_depth(0.5, 8, (2, 6), "metric")[0, :1, :, 0].expand(3, 8), atol=1e-6)
 
 
-# 65..256 samples: 16 lanes per ray with 2 / 3 / 4 quads per lane (round 5); 68, 100, 132, 196, 252 leave a lane's later quads or whole lanes
-# empty, 256 fills four quads, 260 / 320 are the first sizes back on the 64-lane chunked form
-@pytest.mark.parametrize("S", [16, 64, 68, 100, 128, 132, 192, 196, 200, 252, 256, 260, 320])
+# up to 256 samples: 16 lanes per ray with 1 .. 4 quads per lane (round 5); 4, 8, 36, 68, 100, 132, 196, 252 leave a lane's later quads or whole
+# lanes empty, 256 fills four quads, 260 / 320 are the first sizes on the 64-lane chunked form
+@pytest.mark.parametrize("S", [4, 8, 16, 36, 64, 68, 100, 128, 132, 192, 196, 200, 252, 256, 260, 320])
 def test_composite_vs_oracle(S):
     from neural_invertible_warp_amd import ops
     rng = np.random.default_rng(S)
