@@ -104,9 +104,12 @@ def test_fused_iteration_stage_by_stage_equals_the_single_call():
         ops.TIMING.enabled = False
     table = ops.TIMING.summary()
     assert la == lb and torch.equal(a.bucket.flat, b.bucket.flat)
-    for name in ("mlp_fwd_train", "mlp_bwd_dx", "mlp_bwd_dw", "composite_fwd", "composite_bwd", "front", "warp_fwd", "warp_bwd", "loss", "adam"):
+    # (round 5: compositing + photometric residual + their backward are ONE launch per pass -- its stage is listed as composite_train and the
+    # pass's composite_bwd stage, which launches nothing, is not listed)
+    for name in ("mlp_fwd_train", "mlp_bwd_dx", "mlp_bwd_dw", "composite_train", "front", "warp_fwd", "warp_bwd", "loss", "adam"):
         assert name in table and table[name][1] > 0, name
-    assert table["mlp_fwd_train"][0] == 6 and table["resample"][0] == 3          # coarse + fine per step
+    assert "composite_bwd" not in table and "composite_fwd" not in table
+    assert table["mlp_fwd_train"][0] == 6 and table["resample"][0] == 3 and table["composite_train"][0] == 6          # coarse + fine per step
 
 
 @pytest.mark.parametrize("cfg", ["cfg2_nerf_inn_llff_hier", "dtu"])
