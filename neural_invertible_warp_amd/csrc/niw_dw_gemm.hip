@@ -897,7 +897,9 @@ int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, 
 int launch_wide_quadrants(const GemmBatch& batch, int n_sets, long long mpad, float* partial, int* nsplit_out, hipStream_t st) {
     constexpr int WN = 4, WK = 2, NBW = 1, KBW = 2, TN = 128, TK = 128;
     const int steps_total = (int)(mpad / 32);
-    int nsplit = 64 / n_sets;                                  // 7 products: 9 ranges -> 63 groups, padded to 64
+    // (NIW_DW_QUAD_GROUPS: diagnostic -- groups of four tiles per launch; 64 = one workgroup per CU, 128 = two co-resident ones)
+    static const int quad_groups = [] { const char* e = getenv("NIW_DW_QUAD_GROUPS"); const int v = e ? atoi(e) : 64; return v < 8 ? 8 : v; }();
+    int nsplit = quad_groups / n_sets;                         // 7 products: 9 ranges -> 63 groups, padded to 64
     if (nsplit > (steps_total + 1) / 2) nsplit = (steps_total + 1) / 2;
     if (nsplit < 1) nsplit = 1;
     const int per = (steps_total + nsplit - 1) / nsplit;
