@@ -37,6 +37,12 @@ int niw_launch_nt_gemm(int wide, NiwGemmOperand A, NiwGemmOperand B, long long m
 namespace {
 
 constexpr int kLdsStride = 36;   // 32 samples + 4 pad floats per row
+#ifndef NIW_DW_LOAD_AUX
+// cache policy of the operand loads of the exact-fp32 NT GEMM: 2 = non-temporal.  Every slice of `save` / `gradws` is read once per product,
+// 512 contiguous bytes per half wave (whole lines), and the skinny launch is HBM-bound: dW group 6070 -> 6047 us at 785 k samples, 2106 ->
+// 2088 at 260 k, level at 32 k (round 5; 0 = default policy)
+#define NIW_DW_LOAD_AUX 2
+#endif
 #ifndef NIW_DW_SUMS_KB
 #define NIW_DW_SUMS_KB 0
 #endif
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
         for (int k = 0; k < LOADS; ++k) {
             const bool isA = k * GROUP < TN;
             const int g = isA ? k * GROUP : k * GROUP - TN;                 // first row of this load's row group
-            stage[slot][k] = isA ? buf_load4(rsA, voffA, step * STEP_BYTES + g * strideA4) : buf_load4(rsB, voffB, step * STEP_BYTES + g * strideB4);
+            stage[slot][k] = isA ? buf_load4_aux<NIW_DW_LOAD_AUX>(rsA, voffA, step * STEP_BYTES + g * strideA4)
+                                 : buf_load4_aux<NIW_DW_LOAD_AUX>(rsB, voffB, step * STEP_BYTES + g * strideB4);
         }
     };
     auto lstore = [&](int buf, int slot) {

@@ -33,6 +33,10 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
+template <int AUX>
+__device__ __forceinline__ f32x4 buf_load4_aux(rsrc_t r, int voff, int soff) {      // AUX: cache policy (2 = nt: touched once, whole lines)
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
 __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
