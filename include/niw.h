@@ -11,7 +11,7 @@
  *     the calling thread is returned by niw_last_error_string(); nothing throws;
  *   - outputs are fully overwritten unless the parameter is documented as "accumulated";
  *   - threads: every entry point may be called from any host thread.  The two that use a library-owned second stream
- *     (niw_mlp_bwd_dw from 131,072 samples, niw_train_step with overlap) share ONE such stream and its fork / join events per
+ *     (niw_mlp_bwd_dw from 96,000 samples, niw_train_step with overlap) share ONE such stream and its fork / join events per
  *     device; they hold a per-device lock from the fork to the join, so two threads (or two trainers on different streams) take
  *     turns through that part of the call rather than re-recording each other's events -- and a call that fails behind the
  *     fork still joins the stream before it returns (a capture in progress stays valid).
@@ -126,7 +126,7 @@ int niw_mlp_bwd(const float* packed, const float* center, const float* ray,
 
 /* The two passes of niw_mlp_bwd as separate entry points (niw_mlp_bwd = dx then dw):
  *   niw_mlp_bwd_dx: the register-chained dX chain; writes every dY into gradws, then d_center / d_ray (a second, small launch);
- *   niw_mlp_bwd_dw: dW = dY . X^T (split-M NT GEMMs on the fp32 MFMA path) + deterministic reduction.  In exact mode from 131,072
+ *   niw_mlp_bwd_dw: dW = dY . X^T (split-M NT GEMMs on the fp32 MFMA path) + deterministic reduction.  In exact mode from 96,000
  *     samples its two matrix-vector pieces (density row, colour rows) run on a library-owned second stream, forked from and joined to
  *     `stream` by events inside the call (capturable; the stream is created at the first such call or by niw_train_step_prepare(),
  *     which must therefore come before a stream capture that contains the call).  `stream`-ordered like every other entry point. */

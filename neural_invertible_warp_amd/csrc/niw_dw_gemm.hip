@@ -897,7 +897,7 @@ int launch_shape(int wide, const GemmBatch& batch, long long mpad, int batches, 
                 : launch_gemm<8, 1, 1, 2, true, NIW_DW_PF_SKINNY, QUAD, TERMS>(batch, mpad, batches, partial, nsplit_out, st);
 }
 
-// The seven 256 x 256 products of a network over a SHORT reduction (<= 131 k samples: a rank's 1/8 share), as 7 x 4 quadrant tiles of
+// The seven 256 x 256 products of a network over a SHORT reduction (<= 32 k samples: a rank's 1/8 share), as 7 x 4 quadrant tiles of
 // 128 x 128 in ONE round of workgroups: 9 sample ranges per tile instead of 36 per product, i.e. a quarter of the partial-tile bytes
 // (16.5 MB instead of 66 MB at 32 k samples, which the reducer then re-reads), while the four tiles of a product and sample range sit on
 // one XCD (BlockMap) and share the operand rows they all read through its L2.
@@ -995,8 +995,8 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     // dW pieces.  Non-transposed: tile rows = dY rows (gradws), tile columns = X slots (save).
     // Transposed (skinny dY: the density row, the 3 colour rows): tile rows = X slots, columns = dY rows.
     // Launches per network: [layers 1..7: seven 256 x 256 products] [256 x 64 pieces: the encoding columns of layers 0 and 4 -- in the
-    // fast-precision modes and below 131 k samples also the density row and the colour rows] [the colour layer, 128 x 288 in a 128 x 320
-    // tile] [one reduction of all partial-tile sets]; from 131 k samples in exact mode the density row and the colour rows are
+    // fast-precision modes and below 96 k samples also the density row and the colour rows] [the colour layer, 128 x 288 in a 128 x 320
+    // tile] [one reduction of all partial-tile sets]; from 96 k samples in exact mode the density row and the colour rows are
     // dw_heads_kernel's, on a second stream beside the first launch.  (Tried: the density row as a 257th row of layer 7's product,
     // formed on the vector ALU from the staged h6 slice -- the skinny launch lost 75 us of 506 at 523 k samples, but the wide kernel paid
     // 80 us for the mere presence of the code and 50 more for running it; as an MFMA row block of that product: HISTORY.md.)
@@ -1017,10 +1017,11 @@ extern "C" int niw_mlp_bwd_dw(const float* save, const float* gradws, int64_t n_
     const Piece colour[1] = {{8, kGradRgb0, 128, kSaveFeat, 288, 0, 0, 0, 1, 2}};   // feat rows and the 32 view-slot rows are contiguous
     // exact mode: the density row and the colour rows leave the skinny launch for dw_heads_kernel on a second stream (NIW_DW_HEADS=0: the
     // four-piece skinny launch as in the fast-precision modes, whose workspaces are bf16 images; =1: heads kernel on the caller's stream)
-    // from 131 k samples (NIW_DW_HEADS_MIN slices of 32): below, fork + join cost more than the two pieces (cfg3 1/8 share, 65 k samples:
-    // 1.02 ms with the heads kernel, 0.99 without)
+    // from 96,000 samples (NIW_DW_HEADS_MIN slices of 32; rounds 4: 131,072): below, fork + join cost more than the two pieces.  Measured in
+    // round 5: 129 k samples 1121 -> 1067 us for the group; 98 k (the fine pass of a rank's 1/8 share of cfg2) level stand-alone and
+    // the share's step 3.368 -> 3.337 ms; at 32 k the step is 0.6 % SLOWER with the heads kernel (0.944 vs 0.938 ms)
     static const int heads_mode = [] { const char* e = getenv("NIW_DW_HEADS"); return e ? atoi(e) : 2; }();
-    static const long long heads_min = [] { const char* e = getenv("NIW_DW_HEADS_MIN"); return e ? atoll(e) : 4096ll; }();
+    static const long long heads_min = [] { const char* e = getenv("NIW_DW_HEADS_MIN"); return e ? atoll(e) : 3000ll; }();
     const bool heads = precision == NIW_PREC_FP32 && heads_mode > 0 && mpad / 32 >= heads_min;
     struct Group { const Piece* p; int n, wide, TN, TK; };
     const Group groups[3] = {{wide, 7, 1, 256, 256}, {skinny, heads ? 2 : 4, 0, 256, 64}, {colour, 1, 2, 128, kColourTK}};

@@ -410,13 +410,13 @@ def test_ray_split_node_matches_plain_autograd():
         close(a.grad, b.grad, atol=1e-7)
 
 
-@pytest.mark.parametrize("N,S", [(1024, 128), (1025, 128), (1023, 128), (1101, 120)])
+@pytest.mark.parametrize("N,S", [(750, 128), (751, 128), (749, 128), (1101, 120)])
 def test_weight_gradient_is_the_same_on_both_sides_of_the_heads_threshold(N, S):
-    """niw_mlp_bwd_dw forms the density row and the colour rows in dw_heads_kernel (vector ALU, second stream) from 131,072 samples and as two
-    pieces of the skinny MFMA launch below.  The same rays evaluated in ONE call (N x 128 samples: 131,072 at N = 1024 -- the first size on
-    the heads path -- 131,200 with a ragged last chunk, 130,944 just below the threshold, and 1101 x 120 = 132,120 samples, which the
-    workspaces pad to 132,224: the kernel reads the padding columns too) and as two half batches (always below) must give the same
-    parameter gradients up to the order of an fp32 sum over the samples."""
+    """niw_mlp_bwd_dw forms the density row and the colour rows in dw_heads_kernel (vector ALU, second stream) from 96,000 samples (round 5;
+    131,072 in round 4) and as two pieces of the skinny MFMA launch below.  The same rays evaluated in ONE call (N x 128 samples: 96,000 at
+    N = 750 -- the first size on the heads path -- 96,128 with a ragged last chunk, 95,872 just below the threshold, and 1101 x 120 =
+    132,120 samples, which the workspaces pad to 132,224: the kernel reads the padding columns too) and as two half batches (always below)
+    must give the same parameter gradients up to the order of an fp32 sum over the samples."""
     from neural_invertible_warp_amd import ops
     rng = np.random.default_rng(N)
     center, ray = g(t(rng.uniform(-1, 1, (N, 3)))), g(t(rng.standard_normal((N, 3))))
