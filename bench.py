@@ -106,7 +106,7 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False, budget_s=45.0):
     per_ray = S + (S + Sf if Sf else 0)
     t_begin = time.perf_counter()
     # 1. thread count: a short step at every candidate, best of two after a warm-up
-    R_small = max(2, 288 // B)
+    R_small = min(max(2, 288 // B), H * W)
     sweep = {}
     for n in sorted({min(n, affinity) for n in (8, 16, 32, 64)}):          # (all 256 hardware threads of a GPU box: 80 s per step, 90 x the best)
         torch.set_num_threads(n)
@@ -122,7 +122,7 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False, budget_s=45.0):
     R_full = None
     est = sweep[threads] / (B * R_small * per_ray)                    # seconds per evaluation at the short step (an over-estimate)
     R_half = max(R_small, 2048 // B)
-    rays_of_batch = 4096 // B if Sf and not vanilla else 2048 // B if not vanilla else 1024 // B
+    rays_of_batch = min(H * W, 4096 // B if Sf and not vanilla else 2048 // B if not vanilla else 1024 // B)
     R = rays_of_batch if est * B * rays_of_batch * per_ray * 3 < budget_s else min(R_half, rays_of_batch)
     while R > R_small and est * B * R * per_ray * 3 > 2 * budget_s:
         R = max(R_small, R // 2)

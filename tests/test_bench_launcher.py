@@ -111,3 +111,15 @@ def test_replica_placement_deals_every_scene_to_exactly_one_rank():
         assert {len(p) for p in parts} == {8 // world}                             # balanced
     assert [bench.scenes_of_rank(scenes, r, 8) for r in range(8)] == [[sc] for sc in scenes]
     assert bench.scenes_of_rank(scenes, 0, 8) == ["fern"]                          # the single-GPU proxy `--placement replicas --shard-of 8`
+
+
+def test_cpu_baseline_reports_threads_sample_and_calibration():
+    """bench.py's cpu_baseline leg (the oracle timed on the host cores) on a toy shape: it must say how many cores the process may use,
+    which thread count it chose from its sweep, what the sample was, and carry the build container's oracle / reference calibration"""
+    import bench
+    out = bench.cpu_baseline(B=3, S=8, Sf=8, H=12, W=16, budget_s=5.0)
+    assert out["kind"] == "port" and out["unit"] == "ray-samples/s" and out["value"] > 0
+    assert out["cores"] in {int(k) for k in out["thread_sweep"]} and out["affinity_cores"] >= 1
+    assert "3 views x" in out["sample"] and len(out["seconds_per_step"]) == 2
+    assert 0.9 <= out["calibration"]["oracle_over_reference_time"] <= 1.1            # BASELINE.md section 4: the port times within 10 % of the reference
+    assert "r5_oracle_calibration.json" in out["calibration"]["source"]
