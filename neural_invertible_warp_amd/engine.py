@@ -501,9 +501,18 @@ class INNTrainer:
 
     def _overlapped_exchange(self):
         """the fine network's segment travels while the backward is still running: only where the backward is ONE launched library
-        call that records an event when that segment is final (a captured iteration keeps its eager flat all-reduce between graphs)"""
-        return (self.split_exchange in ("auto", True) and self.fused is not None and not self.hip_graph and self.bucket.n_head > 0 and
-                self._collectives_live() and self.bucket.flat.is_cuda)
+        call that records an event when that segment is final (a captured iteration keeps its eager flat all-reduce between graphs).
+        "auto" also asks that the rank's field launches span at least two rounds of workgroups (>= 65,536 samples in the coarse pass): a
+        collective's kernel that holds a few CUs while a ONE-round launch is dispatched makes that launch double up on the remaining CUs
+        (measured with the library's own side kernels, HISTORY.md round 5: 431 us instead of 239) -- at a 1/8 share of the reference's
+        batch the exchange therefore stays behind the backward, at the weak-scaled sizes it travels beside it.  True forces it."""
+        if not (self.split_exchange in ("auto", True) and self.fused is not None and not self.hip_graph and self.bucket.n_head > 0 and
+                self._collectives_live() and self.bucket.flat.is_cuda):
+            return False
+        if self.split_exchange is True:
+            return True
+        shape = getattr(self.fused, "shape", None)
+        return shape is None or shape[4] * shape[2] >= 65536          # rays of the share x coarse samples per ray
 
     def fine_ready_event(self):
         """-> raw handle of the event niw_train_step records behind the fine network's weight gradient, or None when no split exchange
