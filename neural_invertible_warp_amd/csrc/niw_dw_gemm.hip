@@ -592,11 +592,24 @@ struct ReduceBatch {
 __device__ __forceinline__ float sum_partials(const float* __restrict__ p, long long stride, int n) {
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int w = 0;
-    for (; w + 8 <= n; w += 8) {
+    // sixteen loads in flight per trip (the nine partial tiles of a short reduction: one round trip, not two); same order of additions
+    // as the eight-at-a-time loop of rounds 1-4: whole groups of eight to the eight accumulators, a remainder to s[0]
+    for (; w + 16 <= n; w += 16) {
+        float x[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += p[(long long)(w + k) * stride];
+        for (int k = 0; k < 16; ++k) x[k] = p[(long long)(w + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k & 7] += x[k];
     }
-    for (; w < n; ++w) s[0] += p[(long long)w * stride];
+    if (w < n) {
+        float x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = w + k < n ? p[(long long)(w + k) * stride] : 0.f;
+        const int full = (n - w) & ~7;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (w + k < n) { if (k < full) s[k & 7] += x[k]; else s[0] += x[k]; }
+    }
     return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 

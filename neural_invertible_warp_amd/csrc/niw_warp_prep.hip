@@ -150,34 +150,60 @@ __global__ __launch_bounds__(256) void warp_prep_bwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < B * kLat; i += blockDim.x) cb[i] = codeb[(long long)c.b * B * kLat + i];
     __syncthreads();
     const float* dvb = d_view_b + (c.b * 2 + c.part) * kHid;             // + v * 3*2*128 + u
+    // the four rows of the wave side by side (like the forward): every global load of the wave is in flight before the first butterfly --
+    // row after row, each row waited for its own loads and the kernel, which sits on the chain of small launches that ends a rank's
+    // iteration, took 13-15 us for 154 k multiply-adds.  Same sums in the same order.
     float sr[kRowsPerWave], y0r[kRowsPerWave], y1r[kRowsPerWave];
+    float e[kRowsPerWave], de[kRowsPerWave], gq[kRowsPerWave], dwl0[kRowsPerWave], dwl1[kRowsPerWave], db[kRowsPerWave];
 #pragma unroll
     for (int r = 0; r < kRowsPerWave; ++r) {
         const int u = c.u0 + r;
-        // latent half of dW:  dwl[k] = sum_v d_view_b[v][u] * code_b[v][k]
-        float dwl0 = 0.f, dwl1 = 0.f, db = 0.f;
-        for (int v = 0; v < B; ++v) {
-            const float t = dvb[v * 6 * kHid + u];
-            dwl0 += t * cb[v * kLat + lane];
-            dwl1 += t * cb[v * kLat + 64 + lane];
-            db += t;
-        }
         const float* vrow = P + l.v + u * l.K;
         const float* dwe = d_w_emb + c.b * kWembBlock + (c.part ? kHid * kSa : 0) + u * l.S;
-        const float e = lane < l.E ? vrow[lane] : 0.f, de = lane < l.E ? dwe[lane] : 0.f;
-        const float y0 = vrow[l.E + lane], y1 = vrow[l.E + 64 + lane];
-        const float n2 = wave_sum(e * e + y0 * y0 + y1 * y1);
-        const float dot = wave_sum(de * e + dwl0 * y0 + dwl1 * y1);
-        const float n = sqrtf(n2), g = P[l.g + u], s = g / n, coef = g * dot / (n2 * n);
-        float* drow = dP + l.v + u * l.K;                                // d weight_v = s dW - (g/n^3)(dW.v) v
-        if (lane < l.E) drow[lane] = s * de - coef * e;
-        drow[l.E + lane] = s * dwl0 - coef * y0;
-        drow[l.E + 64 + lane] = s * dwl1 - coef * y1;
-        if (lane == 0) {
-            dP[l.g + u] = dot / n;                                       // d weight_g
-            dP[l.bias + u] = db;
+        e[r] = lane < l.E ? vrow[lane] : 0.f;
+        de[r] = lane < l.E ? dwe[lane] : 0.f;
+        y0r[r] = vrow[l.E + lane];
+        y1r[r] = vrow[l.E + 64 + lane];
+        gq[r] = P[l.g + u];
+        dwl0[r] = dwl1[r] = db[r] = 0.f;
+    }
+    for (int v = 0; v < B; ++v) {                                       // latent half of dW:  dwl[k] = sum_v d_view_b[v][u] * code_b[v][k]
+        const float c0 = cb[v * kLat + lane], c1 = cb[v * kLat + 64 + lane];
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const float t = dvb[v * 6 * kHid + c.u0 + r];
+            dwl0[r] += t * c0;
+            dwl1[r] += t * c1;
+            db[r] += t;
         }
-        sr[r] = s; y0r[r] = y0; y1r[r] = y1;
+    }
+    float n2[kRowsPerWave], dot[kRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        n2[r] = e[r] * e[r] + y0r[r] * y0r[r] + y1r[r] * y1r[r];
+        dot[r] = de[r] * e[r] + dwl0[r] * y0r[r] + dwl1[r] * y1r[r];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            n2[r] += __shfl_xor(n2[r], o);
+            dot[r] += __shfl_xor(dot[r], o);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int u = c.u0 + r;
+        const float n = sqrtf(n2[r]), g = gq[r], s = g / n, coef = g * dot[r] / (n2[r] * n);
+        float* drow = dP + l.v + u * l.K;                                // d weight_v = s dW - (g/n^3)(dW.v) v
+        if (lane < l.E) drow[lane] = s * de[r] - coef * e[r];
+        drow[l.E + lane] = s * dwl0[r] - coef * y0r[r];
+        drow[l.E + 64 + lane] = s * dwl1[r] - coef * y1r[r];
+        if (lane == 0) {
+            dP[l.g + u] = dot[r] / n;                                    // d weight_g
+            dP[l.bias + u] = db[r];
+        }
+        sr[r] = s;
     }
     // d code_b[v][k] (this wave's 4 rows) = sum_r d_view_b[v][u_r] * s_r * V[u_r][E+k]
     float* out = partial + (((long long)c.b * kParts + (c.part * kGroups + blockIdx.x % kGroups) * 4 + wave) * B) * kLat;
@@ -199,10 +225,16 @@ __global__ __launch_bounds__(256) void warp_prep_bwd_kernel(const float* __restr
 }
 
 __device__ __forceinline__ float sum_parts(const float* __restrict__ p, long long stride) {   // fixed order over kParts partials
+    // all 64 loads in flight before the first add (this kernel closes the chain of small launches that ends a rank's iteration: rolled,
+    // it paid sixteen dependent round trips); the additions keep their order
+    float x[kParts];
+#pragma unroll
+    for (int w = 0; w < kParts; ++w) x[w] = p[w * stride];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int w = 0; w < kParts; w += 4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += p[(w + k) * stride];
+        for (int k = 0; k < 4; ++k) s[k] += x[w + k];
     }
     return (s[0] + s[1]) + (s[2] + s[3]);
 }
@@ -226,7 +258,14 @@ __global__ __launch_bounds__(256) void warp_prep_bwd_code_kernel(const float* __
             for (int b = 0; b < 3; ++b) {
                 const float* Wc = P + kOffC + b * kBlkC;
                 float a = sh[b * kLat + tid];                             // identity path of code_b = lin_c(code) + code
-                for (int j = 0; j < kLat; ++j) a += sh[b * kLat + j] * Wc[j * kLat + tid];
+#pragma unroll 1
+                for (int j0 = 0; j0 < kLat; j0 += 32) {                   // 32 weight loads in flight per trip, same order of additions
+                    float wc[32];
+#pragma unroll
+                    for (int jj = 0; jj < 32; ++jj) wc[jj] = Wc[(j0 + jj) * kLat + tid];
+#pragma unroll
+                    for (int jj = 0; jj < 32; ++jj) a += sh[b * kLat + j0 + jj] * wc[jj];
+                }
                 acc += a;
             }
             d_code[v * kLat + tid] = acc;
