@@ -801,7 +801,7 @@ def main():
                ms_per_step_fastest_rank=dt_min / args.steps * 1e3, comm_ms=None if comm_ms is None else round(comm_ms, 4),
                comm_exposed_ms=None if comm_exposed_ms is None else round(comm_exposed_ms, 4), strong=strong, placement=placement if args.config == "cfg4" else None,
                replicas=replicas, capture_fallback=bool(os.environ.get("NIW_CAPTURE_FALLBACK")),
-               launches_per_step="one niw_train_step call (25 kernel launches for a single-pass config, 35 with the fine pass) + gradient all-reduce + one Adam launch"
+               launches_per_step="one niw_train_step call (22 kernel launches for a single-pass config, 29 with the fine pass) + gradient exchange + one Adam launch"
                if getattr(loads[0][0], "fused", None) is not None else "autograd mirror over the per-stage entry points",
                roofline=roofline, kernel_check=kernel_check, kernels=kernels)
     g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]

@@ -3,6 +3,7 @@
 // step stays on the device without host round trips.
 #include "niw_common.h"
 #include "niw_loss_device.h"
+#include "niw_warp_prep_device.h"
 
 namespace {
 
@@ -326,8 +327,10 @@ __device__ __forceinline__ void draw_raygen_body(long long i, long long n_pixels
 // niw_mlp_pack_weights_indexed), the zero pad columns of the warp backward's factor rows.  Block ranges select the job; every job is
 // the body of the stand-alone kernel of the same name.
 struct FrontArgs {
-    int first_block[5];            // jobs: 0 rays, 1 depths, 2 weight image (coarse), 3 weight image (fine), 4 pad columns; first_block[k+1] ends job k
+    int first_block[6];            // jobs: 0 rays, 1 depths, 2 weight image (coarse), 3 weight image (fine), 4 pad columns, 5 the warp's code projection
     int end_block;
+    // code projection (job 5): one workgroup per (coupling block, view)
+    const float* warp_params; const float* code; float* codeb; int n_code_views;
     // rays
     long long n_pixels; unsigned long long seed, draw; const unsigned long long* draw_dev; int half;
     const float* intr; const float* pose; int B; long long R; int W; int64_t* ray_idx; float* stacked;
@@ -343,8 +346,13 @@ __global__ void step_front_kernel(FrontArgs a) {
     const int blk = blockIdx.x;
     int job = 0;
 #pragma unroll
-    for (int k = 1; k < 5; ++k)
+    for (int k = 1; k < 6; ++k)
         if (blk >= a.first_block[k]) job = k;
+    if (job == 5) {                                                   // (whole workgroups: the body uses wave butterflies)
+        const int w = blk - a.first_block[5];
+        niw_warp_prep::code_projection(w % 3, w / 3, a.warp_params, a.code, a.n_code_views, a.codeb);
+        return;
+    }
     const long long i = (long long)(blk - a.first_block[job]) * blockDim.x + threadIdx.x;
     if (job == 0) {
         draw_raygen_body(i, a.n_pixels, a.seed, a.draw, a.draw_dev, a.half, a.intr, a.pose, a.B, a.R, a.W, a.ray_idx, a.stacked);
@@ -430,14 +438,17 @@ extern "C" int niw_raygen(const float* intr, const float* pose, const int64_t* r
 }
 
 // The front of a train iteration in one launch (step_front_kernel): niw_draw_ray_idx + stacked mode-0 ray generation; niw_sample_stratified(_rng);
-// niw_mlp_pack_weights_indexed of one or two networks (packed[k] == NULL: skipped); the pad columns [n_cols, ppad) of `pad_rows` factor rows
+// niw_mlp_pack_weights_indexed of one or two networks (packed[k] == NULL: skipped); the pad columns [n_cols, ppad) of `pad_rows` factor rows;
+// the warp's code projection (codeb == NULL: skipped), the first of niw_warp_prep_fwd's two launches
 int niw_launch_step_front(int64_t n_pixels, uint64_t seed, uint64_t draw, const uint64_t* draw_dev, const float* intr, const float* pose, int n_views,
                           long long R, int H, int W, int64_t* ray_idx, float* stacked,
                           uint64_t depth_seed, int stratified, long long n_rays, int S, double depth_min, double depth_max, int inverse, float* depth,
                           const float* params0, const float* params1, const int32_t* index, float* packed0, float* packed1,
-                          float* pad_ws, long long pad_rows, long long ppad, long long n_cols, hipStream_t st) {
+                          float* pad_ws, long long pad_rows, long long ppad, long long n_cols,
+                          const float* warp_params, const float* code, int n_code_views, float* codeb, hipStream_t st) {
     NIW_REQUIRE(n_pixels == (int64_t)H * W && R > 0 && R <= n_pixels && n_pixels <= (1ll << 40), "niw_train_step (pixel draw): %lld rays of %lld pixels", R, (long long)n_pixels);
     NIW_REQUIRE(intr && ray_idx && stacked && depth && n_rays > 0 && S > 0, "niw_train_step (front): null pointer or empty input");
+    NIW_REQUIRE(!codeb || (warp_params && code && n_code_views > 0), "niw_train_step (front): the code projection needs the warp parameters and the latent codes");
     NIW_REQUIRE((!packed0 && !packed1) || index, "niw_train_step (front): weight images need the pack index");
     FrontArgs a{};
     int bits = 1;
@@ -451,10 +462,11 @@ int niw_launch_step_front(int64_t n_pixels, uint64_t seed, uint64_t draw, const 
     a.packed[0] = reinterpret_cast<f32x4*>(packed0); a.packed[1] = reinterpret_cast<f32x4*>(packed1);
     const int n_pad = pad_ws ? (int)(ppad - n_cols) : 0;
     a.pad_ws = pad_ws; a.pad_rows = pad_rows; a.ppad = ppad; a.first_pad = (int)n_cols; a.n_pad = n_pad;
-    const long long work[5] = {(long long)n_views * R, (a.n_depth + 3) / 4, packed0 ? niw::kPackedFloats / 4 : 0, packed1 ? niw::kPackedFloats / 4 : 0,
-                               pad_rows * n_pad};
+    a.warp_params = warp_params; a.code = code; a.codeb = codeb; a.n_code_views = n_code_views;
+    const long long work[6] = {(long long)n_views * R, (a.n_depth + 3) / 4, packed0 ? niw::kPackedFloats / 4 : 0, packed1 ? niw::kPackedFloats / 4 : 0,
+                               pad_rows * n_pad, codeb ? 256ll * 3 * n_code_views : 0};
     int blocks = 0;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         a.first_block[k] = blocks;
         blocks += (int)((work[k] + 255) / 256);
     }

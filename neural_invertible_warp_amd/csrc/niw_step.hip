@@ -23,7 +23,9 @@ int niw_launch_step_front(int64_t n_pixels, uint64_t seed, uint64_t draw, const 
                           long long R, int H, int W, int64_t* ray_idx, float* stacked,
                           uint64_t depth_seed, int stratified, long long n_rays, int S, double depth_min, double depth_max, int inverse, float* depth,
                           const float* params0, const float* params1, const int32_t* index, float* packed0, float* packed1,
-                          float* pad_ws, long long pad_rows, long long ppad, long long n_cols, hipStream_t st);
+                          float* pad_ws, long long pad_rows, long long ppad, long long n_cols,
+                          const float* warp_params, const float* code, int n_code_views, float* codeb, hipStream_t st);
+int niw_launch_warp_prep_fwd_main(const float* params, int n_views, const float* workspace, float* w_emb, float* view_b, float* w_head, hipStream_t st);
 void niw_warp_bwd_pad_geometry(int n_views, int64_t n_pts, long long* rows, long long* ppad, long long* n_cols);
 int niw_launch_align_register(const float* target, const float* source, int n_views, int64_t n_points, double* moments, float* poses, hipStream_t st);
 int niw_launch_warp_prep_bwd(const float* params, const float* code, int n_views, const float* d_w_emb, const float* d_view_b,
@@ -397,14 +399,15 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
                                       d->pose_init ? d->pose_init + 12ll * d->view0 : nullptr, (int)V, R, d->H, d->W, reinterpret_cast<int64_t*>(L.ray_idx),
                                       L.stacked_in, d->depth_seed, d->stratified, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, d->nerf_params,
                                       fine ? d->nerf_fine_params : nullptr, d->pack_index, gather ? L.packed_c : nullptr, gather && fine ? L.packed_f : nullptr,
-                                      L.warp_ws, pad_rows, ppad, n_cols, st));
+                                      L.warp_ws, pad_rows, ppad, n_cols, d->warp_params, d->latent + 128ll * d->view0, (int)V, L.prep_ws, st));
         if (!gather) {                      // split-bf16 images, or no gather table: the packing kernels of the entry points
             NIW_RUN(pack(d, d->nerf_params, L.packed_c, stream));
             if (fine) NIW_RUN(pack(d, d->nerf_fine_params, L.packed_f, stream));
         }
     }
     if (in(NIW_STAGE_WARP_FWD)) {
-        NIW_RUN(niw_warp_prep_fwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.prep_ws, L.w_emb, L.view_b, L.w_head, stream));
+        // (the code projection at the head of prep_ws was made by the front kernel)
+        NIW_RUN(niw_launch_warp_prep_fwd_main(d->warp_params, (int)V, L.prep_ws, L.w_emb, L.view_b, L.w_head, st));
         NIW_RUN(niw_warp_fwd(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window, nullptr,
                              nullptr, 0, L.warped, L.xin, stream));
         split_rays_kernel<<<(unsigned)((V * R * 3 + 255) / 256), 256, 0, st>>>(L.warped, V, R, L.ray, L.center);

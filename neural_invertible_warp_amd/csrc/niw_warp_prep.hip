@@ -18,16 +18,11 @@
 //   for b in 0..2: lin{b}_b_0.bias[128] .weight_g[128] .weight_v[128x141]  lin{b}_b_1.weight[3x128] .bias[3]
 //   for b in 0..2: lin{b}_c.weight[128x128] .bias[128]
 #include "niw_common.h"
+#include "niw_warp_prep_device.h"
 
 namespace {
 
-constexpr int kHid = 128, kLat = 128, kEa = 26, kEb = 13;
-constexpr int kKa = kEa + kLat, kKb = kEb + kLat;                       // 154, 141
-constexpr int kBlkA = kHid + kHid * kKa + kHid + kHid + 1;              // 20097
-constexpr int kBlkB = kHid + kHid * kKb + kHid + 3 * kHid + 3;          // 18691
-constexpr int kBlkC = kLat * kLat + kLat;                               // 16512
-constexpr int kOffB = 3 * kBlkA, kOffC = kOffB + 3 * kBlkB;
-static_assert(kOffC + 3 * kBlkC == NIW_WARP_PARAM_FLOATS, "flat warp parameter count");
+using namespace niw_warp_prep;
 constexpr int kSa = 28, kSb = 16;                                       // row pitch of w_emb / d_w_emb (26 / 13 columns + pad)
 constexpr int kWembBlock = kHid * (kSa + kSb), kHeadBlock = kHid + 1 + 3 * kHid + 3;
 static_assert(3 * kWembBlock == NIW_WARP_WEMB_FLOATS, "w_emb layout");
@@ -49,36 +44,10 @@ __device__ __forceinline__ Layer layer_of(int b, int part) {
     return l;
 }
 
-__device__ __forceinline__ float wave_sum(float x) {    // butterfly: every lane ends with the total, same order on every run
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
-}
-
 // code_b[b][v][j] = bc[j] + code[v][j] + sum_k Wc[j][k] code[v][k];  grid (3, B), one wave per 32 rows j
 __global__ __launch_bounds__(256) void warp_prep_code_kernel(const float* __restrict__ P, const float* __restrict__ code, int B,
                                                              float* __restrict__ codeb) {
-    const int b = blockIdx.x, v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* Wc = P + kOffC + b * kBlkC;
-    const float* bc = Wc + kLat * kLat;
-    const float c0 = code[v * kLat + lane], c1 = code[v * kLat + 64 + lane];
-    // all 64 row loads of the wave are issued before the first butterfly: the kernel is one cold HBM round trip plus arithmetic
-    // (rolled, every row waited for its own two loads: 21 us for a [B,128] x [128,128] product; eight at a time still 21)
-    float w0[32], w1[32];
-#pragma unroll
-    for (int jj = 0; jj < 32; ++jj) {
-        const int j = wave * 32 + jj;
-        w0[jj] = Wc[j * kLat + lane];
-        w1[jj] = Wc[j * kLat + 64 + lane];
-    }
-    const float extra = lane < 32 ? bc[wave * 32 + lane] + code[v * kLat + wave * 32 + lane] : 0.f;
-    float mine = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < 32; ++jj) {
-        const float s = wave_sum(w0[jj] * c0 + w1[jj] * c1);
-        mine = lane == jj ? s : mine;
-    }
-    if (lane < 32) codeb[((long long)b * B + v) * kLat + wave * 32 + lane] = mine + extra;     // one coalesced store per wave
+    code_projection(blockIdx.x, blockIdx.y, P, code, B, codeb);
 }
 
 struct RowCtx { int b, part, u0; Layer l; };
@@ -304,6 +273,15 @@ extern "C" int niw_warp_prep_fwd(const float* params, const float* code, int n_v
     hipStream_t st = (hipStream_t)stream;
     warp_prep_code_kernel<<<dim3(3, n_views), 256, 0, st>>>(params, code, n_views, workspace);
     NIW_LAUNCH_CHECK("niw_warp_prep_fwd (code projection)");
+    warp_prep_fwd_kernel<<<3 * 2 * kGroups, 256, 0, st>>>(params, workspace, n_views, w_emb, view_b, w_head);
+    NIW_LAUNCH_CHECK("niw_warp_prep_fwd");
+    return NIW_OK;
+}
+
+// the forward without its first launch: `workspace` already holds the code projection (the train iteration's front kernel made it)
+int niw_launch_warp_prep_fwd_main(const float* params, int n_views, const float* workspace, float* w_emb, float* view_b, float* w_head, hipStream_t st) {
+    NIW_REQUIRE(params && workspace && w_emb && view_b && w_head, "niw_warp_prep_fwd: null pointer");
+    NIW_REQUIRE(n_views > 0 && n_views <= kMaxViews, "niw_warp_prep_fwd: 1..%d views per call (got %d)", kMaxViews, n_views);
     warp_prep_fwd_kernel<<<3 * 2 * kGroups, 256, 0, st>>>(params, workspace, n_views, w_emb, view_b, w_head);
     NIW_LAUNCH_CHECK("niw_warp_prep_fwd");
     return NIW_OK;
