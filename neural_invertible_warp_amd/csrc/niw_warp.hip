@@ -478,40 +478,50 @@ __device__ __forceinline__ float sum_tiles(const float* __restrict__ p, long lon
 }
 
 // reduce the partial tiles of the two GEMM families and scatter into d_w_emb / d_view_b / d_w_head
-// tk2: columns of the second family's tiles -- 64 (its own 256 x 64 launch) or 256 (one launch with the first family, niw_launch_nt_gemm_pairs)
+// tk2: columns of the second family's tiles -- 64 (its own 256 x 64 launch) or 256 (one launch with the first family, niw_launch_nt_gemm_pairs).
+// One thread per OUTPUT (round 5; rounds 1-4 launched a thread per tile element, 82 k per coupling block of which 7 k had anything to
+// do): [128 x 28 | 128 x 16] first-layer weights incl. their zero pad columns, [256 x views] per-view biases, [128 + 3 x 128] head weights,
+// 4 head biases.  Same sums over the same partial tiles.
 __global__ void warp_reduce_kernel(const float* __restrict__ p1, int nsplit1, const float* __restrict__ p2, int nsplit2, int tk2,
                                    int n_views, float* __restrict__ d_w_emb, float* __restrict__ d_view_b, float* __restrict__ d_w_head) {
     const int b = blockIdx.y;                                   // coupling block
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int T1 = 256 * 256 + 256;
     const int T2 = 256 * tk2 + 256;
-    if (idx < 256 * 256) {
-        const int r = idx >> 8, c = idx & 255;                  // r: [ga 0..127 | gb 128..255], c: [ea 0..31 | eb 32..63 | views 64..127]
-        const int part = r >> 7, u = r & 127;
-        float* dst = nullptr;
-        bool pad = false;                                       // pad columns of the rows: overwritten with zero
-        if (part == 0 && c < kSa) { dst = d_w_emb + b * kWembBlock + u * kSa + c; pad = c >= kEa; }
-        else if (part == 1 && c >= 32 && c < 32 + kSb) { dst = d_w_emb + b * kWembBlock + kHid * kSa + u * kSb + (c - 32); pad = c - 32 >= kEb; }
-        else if (c >= 64 && c < 64 + n_views) dst = d_view_b + ((long long)(c - 64) * 3 + b) * 2 * kHid + part * kHid + u;
-        if (!dst) return;
-        *dst = pad ? 0.f : sum_tiles(p1 + (long long)b * nsplit1 * T1 + idx, T1, nsplit1);
-    } else if (idx < 256 * 256 + 256 * 64 + 256) {
-        const int j = idx - 256 * 256;                          // tile 2: [ha 0..127 | hb 128..255] x [d delta, d theta, d t0, d t1, ...]
-        float* dst = nullptr;
-        int at = 0;                                              // element of the (256 x tk2 + 256)-float tile
-        if (j < 256 * 64) {
-            const int r = j >> 6, c = j & 63, u = r & 127;
-            if (r < 128 && c == 0) dst = d_w_head + b * kHeadBlock + u;
-            else if (r >= 128 && c >= 1 && c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + (c - 1) * kHid + u;
-            at = r * tk2 + c;
-        } else {
-            const int c = j - 256 * 64;                         // row sums of the head gradients = bias gradients
-            if (c == 0) dst = d_w_head + b * kHeadBlock + kHid;
-            else if (c < 4) dst = d_w_head + b * kHeadBlock + kHid + 1 + 3 * kHid + (c - 1);
-            at = 256 * tk2 + c;
-        }
-        if (!dst) return;
-        *dst = sum_tiles(p2 + (long long)b * nsplit2 * T2 + at, T2, nsplit2);
+    const float* t1 = p1 + (long long)b * nsplit1 * T1;         // tile 1: rows [ga 0..127 | gb 128..255], columns [ea 0..31 | eb 32..63 | views 64..127]
+    const float* t2 = p2 + (long long)b * nsplit2 * T2;         // tile 2: rows [ha 0..127 | hb 128..255], columns [d delta, d theta, d t0, d t1, ...]
+    if (j < kHid * kSa) {                                       // part a: 26 embedding columns + 2 pad columns (overwritten with zero)
+        const int u = j / kSa, c = j % kSa;
+        d_w_emb[b * kWembBlock + u * kSa + c] = c >= kEa ? 0.f : sum_tiles(t1 + u * 256 + c, T1, nsplit1);
+        return;
+    }
+    j -= kHid * kSa;
+    if (j < kHid * kSb) {                                       // part b: 13 + 3 pad
+        const int u = j / kSb, c = j % kSb;
+        d_w_emb[b * kWembBlock + kHid * kSa + u * kSb + c] = c >= kEb ? 0.f : sum_tiles(t1 + (kHid + u) * 256 + 32 + c, T1, nsplit1);
+        return;
+    }
+    j -= kHid * kSb;
+    if (j < 2 * kHid * n_views) {                               // per-view biases: the view indicator columns
+        const int r = j / n_views, v = j % n_views, part = r >> 7, u = r & 127;
+        d_view_b[((long long)(v * 3 + b) * 2 + part) * kHid + u] = sum_tiles(t1 + r * 256 + 64 + v, T1, nsplit1);
+        return;
+    }
+    j -= 2 * kHid * n_views;
+    if (j < kHid) {                                             // lin_a_1.weight: rows ha, column d delta
+        d_w_head[b * kHeadBlock + j] = sum_tiles(t2 + j * tk2, T2, nsplit2);
+        return;
+    }
+    j -= kHid;
+    if (j < 3 * kHid) {                                         // lin_b_1.weight [3][128]: rows hb, columns d theta, d t0, d t1
+        const int c = j / kHid, u = j % kHid;
+        d_w_head[b * kHeadBlock + kHid + 1 + c * kHid + u] = sum_tiles(t2 + (kHid + u) * tk2 + 1 + c, T2, nsplit2);
+        return;
+    }
+    j -= 3 * kHid;
+    if (j < 4) {                                                // row sums of the head gradients = head biases
+        float* dst = j == 0 ? d_w_head + b * kHeadBlock + kHid : d_w_head + b * kHeadBlock + kHid + 1 + 3 * kHid + (j - 1);
+        *dst = sum_tiles(t2 + 256 * tk2 + j, T2, nsplit2);
     }
 }
 
@@ -632,7 +642,8 @@ int niw_launch_warp_bwd_main(const float* w_emb, const float* view_b, const floa
                                 NiwGemmOperand{workspace + kRowGo * ppad, 4, stride, ppad}, ppad, 3, p2, 2, &ns2, st);
         if (rc != NIW_OK) return rc;
     }
-    warp_reduce_kernel<<<dim3((256 * 256 + 256 * 64 + 256 + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, tk2, n_views, d_w_emb, d_view_b, d_w_head);
+    const int n_out = kHid * kSa + kHid * kSb + 2 * kHid * n_views + 4 * kHid + 4;
+    warp_reduce_kernel<<<dim3((n_out + 255) / 256, 3), 256, 0, st>>>(p1, ns1, p2, ns2, tk2, n_views, d_w_emb, d_view_b, d_w_head);
     NIW_LAUNCH_CHECK("niw_warp_bwd (reduce)");
     return NIW_OK;
 }
