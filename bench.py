@@ -55,9 +55,39 @@ FLOP_FWD = 2 * 527872           # algorithmic GEMM FLOPs per MLP evaluation (SUR
 PEAK_FP32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA = 2500.0         # TFLOP/s dense (the guide's ~2.5 PF; never the 2:1-sparsity figure)
 PEAK_HBM = 8000.0               # GB/s spec (6290 GB/s measured streaming copy)
+XGMI_LINK_GBPS = 153.0          # GB/s per xGMI link (7 links per GPU, point to point): a ring all-reduce is bound by ONE link per neighbour
 
 
-def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False, budget_s=45.0):
+def wire_ms(n_bytes, world):
+    """Algorithmic wire time of a ring all-reduce of n_bytes over `world` GPUs: every rank sends (and receives) 2 (N - 1) / N x the
+    buffer over one xGMI link per neighbour.  A measured comm_ms far above this is latency (2 (N - 1) hops), not bandwidth."""
+    if world < 2 or not n_bytes:
+        return 0.0
+    return 2.0 * (world - 1) / world * n_bytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+
+
+def host_flags_agree(tag, ok, rank, world):
+    """HOST-ONLY exchange of one boolean per rank through the process group's key-value store (no device work, no collective): used
+    where a rank's HIP state may have become unusable (a failed graph capture is sticky in-process) and its peers must learn of it BEFORE
+    they enter a collective that rank will never join.  -> list of the ranks that reported False."""
+    import torch.distributed as dist
+    store = dist.distributed_c10d._get_default_store()
+    store.set(f"niw_flag/{tag}/{rank}", "1" if ok else "0")
+    return [r for r in range(world) if store.get(f"niw_flag/{tag}/{r}") != b"1"]
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False, budget_s=60.0, timed_steps=3):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to golden vectors) timed on this box's host cores on a
     bounded sample of the same workload: same views / resolution / samples per ray, and since round 5 HALF the rays of the batch (113
     per view at 18 views; the whole 227 when a step fits the budget): at 16 rays per view (rounds 1-4) the fixed per-step work -- the
@@ -117,22 +147,34 @@ def cpu_baseline(B, S, Sf, H, W, ga_weight=None, vanilla=False, budget_s=45.0):
         sweep[n] = min(one_step(R_small), one_step(R_small))
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
-    # 2. the figure: half the batch's rays per view (113 of 227 at cfg2 / all 113 of cfg3's), 1 warm-up + 2 timed; the full batch if the
-    # budget allows (estimated from the short step)
+    # 2. the figure (1 warm-up + >= 3 timed steps): the full batch if the budget allows (estimated from the short
+    # step; cfg2's 14 s step does: ~57 s), else half the batch's rays per view, halved again while the estimate is twice the budget
     R_full = None
     est = sweep[threads] / (B * R_small * per_ray)                    # seconds per evaluation at the short step (an over-estimate)
     R_half = max(R_small, 2048 // B)
     rays_of_batch = min(H * W, 4096 // B if Sf and not vanilla else 2048 // B if not vanilla else 1024 // B)
-    R = rays_of_batch if est * B * rays_of_batch * per_ray * 3 < budget_s else min(R_half, rays_of_batch)
-    while R > R_small and est * B * R * per_ray * 3 > 2 * budget_s:
+    n_steps = 1 + max(3, int(timed_steps))
+    R = rays_of_batch if est * B * rays_of_batch * per_ray * n_steps < budget_s else min(R_half, rays_of_batch)
+    while R > R_small and est * B * R * per_ray * n_steps > 2 * budget_s:
         R = max(R_small, R // 2)
-    times = [one_step(R) for _ in range(3)]
+    times = [one_step(R) for _ in range(n_steps)]
     evals = B * R * per_ray
     timed = sorted(times[1:])
-    best = timed[0]
-    out = dict(value=evals / best, unit="ray-samples/s", cores=threads, kind="port",
+    best, median = timed[0], timed[len(timed) // 2]
+    fwd_only = None
+    if not vanilla:
+        # forward only (BASELINE.md section 4 asks for both figures): the same step without the backward pass, one timed call
+        with torch.no_grad():
+            ray_idx = torch.randperm(H * W, generator=gen)[:R]
+            u = torch.rand(B, R, S, 1, generator=gen)
+            t0 = time.perf_counter()
+            O.inn_train_step(pc, wp, lat, image, intr, ray_idx, u, H, W, S, (1, 0), "inverse", 0.3, nerf_fine_p=pf, Sf=Sf, ga_weight=ga_weight,
+                             w3d=w3, wview=wv, reference_cost=True)
+            fwd_only = evals / (time.perf_counter() - t0)
+    out = dict(value=evals / best, value_median=evals / median, forward_only_value=fwd_only, cpu_model=cpu_model_name(),
+               unit="ray-samples/s", cores=threads, kind="port",
                sample=f"{B} views x {R} rays x ({S}" + (f"+{S + Sf}" if Sf else "") + f") samples = {evals} MLP evals per step (the batch has {rays_of_batch} "
-                      f"rays per view), fwd+bwd, best of 2 timed steps after 1 warm-up, torch CPU {threads} threads",
+                      f"rays per view), fwd+bwd, {len(timed)} timed steps after 1 warm-up (value = best, value_median = median), torch CPU {threads} threads",
                seconds_per_step=[round(t, 3) for t in times[1:]], affinity_cores=affinity, host_cores=os.cpu_count(),
                thread_sweep={str(n): dict(seconds_per_step=round(t, 4), value=round(B * R_small * per_ray / t, 1)) for n, t in sweep.items()},
                thread_sweep_sample=f"{B} views x {R_small} rays, best of 2 after 1 warm-up at each count; the count with the shortest step times the figure",
@@ -463,6 +505,10 @@ def main():
     ap.add_argument("--split-exchange", choices=["auto", "on", "off"], default="auto",
                     help="N > 1 with a fine network: the gradient exchange as two all-reduces, the fine network's segment on a communication stream "
                          "while the rest of the backward runs (auto: where the iteration is one launched call); off: one flat all-reduce")
+    ap.add_argument("--ab", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1 (auto) or any live process group (on): after the headline, time the weak workload a few more steps with the split "
+                         "gradient exchange forced on / off and launched vs replayed as a HIP graph -- `split_exchange: {on_ms, off_ms}`, "
+                         "`hip_graph: {launched_ms, replayed_ms}` -- so that ONE hardware run answers both open questions of DESIGN section 5")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the torch.distributed process group even for ONE rank, so that the gradient all-reduce really goes through RCCL "
                          "(hardware evidence of the N > 1 code path on a 1-GPU box)")
@@ -514,7 +560,7 @@ def main():
     # seventh iteration after start-up (tools/rccl_probe.py, round 4) that would otherwise sit inside the timed region
     n_warm = max(args.warmup, 3 if use_graph else 16)
 
-    def timed_run(loads_):
+    def timed_run(loads_, exit_on_capture_error=True):
         """warm-up + `--steps` timed iterations of one workload -> (seconds, final loss, replayed?, mean all-reduce ms | None, step fn)"""
         # the batch tensors stay resident at fixed addresses (a captured graph reads private copies of them, in place)
         def step(replay=True):
@@ -526,6 +572,8 @@ def main():
             for _ in range(n_warm):                       # >= 3: two launch-by-launch iterations, then the capture
                 step()
         except engine.CaptureError as e:
+            if not exit_on_capture_error:
+                raise
             report_capture_failure_and_exit(e)
         for tr, *_ in loads_:
             if hasattr(tr, "comm_events"):
@@ -559,6 +607,25 @@ def main():
                              "run is not a measurement")
         mean = lambda v: sum(v) / len(v) if v else None
         return dt_, value_, all(getattr(tr, "_captured", None) is not None for tr, *_ in loads_), (mean(comm), mean(exposed)), step
+
+    class CaptureAbort(Exception):
+        """a rank's graph capture failed and every rank has learnt of it (host-side) before any of them entered a replay's collective"""
+
+    def guard_captures(loads_, tag):
+        """wrap every trainer's capture so that its outcome is agreed on by all ranks through the store BEFORE the first replay: a rank
+        whose capture failed can issue no further device work, and a peer that went on to replay would wait for it in the all-reduce"""
+        for j, (tr, *_) in enumerate(loads_):
+            def guarded(var, it, _orig=tr._capture, _tag=f"{tag}/{j}"):
+                err = None
+                try:
+                    ok = _orig(var, it)
+                except engine.CaptureError as e:
+                    ok, err = False, e
+                bad = host_flags_agree(_tag, bool(ok), rank, world)
+                if bad:
+                    raise CaptureAbort(f"capture failed on rank(s) {bad}" + (f": {err}" if err else ""))
+                return ok
+            tr._capture = guarded
 
     def over_ranks(dt_, evals_, comm_, loads_, check_params=True):
         """max / min over ranks of the timed seconds, sum of the evaluations, max of the all-reduce time; and the ranks' parameters must
@@ -702,9 +769,79 @@ def main():
         if placement != "replicas":
             del loads_r
 
-    if rank != 0:
+    # bucket bytes one iteration exchanges (all trainers of the step) and their algorithmic wire time over one xGMI link per neighbour
+    bucket_bytes = sum(4 * tr.bucket.flat.numel() for tr, *_ in loads if getattr(tr, "collectives", False))
+    auto_split = bool(loads and hasattr(loads[0][0], "_overlapped_exchange") and loads[0][0]._overlapped_exchange())
+
+    # A/B legs (N > 1): the headline workload a few more timed steps (i) with the split gradient exchange forced off / on, launched,
+    # (ii) flat exchange, launched vs replayed as HIP graphs -- in the same processes, so that one hardware run answers whether the
+    # overlap pays over xGMI and whether the replayed form catches up when every rank's host also drives a communicator.  The replayed
+    # leg comes LAST and its captures are agreed on host-side (guard_captures): a failed capture costs this field, never the line.
+    split_ab, graph_ab, capture_abort = None, None, None
+    want_ab = args.ab == "on" or (args.ab == "auto" and world > 1)
+    if want_ab and dist.is_initialized() and placement == "shard" and loads and getattr(loads[0][0], "fused", None) is not None:
+        def release(loads_):
+            for tr, *_ in loads_:
+                if getattr(tr, "fused", None) is not None:
+                    tr.fused.ws = None
+
+        def leg(loads_):
+            dt_, _, graphed_, comm_, _ = timed_run(loads_, exit_on_capture_error=False)
+            mx, _, _, comm_ = over_ranks(dt_, 0, comm_, loads_, check_params=False)
+            r4 = lambda x: None if x is None else round(x, 4)
+            return dict(ms=r4(mx / args.steps * 1e3), comm_ms=r4(comm_[0]), comm_exposed_ms=r4(comm_[1]), hip_graph=graphed_)
+
+        step = None
+        release(loads)
+        wl_ab = dict(wl, hip_graph=False, split_exchange=False)
+        loads_ab, _ = build_workloads(args.config, dev, rank, world, scaling, 0, placement="shard", **wl_ab)
+        off = leg(loads_ab)
+        on = None
+        if all(tr.bucket.n_head > 0 for tr, *_ in loads_ab):
+            for tr, *_ in loads_ab:
+                tr.split_exchange = True
+            on = leg(loads_ab)
+        split_ab = dict(off_ms=off["ms"], on_ms=None if on is None else on["ms"], off=off, on=on, auto_resolves_to="on" if auto_split else "off",
+                        steps=args.steps, workload=f"{scaling}-scaled {args.config}, launched; off = one flat all-reduce behind the backward, on = the fine "
+                        "network's segment all-reduced on a communication stream while the coarse / warp backward runs" +
+                        ("" if on is not None else " (no fine network in this config: nothing to split)"))
+        release(loads_ab)
+        del loads_ab
+        loads_g, _ = build_workloads(args.config, dev, rank, world, scaling, 0, placement="shard", **dict(wl_ab, hip_graph=True))
+        guard_captures(loads_g, "ab_graph")
+        try:
+            rep = leg(loads_g)
+            graph_ab = dict(launched_ms=off["ms"], replayed_ms=rep["ms"] if rep["hip_graph"] else None, replayed=rep, steps=args.steps,
+                            workload=f"{scaling}-scaled {args.config}, flat all-reduce; replayed = two captured graphs (forward + backward | Adam) around the "
+                                     "eagerly issued all-reduce")
+        except (CaptureAbort, engine.CaptureError) as e:
+            capture_abort = str(e)[:300]
+            graph_ab = dict(launched_ms=off["ms"], replayed_ms=None, capture_failed=capture_abort)
+        if capture_abort is None:
+            release(loads_g)
+        else:
+            # (a one-rank --force-dist run: the side figures below would need the device)
+            args.no_composite_scan = args.no_forward_only = args.no_psnr_parity = args.no_torch_baseline = True
+        del loads_g
+
+    def finish(code=0):
+        """leave the process: normally through destroy_process_group; after an aborted capture some rank's HIP state is unusable, so every
+        rank leaves without touching the device or the communicator again"""
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if capture_abort is not None:
+            os._exit(code)
         if dist.is_initialized():
             dist.destroy_process_group()
+
+    # peak device memory of the run's trainers (torch's allocator: workspaces, batch, parameters), max over ranks
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    if world > 1 and capture_abort is None:
+        pm = torch.tensor([peak_mem], device=dev, dtype=torch.float64)
+        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+        peak_mem = float(pm[0])
+    if rank != 0:
+        finish()
         return
 
     # per-kernel rates from the device events recorded during the timed steps
@@ -801,6 +938,11 @@ def main():
                ms_per_step_fastest_rank=dt_min / args.steps * 1e3, comm_ms=None if comm_ms is None else round(comm_ms, 4),
                comm_exposed_ms=None if comm_exposed_ms is None else round(comm_exposed_ms, 4), strong=strong, placement=placement if args.config == "cfg4" else None,
                replicas=replicas, capture_fallback=bool(os.environ.get("NIW_CAPTURE_FALLBACK")),
+               comm_bucket_bytes=bucket_bytes if dist_backend else None,
+               comm_wire_ms=round(wire_ms(bucket_bytes, world), 4) if dist_backend else None,
+               comm_wire_model=f"ring all-reduce: 2 (N - 1) / N x bucket bytes over one xGMI link per neighbour at {XGMI_LINK_GBPS:.0f} GB/s; comm_ms well above it "
+                               "= a latency-bound exchange (2 (N - 1) hops), not a bandwidth-bound one" if dist_backend else None,
+               split_exchange=split_ab, hip_graph_ab=graph_ab, peak_memory_gb=round(peak_mem, 2),
                launches_per_step="one niw_train_step call (22 kernel launches for a single-pass config, 29 with the fine pass) + gradient exchange + one Adam launch"
                if getattr(loads[0][0], "fused", None) is not None else "autograd mirror over the per-stage entry points",
                roofline=roofline, kernel_check=kernel_check, kernels=kernels)
@@ -836,13 +978,10 @@ def main():
                                    stage_by_stage=dict(value=n_eval / t_sweep, ms_per_image=round(t_sweep * 1e3, 2), frac_of_fwd_roofline=frac(t_sweep),
                                                        slices=f"{-(-opt.H * opt.W // opt.nerf.rand_rays)} of {opt.nerf.rand_rays} rays"))
     if world == 1 and not args.no_psnr_parity and args.config != "cfg1":
-        # the "+ PSNR parity" half of the metric, bounded: 10 identical optimisation steps on the HIP path and on the CPU oracle
+        # the "+ PSNR parity" half of the metric, bounded (~20 s): the teacher-student scene the trajectory tests use, alignment term on, 120
+        # chained iterations on the HIP engine and on the oracle, with the spread between draws as the yardstick; null when the run did not train
         from oracle import parity
-        pg, pc = parity.psnr_trajectories(dev, steps=10, precision=args.precision)
-        out["psnr_parity"] = dict(steps=len(pg), max_abs_diff_db=round(max(abs(a - b) for a, b in zip(pg, pc)), 5),
-                                  final_psnr_hip=round(pg[-1], 4), final_psnr_oracle=round(pc[-1], 4),
-                                  sample="barf_inn_llff, 3 views x 16 rays x 32 samples on 12x16 images, identical weights / pixel draws / stratified draws, "
-                                         "photometric PSNR of every step, HIP engine vs CPU oracle (autograd + torch.optim.Adam)")
+        out["psnr_parity"] = parity.trajectory_summary(dev, steps=120, precision=args.precision)
     ga = {"cfg3": 4, "cfg5": 3}.get(args.config, 4 if args.config.startswith("cfg4") else None)
     if world == 1 and not args.no_torch_baseline and not args.shard_of and args.config != "cfg1":
         rng_kw = dict(depth_range=(1.2, 5.2), param="metric") if args.config == "cfg5" else {}
@@ -854,8 +993,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(loads[0][2], S, Sf, opt.H, opt.W, ga_weight=ga, vanilla=args.config == "cfg1")
     print(json.dumps(out), flush=True)
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

@@ -160,3 +160,36 @@ def long_trajectories(dev, steps=1000, views=8, size=(48, 64), R=256, S=64, ga=4
     finally:
         torch.rand, torch.randperm = rand, perm
     return out
+
+
+def trajectory_summary(dev, steps=120, views=8, size=(48, 64), R=256, S=64, ga=4, spread_runs=2, log_every=10, precision="fp32"):
+    """The "+ PSNR parity" half of the metric as bench.py reports it (round 6; the 12 x 16 / 10-step sample of rounds 1-5 never left the
+    untrained regime): the teacher-student scene of `long_trajectories` -- 8 views of 48 x 64, 256 rays x 64 samples, alignment term ON,
+    `steps` >= 120 chained iterations -- on the HIP engine and on the oracle from identical weights with identical pixel and stratified
+    draws, plus `spread_runs` HIP runs that differ ONLY in their draws (the yardstick for "the same trajectory" of a chaotic fp32
+    optimisation).  -> dict, or None when the HIP run did not train (PSNR rise < 3 dB): a parity figure of an untrained network is not
+    evidence."""
+    import time
+    t0 = time.perf_counter()
+    kw = dict(steps=steps, views=views, size=size, R=R, S=S, ga=ga, log_every=log_every, precision=precision)
+    pair = long_trajectories(dev, draw_seed=0, oracle=True, **kw)
+    others = [long_trajectories(dev, draw_seed=s, oracle=False, **kw)["hip"] for s in range(1, 1 + spread_runs)]
+    hip, ora, n = pair["hip"], pair["oracle"], len(pair["it"])
+    rise = hip["psnr"][-1] - hip["psnr"][0]
+    if not (rise >= 3.0 and math.isfinite(hip["psnr"][-1]) and math.isfinite(ora["psnr"][-1])):
+        return None
+    half = n // 2
+    gap = [abs(a - b) for a, b in zip(hip["psnr"], ora["psnr"])]
+    spread = [max(x) - min(x) for x in zip(hip["psnr"], *[o["psnr"] for o in others])]
+    rot_gap = [abs(a - b) for a, b in zip(hip["rel_rot"], ora["rel_rot"])]
+    r = lambda x, k=4: round(float(x), k)
+    return dict(steps=steps, logged_points=n, initial_psnr_hip=r(hip["psnr"][0]), final_psnr_hip=r(hip["psnr"][-1]), final_psnr_oracle=r(ora["psnr"][-1]),
+                psnr_rise_db=r(rise), max_abs_diff_db=r(max(gap)), second_half_mean_abs_diff_db=r(sum(gap[half:]) / (n - half)),
+                second_half_mean_draw_spread_db=r(sum(spread[half:]) / (n - half)), draw_spread_runs=spread_runs,
+                rel_rot_deg_hip=r(hip["rel_rot"][-1]), rel_rot_deg_oracle=r(ora["rel_rot"][-1]), initial_rel_rot_deg=r(hip["rel_rot"][0]),
+                max_rel_rot_gap_deg=r(max(rot_gap)), seconds=r(time.perf_counter() - t0, 1),
+                sample=f"barf_inn_llff teacher-student scene (analytic density blobs rendered from perturbed poses, training starts at identity poses): "
+                       f"{views} views of {size[0]}x{size[1]}, {R} rays x {S} samples, c2f encoding, alignment term 10^{ga}, both Adam groups under "
+                       f"ExponentialLR, {steps} chained iterations; HIP engine vs the oracle (autograd + torch.optim.Adam through torch's kernels on "
+                       f"this GPU) from identical weights and identical pixel / stratified draws; draw spread = range over the HIP run and "
+                       f"{spread_runs} HIP runs that differ only in their draws; PSNR of the step's photometric loss at every {log_every}th iteration")

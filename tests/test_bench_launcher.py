@@ -120,6 +120,41 @@ def test_cpu_baseline_reports_threads_sample_and_calibration():
     out = bench.cpu_baseline(B=3, S=8, Sf=8, H=12, W=16, budget_s=5.0)
     assert out["kind"] == "port" and out["unit"] == "ray-samples/s" and out["value"] > 0
     assert out["cores"] in {int(k) for k in out["thread_sweep"]} and out["affinity_cores"] >= 1
-    assert "3 views x" in out["sample"] and len(out["seconds_per_step"]) == 2
+    assert "3 views x" in out["sample"] and len(out["seconds_per_step"]) >= 3             # 1 warm-up + >= 3 timed steps
+    assert out["value"] >= out["value_median"] > 0 and out["forward_only_value"] > out["value_median"] and out["cpu_model"]
     assert 0.9 <= out["calibration"]["oracle_over_reference_time"] <= 1.1            # the port times within 10 % of the reference
     assert "r5_oracle_calibration.json" in out["calibration"]["source"]
+
+
+def test_wire_time_of_the_gradient_exchange():
+    """comm_wire_ms of the N > 1 line: a ring all-reduce moves 2 (N - 1) / N x the bucket over one xGMI link per neighbour (153 GB/s)"""
+    import bench
+    assert bench.wire_ms(4_913_232, 1) == 0.0
+    assert abs(bench.wire_ms(4_913_232, 8) - 2 * 7 / 8 * 4_913_232 / 153e9 * 1e3) < 1e-12          # cfg2's bucket: 0.056 ms
+    assert abs(bench.wire_ms(153e9, 2) - 1000.0) < 1e-6
+
+
+def _flag_rank(rank, world, port, ok, q):
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, bench.host_flags_agree("t", ok, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_capture_outcome_is_agreed_on_host_side_with_two_ranks():
+    """the replayed A/B leg of the N > 1 line: every rank learns through the store -- no device work, no collective -- that rank 1's capture
+    failed, before any rank enters a replay's all-reduce"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flag_rank, args=(r, 2, 29877, r == 0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: [1], 1: [1]}

@@ -296,6 +296,15 @@ def test_warp_vs_oracle_and_golden(alpha, exact):
     if exact:
         close(y, gd[f"fwd_a{alpha}"], atol=1e-4)
     close(net.inverse(code, y.detach(), alpha), pts, atol=2e-4)          # round trip
+    # W4 pinned on its own (reference nvp_ndr.py:471-567), not only as the forward's mirror image:
+    # (i) the reference's inverse of the reference's forward output, both in the fixture (the HIP kernel sees the reference's input, not its own)
+    if exact:
+        close(net.inverse(code, g(t(gd[f"fwd_a{alpha}"])), alpha), gd[f"inv_a{alpha}"], atol=2e-4)
+    # (ii) a point set that is NOT the image of the forward, against the float64 oracle inverse
+    gen = torch.Generator().manual_seed(77)
+    arb = (torch.rand(tuple(pts.shape), generator=gen) * 2.4 - 1.2)
+    inv64 = O.warp_inverse({k: v.detach() for k, v in p64.items()}, c64.detach(), arb.double(), alpha, reference_exact=exact)
+    close(net.inverse(code, g(arb), alpha), inv64.float(), atol=2e-4)
     gw = t(gd["gw_a0.3"])
     (y * g(gw)).sum().backward()
     (y64 * gw.double()).sum().backward()

@@ -1,0 +1,75 @@
+"""The driver's N > 1 invocation rehearsed at the widest width a one-GPU box allows (round 6).  The pool's process guard admits six GPU
+processes at a time and this test process is one of them, so the rehearsal here runs FOUR gloo ranks time-slicing this GPU (the driver's
+own N = 4 command line); tools/rehearse_ranks.sh runs six outside pytest and keeps the lines (profiles/r6_bench_lines.json).  Checked: every
+rank is seen, the ranks' parameters agree after the timed steps (bench.py exits non-zero otherwise), losses are finite, the line carries
+the self-diagnosing fields (split_exchange on / off, launched vs replayed, wire time of the bucket) and the run stays far inside the
+driver's 600 s."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RANKS = 4
+
+
+def _driver_line(extra, port, timeout=900):
+    env = dict(os.environ, NIW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(RANKS), "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(RANKS), "--steps", "3", "--warmup", "2"] + extra
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == RANKS and line["ranks_seen"] == RANKS and line["backend"] == "gloo"
+    assert wall < 600, f"{wall:.0f} s: the driver allows 600"
+    return line, wall
+
+
+def test_four_ranks_default_workload_line_is_self_diagnosing():
+    """cfg2 (the driver's default): weak headline + strong, and the A/B legs of the weak workload"""
+    import math
+    line, wall = _driver_line([], 29731)
+    assert line["scaling"] == "weak" and line["strong"]["scaling"] == "strong" and math.isfinite(line["loss"]) and math.isfinite(line["strong"]["loss"])
+    assert line["config"]["rays_per_gpu"] == 18 * 227 and line["strong"]["rays_per_gpu"] in (1021, 1022)
+    se, hg = line["split_exchange"], line["hip_graph_ab"]
+    assert se["on_ms"] > 0 and se["off_ms"] > 0 and se["auto_resolves_to"] == "on"          # weak-scaled cfg2: two rounds of workgroups and more
+    assert se["on"]["comm_exposed_ms"] is not None and se["off"]["comm_ms"] is not None
+    assert hg["launched_ms"] > 0 and (hg["replayed_ms"] is None and "capture_failed" in hg or hg["replayed_ms"] > 0)
+    assert line["comm_bucket_bytes"] == 4 * 1228308 and abs(line["comm_wire_ms"] - 2 * 3 / 4 * 4913232 / 153e9 * 1e3) < 1e-3
+    assert line["comm_ms"] is not None and line["comm_exposed_ms"] is not None
+    print(f"4 gloo ranks, cfg2: {wall:.0f} s wall; weak {line['ms_per_step']:.1f} ms, strong {line['strong']['ms_per_step']:.1f} ms; split exchange on/off "
+          f"{se['on_ms']}/{se['off_ms']} ms; launched/replayed {hg['launched_ms']}/{hg['replayed_ms']} ms")
+
+
+def test_four_ranks_dtu_three_views_leave_a_rank_without_a_view():
+    """cfg5: 3 views x 682 rays over 4 ranks -- rank 3's share lies inside view 2, whose first ray is rank 2's: it owns no view, counts no
+    alignment term, and still all-reduces; 8 ranks leave five such ranks (tools/rehearse_ranks.sh: six ranks, three such)"""
+    import math
+    from neural_invertible_warp_amd import parallel
+    wins = [parallel.ViewWindow(3, 682, r, RANKS) for r in range(RANKS)]
+    assert [w.own1 - w.own0 for w in wins] == [1, 1, 1, 0]
+    line, wall = _driver_line(["--config", "cfg5", "--kernel-steps", "0"], 29733)
+    assert math.isfinite(line["loss"]) and math.isfinite(line["strong"]["loss"])
+    assert line["split_exchange"]["on_ms"] is None and line["split_exchange"]["off_ms"] > 0          # no fine network: nothing to split
+    print(f"4 gloo ranks, cfg5: {wall:.0f} s wall; weak {line['ms_per_step']:.1f} ms, strong {line['strong']['ms_per_step']:.1f} ms")
+
+
+def test_four_ranks_all_eight_scenes_both_placements():
+    """cfg4: ray shard (one all-reduce per scene and step) and the replicas (two scenes per rank at N = 4, no exchange)"""
+    from neural_invertible_warp_amd import configs
+    line, wall = _driver_line(["--config", "cfg4", "--kernel-steps", "0", "--ab", "off"], 29735, timeout=1200)
+    rep = line["replicas"]
+    assert line["placement"] == "shard" and rep["comm_ms"] == 0
+    assert {r["scene"]: r["rank"] for r in rep["scenes"]} == {sc: i % RANKS for i, sc in enumerate(configs.LLFF_TRAIN_VIEWS)}
+    assert line["comm_bucket_bytes"] == 8 * 4 * (698256 - 18 * 128) + 4 * 128 * sum(configs.LLFF_TRAIN_VIEWS.values())
+    print(f"4 gloo ranks, cfg4: {wall:.0f} s wall; shard {line['ms_per_step']:.1f} ms, replicas {rep['ms_per_step']:.1f} ms")
