@@ -708,6 +708,7 @@ def main():
         for tr, *_ in loads:
             if getattr(tr, "fused", None) is not None:
                 tr.fused.ws = None
+        torch.cuda.empty_cache()        # (back to the device, not only to this process's allocator: ranks that time-slice ONE GPU share its memory)
         loads2, desc2 = build_workloads(args.config, dev, rank, world, modes[1], 0, **wl)
         e2 = n_evals(loads2)
         dt2, loss2, graphed2, comm2, _ = timed_run(loads2)
@@ -718,7 +719,11 @@ def main():
                       mlp_evals_per_step_per_gpu=e2, rays_per_gpu=sum(int(round(B * R)) for _, _, B, R, _, _ in loads2),
                       frac_of_train_roofline=round(v2 / world * 3 * FLOP_FWD / 1e12 / peak_mfma, 4), comm_ms=None if comm2 is None else round(comm2, 4),
                       comm_exposed_ms=None if comm2_exposed is None else round(comm2_exposed, 4), loss=loss2, hip_graph=graphed2, workload=desc2 + f"; the reference's batch split over {world} ranks")
+        for tr, *_ in loads2:
+            if getattr(tr, "fused", None) is not None:
+                tr.fused.ws = None
         del loads2
+        torch.cuda.empty_cache()
 
     # cfg4: the other placement of the eight scenes, same processes, right after -- scene i WHOLE on rank i mod N, no gradient exchange
     # ("report both").  Also the line's own figures when --placement replicas was asked for.
@@ -753,6 +758,7 @@ def main():
             for tr, *_ in loads:
                 if getattr(tr, "fused", None) is not None:
                     tr.fused.ws = None
+            torch.cuda.empty_cache()
             loads_r, desc_r = build_workloads(args.config, dev, rank, world, "strong", args.shard_of, placement="replicas", **wl)
             e_r = n_evals(loads_r)
             dt_r, loss_r, graphed_r, comm_r, _ = timed_run(loads_r) if loads_r else (0.0, 0.0, False, (None, None), None)
@@ -767,7 +773,11 @@ def main():
                         scenes=scene_table(loads_r), hip_graph=graphed_r, workload=desc_r,
                         note="a step = one train iteration of every scene this rank holds; ranks holding more scenes (N < 8: scene i on rank i mod N) set the pace")
         if placement != "replicas":
+            for tr, *_ in loads_r:
+                if getattr(tr, "fused", None) is not None:
+                    tr.fused.ws = None
             del loads_r
+            torch.cuda.empty_cache()
 
     # bucket bytes one iteration exchanges (all trainers of the step) and their algorithmic wire time over one xGMI link per neighbour
     bucket_bytes = sum(4 * tr.bucket.flat.numel() for tr, *_ in loads if getattr(tr, "collectives", False))
@@ -784,6 +794,7 @@ def main():
             for tr, *_ in loads_:
                 if getattr(tr, "fused", None) is not None:
                     tr.fused.ws = None
+            torch.cuda.empty_cache()
 
         def leg(loads_):
             dt_, _, graphed_, comm_, _ = timed_run(loads_, exit_on_capture_error=False)

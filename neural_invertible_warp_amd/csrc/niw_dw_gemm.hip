@@ -16,8 +16,10 @@
 #include <type_traits>
 #include <stdlib.h>
 #include <atomic>
+#include "niw_trace.h"
 
 using namespace niw;
+NIW_TRACE_SETTER(niw_trace_set_dw)
 
 int niw_launch_mlp_bwd_dx(const float* packed, const float* center, const float* ray, const float* depth,
                           int64_t n_rays, int n_samples, int density_activ, const float* rgb, const float* d_rgb,
@@ -89,6 +91,8 @@ struct BlockMap {
 template <int WN, int WK, int NBW, int KBW, bool SKIP, int PF, bool QUAD>
 __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, int steps_total, int steps_per_wg,
                                                                float* __restrict__ partial, BlockMap map) {
+    constexpr int kTraceKind = WN * 1000 + WK * 100 + NBW * 10 + KBW;       // 4224: wide tile, 8112: skinny, 4215: colour, 4212: quadrant tile
+    NIW_STAMP_KIND(0, kTraceKind);
     int bx = blockIdx.x, by = blockIdx.y, nx = gridDim.x;
     if (map.groups_pad > 0) {
         const int member = (int)blockIdx.x / map.groups_pad, group = (int)blockIdx.x % map.groups_pad;
@@ -234,11 +238,13 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
     if (PF >= 2 && nsteps > 1) gload(step0 + 1, 1 % PF);
     if (PF >= 3 && nsteps > 2) gload(step0 + 2, 2 % PF);
     __syncthreads();
+    NIW_STAMP_KIND(1, kTraceKind);                   // first slice in LDS: the first matrix instruction follows
     for (int s = 0; s < nsteps; s += PF) {
         step_body(s, std::integral_constant<int, 0>{});
         if (PF >= 2 && s + 1 < nsteps) step_body(s + 1, std::integral_constant<int, 1 % PF>{});
         if (PF >= 3 && s + 2 < nsteps) step_body(s + 2, std::integral_constant<int, 2 % PF>{});
     }
+    NIW_STAMP_KIND(2, kTraceKind);                   // reduction done: the partial tile follows
     // partial tile [TN][TK] (+ TN-or-TK bias sums) of this workgroup
     float* out = partial + ((long long)by * nx + bx) * (TN * TK + 256);
 #pragma unroll
@@ -249,6 +255,7 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
             for (int r = 0; r < 16; ++r)
                 out[((wn * NBW + x) * 32 + acc_row(r, h)) * TK + (wk * KBW + y) * 32 + i] = acc[x][y][r];
     if (tid < 256) out[TN * TK + tid] = bsum;
+    NIW_STAMP_KIND(3, kTraceKind);
 }
 
 // The same product in the fast-precision modes (include/niw.h NIW_PREC_BF16X3 / NIW_PREC_BF16): the fp32 operands (quad-row images

@@ -9,8 +9,10 @@
 #include "niw_common.h"
 #include "niw_mlp_device.h"
 #include "niw_mlp_encode.h"
+#include "niw_trace.h"
 
 using namespace niw;
+NIW_TRACE_SETTER(niw_trace_set_bwd)
 
 struct MlpBwdArgs {
     const float* packed;
@@ -92,6 +94,7 @@ struct AddStashEpilogue {
 // enc_backward(): niw_mlp_encode.h (shared with the fast-precision dX chain)
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
+    NIW_STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     }
     reinterpret_cast<f32x4*>(a.grad + (long long)kGradRgb1 * P)[qoff] = f32x4{dy9[0], dy9[1], dy9[2], dy9[3]};   // rows 4h + t of the 8-row slot block
     float dyr[64];
+    NIW_STAMP(1);                                    // colour head done: the first matrix instruction follows
     {
         MaskEpilogue<4> ep{mk_cur, zero, dyr, gwin(kGradRgb0)};
         stream_layer<1, 0, 4, 4>(pw, wp + bwd_pack_off(9) / 4, dy9, none, ep);
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         MaskEpilogue<8> ep{mk_cur, zero, dy, gwin(kGradY7)};
         stream_layer<16, 0, 8, 9>(pw, wp + bwd_pack_off(8) / 4, dyr, none, ep);
     }
+    NIW_STAMP(2);                                    // colour layers transposed
     // ---- density head: d sigma_raw (kernel row 256 of layer 7)
     float dsig[4] = {0.f, 0.f, 0.f, 0.f};
     {
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         stream_layer<32, 1, 8, 8>(pw, wp + bwd_pack_off(7) / 4, dy, dsig, ep);
         advance();
     }
+    NIW_STAMP(3);
     // ---- layers 6, 5 transposed: produce dY5, dY4
 #pragma unroll 1
     for (int l = 6; l >= 5; --l) {
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         MaskEpilogue<8> ep{mk_cur, zero, nxt, gwin((l - 1) * 256)};
         stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(5) / 4 + (l - 5) * (32 * 8 * 64), dy, none, ep);
         advance();
+        NIW_STAMP(10 - l);                           // 4: layer 6, 5: layer 5
     }
     // ---- layer 4 transposed: 256 -> 256 features (+ 64 encoding slots = row blocks 8, 9 of 10)
     if (a.ray_grad) {
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         stream_layer<32, 0, 8, 10>(pw, wp + bwd_pack_off(4) / 4, dy, none, ep);
         advance();
     }
+    NIW_STAMP(6);
     // ---- layers 3, 2, 1 transposed: produce dY2, dY1, dY0
 #pragma unroll 1
     for (int l = 3; l >= 1; --l) {
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
         MaskEpilogue<8> ep{mk_cur, zero, nxt, gwin((l - 1) * 256)};
         stream_layer<32, 0, 8, 8>(pw, wp + bwd_pack_off(1) / 4 + (l - 1) * (32 * 8 * 64), dy, none, ep);
         advance();
+        NIW_STAMP(10 - l);                           // 7, 8, 9: layers 3, 2, 1
     }
     if (!a.ray_grad) return;
     // ---- layer 0 transposed: 256 -> 64 encoding slots (+ the parked skip-connection part)
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     // and need no zero-fill.
     reinterpret_cast<f32x4*>(a.grad + (long long)kGradStashEnc * P)[qoff] =
         h == 0 ? f32x4{gc[0], gc[1], gc[2], gr[0]} : f32x4{gr[1], gr[2], 0.f, 0.f};
+    NIW_STAMP(10);
 }
 
 // d_center[r], d_ray[r] = sum over the S samples of ray r of the parked per-sample gradients: one wave per ray, every lane a strided

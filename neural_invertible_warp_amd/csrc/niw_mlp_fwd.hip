@@ -15,8 +15,10 @@
 #include "niw_common.h"
 #include "niw_mlp_device.h"
 #include "niw_mlp_encode.h"
+#include "niw_trace.h"
 
 using namespace niw;
+NIW_TRACE_SETTER(niw_trace_set_fwd)
 
 // fast-precision modes: niw_mlp_fast.hip
 extern "C" int64_t niw_mlp_fast_image_bytes(void);
@@ -196,6 +198,7 @@ __device__ __forceinline__ float density_act(float x, int kind) {
 
 template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
+    NIW_STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + j;
@@ -272,13 +275,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         stream_layer<32, 0, 8, 8, decltype(ep), true, true>(pw, wp + w_bytes(l) / 16, in, none, ep, &carry, next_of(l));
     };
     // ---- layer 0: 63 -> 256
+    NIW_STAMP(1);                                    // encodings done: the first matrix instruction follows
     {
         FwdEpilogue<8, true, SAVE> ep{pw, b_bytes(0), hoff, xa, xb, window(save_h(1)), 0.f, mask_rec(0), lane};
         stream_layer<8, 0, 8, 8, decltype(ep), false, true>(pw, wp + fwd_pack_off(0) / 4, enc, none, ep, &carry, next_of(0));
     }
+    NIW_STAMP(2);
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) {
         plain(2 * k + 1, xa, xb);                    // layers 1, 3, 5
+        NIW_STAMP(3 + 2 * k);
         if (k != 1) {
             plain(2 * k + 2, xb, xa);                // layers 2, 6
         } else {
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
             FwdEpilogue<8, true, SAVE> ep{pw, b_bytes(4), hoff, xa, xb, window(save_h(5)), 0.f, mask_rec(4), lane};
             stream_layer<32, 8, 8, 8, decltype(ep), true, true>(pw, wp + fwd_pack_off(4) / 4, xb, enc, ep, &carry, next_of(4));
         }
+        NIW_STAMP(4 + 2 * k);
     }
     // ---- layer 7: 256 -> 256 features (+ density row 256 = row block 8)
     {
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
             if (valid) a.sigma[m] = density_act(sig_raw, a.act);
         }
     }
+    NIW_STAMP(9);
     // ---- colour layer 0: cat[feat, view_enc] (283) -> 128
     // ---- colour layer 1 (128 -> 3, sigmoid) rides on layer 0's epilogue: three FMAs per hidden value as it is produced
     float hr[64];
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
             for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-o[c]));
         }
     }
+    NIW_STAMP(10);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Rehearsal of the driver's N > 1 invocation on ONE GPU (round 6): `python bench.py --gpus N` -- the launcher parent never touches the GPU and
 # starts N gloo ranks that time-slice the device -- for the default workload (cfg2), all eight LLFF scenes in both placements (cfg4) and the
-# three-view DTU config (cfg5).  N defaults to 6: the pool's process guard admits six GPU processes at a time, so EIGHT ranks cannot be run
-# on these boxes; six still covers what four does not (cfg5: three ranks own no view; cfg4 replicas: 8 scenes over 6 ranks, two ranks hold
-# two).  Keeps every line and the wall time of each run under gpurun_out/r6_ranks/.
+# three-view DTU config (cfg5).  N defaults to 5: the pool's process guard admits six GPU processes at a time and torch.distributed.run's agent counts as one
+# (six ranks: "7 processes had the GPU open (limit 6)", run killed), so EIGHT ranks cannot be run on these boxes; five still covers what four
+# does not (an odd world: shares that cut views unevenly; cfg5: two ranks own no view; cfg4 replicas: 8 scenes over 5 ranks, three ranks hold two).  Keeps every line and the wall time of each run under gpurun_out/r6_ranks/.
 #   bash tools/rehearse_ranks.sh [N]
 set -u
-N=${1:-6}
+N=${1:-5}
 OUT=gpurun_out/r6_ranks
 mkdir -p $OUT
 export NIW_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
