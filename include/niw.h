@@ -188,6 +188,11 @@ int niw_sample_stratified(const float* u, int64_t n_rays, int n_samples, double 
 int niw_sample_stratified_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n_rays, int n_samples,
                               double depth_min, double depth_max, int inverse, float* depth, float* u_out, niw_stream_t stream);
 
+/* Density noise of the train-mode field forward (reference model/nerf.py:428-429: `density += torch.randn_like(density) * density_noise_reg`)
+ * drawn on the device: out[i] = scale * z_i, z ~ N(0, 1) by Box-Muller over the Philox4x32-10 stream of niw_sample_stratified_rng (counter =
+ * (i / 4, draw), key = seed; draw_dev as there).  The result is what niw_mlp_fwd takes as `noise`.  A pure function of (seed, draw, i). */
+int niw_normal_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n, float scale, float* out, niw_stream_t stream);
+
 /* Graph.sample_depth_from_pdf (model/nerf.py:346-365) followed by the cat + ascending sort of
  * Graph.render (model/nerf.py:313-315).  pdf [n_rays,S], depth_coarse [n_rays,S];
  * unif [Sf] = mid-points of linspace(0,1,Sf+1) (nerf.py:352-353) and bins [S+1] =
@@ -475,6 +480,18 @@ typedef struct niw_train_desc {
      * optimizer group whose gradients are final, a third of the way into the backward.  A data-parallel caller makes its communication
      * stream wait for it and exchanges that group while the coarse network's and the warp's backward are still running (engine.py). */
     void* fine_grads_ready;
+    /* ---- round 6: the VANILLA model's iteration (reference model/nerf.py:251-288: Graph.forward + compute_loss in train mode on the
+     * ground-truth poses; BASELINE configs[0], options/nerf_llff_repr.yaml).  warp_params == NULL selects it: rays of the cameras
+     * `pose_init` (then REQUIRED: world->camera [n_views,3,4]; niw_raygen mode 1), no warp, no registration / alignment term
+     * (w_align must be negative), no ray gradients (the dX chain stops above layer 0, SURVEY section 8(a) "Gradient routes");
+     * latent / d_warp / d_latent / poses are not touched and may be NULL.  With a warp, `density_noise` applies likewise and `ndc`
+     * is refused (the NDC gradient into the warp exists only on the autograd mirror). */
+    float density_noise;        /* opt.nerf.density_noise_reg: N(0, density_noise^2) added to the raw density of every sample in BOTH passes
+                                   (model/nerf.py:428-429), drawn by niw_normal_rng(noise_seed [+ 1 for the fine pass], draw); 0: none */
+    int32_t ndc;                /* opt.camera.ndc: rays re-parametrised by niw_convert_ndc (camera.py:523-540) */
+    uint64_t noise_seed;
+    float ndc_near;             /* near plane of the NDC re-parametrisation (the reference passes 1) */
+    int32_t reserved2;
 } niw_train_desc;
 
 /* Optional: create the library's own streams (niw_train_desc.overlap; niw_mlp_bwd_dw's second stream) for the current device NOW instead

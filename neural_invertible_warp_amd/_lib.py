@@ -44,7 +44,8 @@ class TrainDesc(ctypes.Structure):
                 ("warp_params", _vp), ("latent", _vp), ("chan_w", _fp), ("index_window", _fp), ("window_dev", _vp),
                 ("w_render", _f), ("w_render_fine", _f), ("w_align", _f), ("always_register", _i32), ("mse_norm", _d),
                 ("loss", _vp), ("d_nerf", _vp), ("d_nerf_fine", _vp), ("d_warp", _vp), ("d_latent", _vp), ("poses", _vp),
-                ("rgb", _vp), ("rgb_fine", _vp), ("overlap", _i32), ("reserved", _i32), ("fine_grads_ready", _vp)]
+                ("rgb", _vp), ("rgb_fine", _vp), ("overlap", _i32), ("reserved", _i32), ("fine_grads_ready", _vp),
+                ("density_noise", _f), ("ndc", _i32), ("noise_seed", _u64), ("ndc_near", _f), ("reserved2", _i32)]
 
 
 # train stages (enum niw_train_stage), in execution order
@@ -73,6 +74,7 @@ SIGNATURES = {
     "niw_mse_from_residuals": (_i, [_vp, _i64, _d, _vp, _vp]),
     "niw_sample_stratified": (_i, [_vp, _i64, _i, _d, _d, _i, _vp, _vp]),
     "niw_sample_stratified_rng": (_i, [_u64, _u64, _vp, _i64, _i, _d, _d, _i, _vp, _vp, _vp]),
+    "niw_normal_rng": (_i, [_u64, _u64, _vp, _i64, _f, _vp, _vp]),
     "niw_sample_pdf_merge": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "niw_raygen": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "niw_draw_ray_idx": (_i, [_i64, _i64, _u64, _u64, _vp, _i64, _i64, _vp, _vp]),

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * WN * WK) void dw_gemm_kernel(GemmBatch batch, 
             for (int r = 0; r < 16; ++r)
                 out[((wn * NBW + x) * 32 + acc_row(r, h)) * TK + (wk * KBW + y) * 32 + i] = acc[x][y][r];
     if (tid < 256) out[TN * TK + tid] = bsum;
-    NIW_STAMP_KIND(3, kTraceKind);
+    NIW_STAMP_KIND_LAST(3, kTraceKind);
 }
 
 // The same product in the fast-precision modes (include/niw.h NIW_PREC_BF16X3 / NIW_PREC_BF16): the fp32 operands (quad-row images

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_dx_kernel(MlpBwdArgs a) {
     // and need no zero-fill.
     reinterpret_cast<f32x4*>(a.grad + (long long)kGradStashEnc * P)[qoff] =
         h == 0 ? f32x4{gc[0], gc[1], gc[2], gr[0]} : f32x4{gr[1], gr[2], 0.f, 0.f};
-    NIW_STAMP(10);
+    NIW_STAMP_LAST(10);
 }
 
 // d_center[r], d_ray[r] = sum over the S samples of ray r of the parked per-sample gradients: one wave per ray, every lane a strided

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         const float nrm = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
         u[0] = rx / nrm; u[1] = ry / nrm; u[2] = rz / nrm;
     }
+    NIW_STAMP(11);                                   // inputs of the sample are in registers; the encodings follow
     float enc[32], venc[16];
     {
         float w3[NIW_L3D], wv[NIW_LVIEW];
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
         encode_slots<NIW_L3D, 8>(p, w3, h, enc);
         encode_slots<NIW_LVIEW, 4>(u, wv, h, venc);
     }
+    NIW_STAMP(12);                                   // encodings in registers; their stores (training) follow
     // Workspace layout: the quad-row image of niw_mlp_device.h ([row / 4][Mpad][4]; rows >= kSaveSigma -- raw density and the mask
     // records -- stay plain [row][Mpad]).  (A blocked [128-sample block][row][128] image was measured 10-14 % slower for this
     // kernel and the dX chain on MI355X.)
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(MlpFwdArgs a) {
             for (int c = 0; c < 3; ++c) a.rgb[m * 3 + c] = 1.f / (1.f + expf(-o[c]));
         }
     }
-    NIW_STAMP(10);
+    NIW_STAMP_LAST(10);
 }
 
 // ---------------------------------------------------------------------------------------

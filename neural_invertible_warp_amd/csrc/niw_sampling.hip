@@ -57,6 +57,35 @@ __global__ void sample_stratified_rng_kernel(unsigned long long seed, unsigned l
     }
 }
 
+// Density noise (reference model/nerf.py:428-429: density += randn_like(density) * density_noise_reg in train mode) drawn in a kernel:
+// the same Philox4x32-10 stream layout as the stratified draw -- counter = (group of four consecutive samples, draw number), key = seed --
+// and Box-Muller on the two uniform pairs of a counter value: r = sqrt(-2 ln u1) with u1 in (0, 1] from the upper 24 bits, theta = 2 pi u2;
+// samples 4g .. 4g+3 = r1 cos t1, r1 sin t1, r2 cos t2, r2 sin t2, times `scale`.  fp32 libm (logf, sqrtf, sincosf): a pure function of
+// (seed, draw, sample index), reproducible and replayable from a captured graph (draw_dev); the reference's torch.randn stream is not
+// reproduced (no fixture could pin it: the reference draws on whatever device it runs on), its distribution is.
+__global__ void normal_rng_kernel(unsigned long long seed, unsigned long long draw, const unsigned long long* __restrict__ draw_dev, long long n,
+                                  float scale, float* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * g >= n) return;
+    if (draw_dev) draw = *draw_dev;
+    unsigned c[4] = {(unsigned)g, (unsigned)(g >> 32), (unsigned)draw, (unsigned)(draw >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    float z[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float u1 = (float)((c[2 * t] >> 8) + 1u) * 5.9604644775390625e-08f;        // (0, 1]
+        const float u2 = (float)(c[2 * t + 1] >> 8) * 5.9604644775390625e-08f;           // [0, 1)
+        const float r = sqrtf(niw::mul_rn(-2.f, logf(u1)));
+        float sn, cs;
+        sincosf(niw::mul_rn(6.28318530717958647692f, u2), &sn, &cs);
+        z[2 * t] = niw::mul_rn(r, cs);
+        z[2 * t + 1] = niw::mul_rn(r, sn);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (4 * g + t < n) out[4 * g + t] = niw::mul_rn(z[t], scale);
+}
+
 // ---------------------------------------------------------------- H1 + H2: nerf.py:346-365, 313-315
 // One wave per ray.  cdf in LDS (accumulated sequentially in fp64 and rounded per element, the
 // arithmetic of the CPU reference's cumsum), Sf binary searches, then a rank sort of the S+Sf
@@ -407,6 +436,14 @@ extern "C" int niw_sample_stratified_rng(uint64_t seed, uint64_t draw, const uin
     sample_stratified_rng_kernel<<<(int)((groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         seed, draw, reinterpret_cast<const unsigned long long*>(draw_dev), n, n_samples, (float)depth_min, (float)(depth_max - depth_min), inverse, depth, u_out);
     NIW_LAUNCH_CHECK("niw_sample_stratified_rng");
+    return NIW_OK;
+}
+
+extern "C" int niw_normal_rng(uint64_t seed, uint64_t draw, const uint64_t* draw_dev, int64_t n, float scale, float* out, niw_stream_t stream) {
+    NIW_REQUIRE(out && n > 0, "niw_normal_rng: null output or empty draw");
+    const long long groups = (n + 3) / 4;
+    normal_rng_kernel<<<(int)((groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, draw, reinterpret_cast<const unsigned long long*>(draw_dev), n, scale, out);
+    NIW_LAUNCH_CHECK("niw_normal_rng");
     return NIW_OK;
 }
 

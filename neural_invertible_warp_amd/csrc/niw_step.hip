@@ -254,6 +254,7 @@ struct Layout {
     float *z_all, *rgb_f, *sigma_f, *rgb_fine, *depth_fine, *opacity_fine;
     float *packed_c, *packed_f, *save_c, *save_f, *gradws, *partial;
     float *d_rgb, *d_rgb_f, *d_rgb_s, *d_sigma_s, *comp_d_ray_c, *comp_d_ray_f, *mlp_d_c, *mlp_d_f;   // mlp_d_*: [2][n][3] = {d_center, d_ray}
+    float *noise_c, *noise_f;        // density noise of the two passes (density_noise > 0)
     float *resid_c, *resid_f, *d_rgb_s_c, *d_sigma_s_c;   // one-launch compositing + loss + backward: residuals [n,3]; the coarse pass's own sample gradients
     float *mom, *poses, *d_target, *d_warped, *warp_ws, *d_w_emb, *d_view_b, *d_w_head, *prep_bwd_ws;
     long long total;
@@ -261,8 +262,18 @@ struct Layout {
 
 int check_desc(const niw_train_desc* d) {
     NIW_REQUIRE(d, "niw_train_step: null descriptor");
-    NIW_REQUIRE(d->image && d->intr && d->nerf_params && d->warp_params && d->latent, "niw_train_step: batch, field parameters, warp parameters and latent table are required");
-    NIW_REQUIRE(d->loss && d->d_nerf && d->d_warp && d->d_latent, "niw_train_step: loss and gradient outputs are required");
+    NIW_REQUIRE(d->image && d->intr && d->nerf_params, "niw_train_step: batch and field parameters are required");
+    NIW_REQUIRE(d->loss && d->d_nerf, "niw_train_step: loss and gradient outputs are required");
+    if (d->warp_params) {
+        NIW_REQUIRE(d->latent && d->d_warp && d->d_latent, "niw_train_step: the warp needs its latent table and the two gradient outputs");
+        NIW_REQUIRE(!d->ndc, "niw_train_step: camera.ndc with warped rays runs on the autograd mirror (the NDC gradient into the warp)");
+    } else {
+        // the vanilla model (model/nerf.py:251-288): rays of the given cameras, nothing pose-related is trained
+        NIW_REQUIRE(d->pose_init, "niw_train_step: without a warp the rays come from the cameras `pose_init` (world->camera, required)");
+        NIW_REQUIRE(d->w_align < 0.f && !d->always_register, "niw_train_step: the alignment term / registration need the warp");
+        NIW_REQUIRE(!d->ndc || d->ndc_near > 0.f, "niw_train_step: ndc_near=%g", (double)d->ndc_near);
+    }
+    NIW_REQUIRE(d->density_noise >= 0.f, "niw_train_step: density_noise=%g", (double)d->density_noise);
     NIW_REQUIRE(d->n_views > 0 && d->n_views <= 64 && d->H > 0 && d->W > 0 && d->rays_per_view > 0, "niw_train_step: n_views=%d (1..64) H=%d W=%d rays_per_view=%lld",
                 d->n_views, d->H, d->W, (long long)d->rays_per_view);
     NIW_REQUIRE(d->rays_per_view <= (int64_t)d->H * d->W, "niw_train_step: %lld rays per view from a %d x %d image", (long long)d->rays_per_view, d->H, d->W);
@@ -325,6 +336,7 @@ Layout make_layout(const niw_train_desc* d, float* base) {
     L.resid_c = ws.take(3 * n);
     L.d_rgb_s_c = L.d_rgb_s; L.d_sigma_s_c = L.d_sigma_s;
     if (T) { L.resid_f = ws.take(3 * n); L.d_rgb_s_c = ws.take(3 * n * S); L.d_sigma_s_c = ws.take(n * S); }
+    if (d->density_noise > 0.f) { L.noise_c = ws.take(n * S); if (T) L.noise_f = ws.take(n * T); }
     L.mom = ws.take(2 * 16 * L.V);                     // double [V,16]
     L.poses = ws.take(12 * L.V);
     L.d_target = ws.take(3 * P); L.d_warped = ws.take(3 * P);
@@ -377,6 +389,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     const float* center = L.center + 3 * a;
     const int64_t* ray_idx = reinterpret_cast<const int64_t*>(L.ray_idx);
     const bool fine = T > 0;
+    const bool warp = d->warp_params != nullptr;     // false: the vanilla model on the given cameras
     const bool loss_c = d->w_render >= 0.f, loss_f = fine && d->w_render_fine >= 0.f, align = d->w_align >= 0.f;
     const bool registration = align || d->always_register;
     float* poses = d->poses ? d->poses + 12ll * d->view0 : L.poses;
@@ -386,7 +399,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     auto in = [&](int s) { return stage_begin <= s && s < stage_end; };
 
     // second stream (niw.h: overlap): X carries the small independent stages, `stream` the field-MLP chain
-    SideLane* lane = (d->overlap && stage_begin == 0 && stage_end == NIW_STAGE_END) ? side_lane() : nullptr;
+    SideLane* lane = (warp && d->overlap && stage_begin == 0 && stage_end == NIW_STAGE_END) ? side_lane() : nullptr;   // (the vanilla chain has nothing to run beside it)
     SideLaneHold hold(lane, st);
     hipStream_t X = lane ? lane->s : st;
     niw_stream_t sx = (niw_stream_t)X;
@@ -394,18 +407,32 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     if (in(NIW_STAGE_FRONT)) {
         const bool gather = d->precision == NIW_PREC_FP32 && d->pack_index;
         long long pad_rows = 0, ppad = 0, n_cols = 0;
-        niw_warp_bwd_pad_geometry((int)V, 2 * R, &pad_rows, &ppad, &n_cols);
+        if (warp) niw_warp_bwd_pad_geometry((int)V, 2 * R, &pad_rows, &ppad, &n_cols);
         NIW_RUN(niw_launch_step_front((int64_t)d->H * d->W, d->pixel_seed, d->draw, d->draw_dev, d->intr + 9ll * d->view0,
                                       d->pose_init ? d->pose_init + 12ll * d->view0 : nullptr, (int)V, R, d->H, d->W, reinterpret_cast<int64_t*>(L.ray_idx),
                                       L.stacked_in, d->depth_seed, d->stratified, n, S, d->depth_min, d->depth_max, d->inverse_depth, L.z, d->nerf_params,
                                       fine ? d->nerf_fine_params : nullptr, d->pack_index, gather ? L.packed_c : nullptr, gather && fine ? L.packed_f : nullptr,
-                                      L.warp_ws, pad_rows, ppad, n_cols, d->warp_params, d->latent + 128ll * d->view0, (int)V, L.prep_ws, st));
+                                      warp ? L.warp_ws : nullptr, pad_rows, ppad, n_cols, d->warp_params, warp ? d->latent + 128ll * d->view0 : nullptr, (int)V,
+                                      warp ? L.prep_ws : nullptr, st));
+        // density noise of both passes (model/nerf.py:428-429): streams keyed like the depth draw, the fine pass one key further
+        if (d->density_noise > 0.f) {
+            NIW_RUN(niw_normal_rng(d->noise_seed, d->draw, d->draw_dev, n * S, d->density_noise, L.noise_c, stream));
+            if (fine) NIW_RUN(niw_normal_rng(d->noise_seed + 1, d->draw, d->draw_dev, n * T, d->density_noise, L.noise_f, stream));
+        }
         if (!gather) {                      // split-bf16 images, or no gather table: the packing kernels of the entry points
             NIW_RUN(pack(d, d->nerf_params, L.packed_c, stream));
             if (fine) NIW_RUN(pack(d, d->nerf_fine_params, L.packed_f, stream));
         }
     }
-    if (in(NIW_STAGE_WARP_FWD)) {
+    if (in(NIW_STAGE_WARP_FWD) && !warp) {
+        // the vanilla model: camera centres and rays of the drawn pixels (camera.get_center_and_ray, camera.py:419-443), re-parametrised
+        // in NDC when asked (camera.py:523-540) -- the entry points the mirror calls, nothing to differentiate
+        float* c0 = d->ndc ? L.warped : L.center;            // (NDC: camera-frame rays parked where a warp would put its points)
+        float* r0 = d->ndc ? L.warped + 3 * V * R : L.ray;
+        NIW_RUN(niw_raygen(d->intr + 9ll * d->view0, d->pose_init + 12ll * d->view0, ray_idx, 0, (int)V, R, d->H, d->W, 1, c0, r0, stream));
+        if (d->ndc) NIW_RUN(niw_convert_ndc(c0, r0, d->intr + 9ll * d->view0, (int)V, R, d->ndc_near, L.center, L.ray, stream));
+    }
+    if (in(NIW_STAGE_WARP_FWD) && warp) {
         // (the code projection at the head of prep_ws was made by the front kernel)
         NIW_RUN(niw_launch_warp_prep_fwd_main(d->warp_params, (int)V, L.prep_ws, L.w_emb, L.view_b, L.w_head, st));
         NIW_RUN(niw_warp_fwd(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window, nullptr,
@@ -428,7 +455,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     }
     // ---- main: field forward(s), compositing, photometric loss(es), their backward
     if (in(NIW_STAGE_MLP_FWD))
-        NIW_RUN(niw_mlp_fwd(L.packed_c, center, ray, L.z, nullptr, n, S, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_s, L.sigma_s,
+        NIW_RUN(niw_mlp_fwd(L.packed_c, center, ray, L.z, L.noise_c, n, S, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_s, L.sigma_s,
                             (loss_c ? L.save_c : nullptr), stream));
     // compositing + photometric residual + their backward as ONE launch per pass wherever the span kernels cover the sample count
     // (niw_composite_mse_train; NIW_TRAIN_ONE_LAUNCH_LOSS=0: the three launches, diagnostic); the loss values are then formed by the
@@ -447,7 +474,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     if (fine) {
         if (in(NIW_STAGE_RESAMPLE)) NIW_RUN(niw_sample_pdf_merge(L.prob, L.z, d->unif, d->bins, n, S, d->n_fine, nullptr, L.z_all, stream));
         if (in(NIW_STAGE_MLP_FWD_FINE))
-            NIW_RUN(niw_mlp_fwd(L.packed_f, center, ray, L.z_all, nullptr, n, T, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_f,
+            NIW_RUN(niw_mlp_fwd(L.packed_f, center, ray, L.z_all, L.noise_f, n, T, d->band_w3d, d->band_wview, d->band_dev, d->density_activ, d->precision, L.rgb_f,
                                 L.sigma_f, (loss_f ? L.save_f : nullptr), stream));
         if (in(NIW_STAGE_COMPOSITE_FWD_FINE)) {
             if (one_f)
@@ -470,7 +497,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
                 NIW_RUN(niw_composite_bwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, L.d_rgb_f, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
             if (in(NIW_STAGE_MLP_BWD_DX_FINE))
                 NIW_RUN(niw_mlp_bwd_dx(L.packed_f, center, ray, L.z_all, n, T, d->density_activ, d->precision, L.rgb_f, L.d_rgb_s, L.d_sigma_s, L.save_f, L.gradws,
-                                       L.mlp_d_f, L.mlp_d_f + 3 * n, stream));
+                                       warp ? L.mlp_d_f : nullptr, warp ? L.mlp_d_f + 3 * n : nullptr, stream));
             if (in(NIW_STAGE_MLP_BWD_DW_FINE)) NIW_RUN(niw_mlp_bwd_dw(L.save_f, L.gradws, n, T, d->precision, L.partial, d->d_nerf_fine, stream));
         } else if (in(NIW_STAGE_MLP_BWD_DW_FINE)) {
             NIW_RUN(fill(d->d_nerf_fine, NIW_NERF_PARAM_FLOATS, 0.f, st));
@@ -481,8 +508,8 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         if (in(NIW_STAGE_COMPOSITE_BWD) && !one_c)
             NIW_RUN(niw_composite_bwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, L.d_rgb, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_c, stream));
         if (in(NIW_STAGE_MLP_BWD_DX))
-            NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, d_rgb_s_c, d_sigma_s_c, L.save_c, L.gradws, L.mlp_d_c,
-                                   L.mlp_d_c + 3 * n, stream));
+            NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, d_rgb_s_c, d_sigma_s_c, L.save_c, L.gradws,
+                                   warp ? L.mlp_d_c : nullptr, warp ? L.mlp_d_c + 3 * n : nullptr, stream));
     }
     if (lane) {
         NIW_HIP(hipEventRecord(lane->dx, st), "dx");
@@ -502,23 +529,25 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         c.d_center[0] = loss_f ? L.mlp_d_f : nullptr; c.d_center[1] = loss_c ? L.mlp_d_c : nullptr;
         c.d_target = (align && L.n_own > 0) ? L.d_target : nullptr;
         c.d_warped = L.d_warped;
-        c.V = V; c.R = R; c.a = a; c.b = a + n;
+        c.V = warp ? V : 0; c.R = R; c.a = a; c.b = a + n;      // (vanilla: no gradient route to sum, the kernel only closes the losses)
         c.own_lo = (int)own_off; c.own_hi = (int)own_off + L.n_own;
         c.w_align = d->w_align;
-        c.d_latent = d->d_latent; c.lat_lo = 128ll * d->view0; c.lat_hi = 128ll * d->view1; c.lat_n = 128ll * d->n_views;
+        c.d_latent = warp ? d->d_latent : nullptr; c.lat_lo = 128ll * d->view0; c.lat_hi = 128ll * d->view1; c.lat_n = warp ? 128ll * d->n_views : 0;
         c.loss = d->loss;
         c.w[0] = d->w_render; c.w[1] = d->w_render_fine; c.w[2] = d->w_align;
         c.present[0] = loss_c; c.present[1] = loss_f; c.present[2] = align && L.n_own > 0;
         c.resid[0] = one_c ? L.resid_c : nullptr; c.resid[1] = one_f ? L.resid_f : nullptr;
         c.resid_n = 3 * n; c.n_norm = d->mse_norm;
-        const long long work = V * R * 3 > c.lat_n ? V * R * 3 : c.lat_n;
+        const long long work = warp ? (V * R * 3 > c.lat_n ? V * R * 3 : c.lat_n) : 1;
         combine_kernel<<<(unsigned)((work + 255) / 256), 256, 0, X>>>(c);
         NIW_LAUNCH_CHECK("niw_train_step (combine)");
+        if (warp) {
         NIW_RUN(niw_launch_warp_bwd_main(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window,
                                          nullptr, nullptr, L.xin, L.d_warped, L.warp_ws, L.d_w_emb, L.d_view_b, L.d_w_head, nullptr, X));
         // (the code projection of the forward's operand preparation is still at the head of its workspace)
         NIW_RUN(niw_launch_warp_prep_bwd(d->warp_params, d->latent + 128ll * d->view0, (int)V, L.d_w_emb, L.d_view_b, L.d_w_head, L.prep_bwd_ws, L.prep_ws,
                                          d->d_warp, d->d_latent + 128ll * d->view0, X));
+        }
     }
     if (lane) {
         hold.forked = false;

@@ -73,6 +73,20 @@ def _sched_gamma(lr0, lr_end, sched, max_iter, what):
 
 
 
+def noise_stream_seed(opt, rank, tag):
+    """Philox key of a network's density-noise stream (niw_normal_rng): folds in opt.seed, the rank (ranks render different rays) and the
+    network (tag 0: coarse, 1: fine -- consecutive keys, which is what niw_train_step assumes: noise_seed, noise_seed + 1)"""
+    return (int(getattr(opt, "seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x4E015E + rank * 0xD1B54A32D192ED03 + tag) & (2 ** 64 - 1)
+
+
+def set_noise_keys(opt, nets, draw, draw_dev=None):
+    """before an iteration: every field network learns the stream its density noise comes from in THIS iteration (mirror: model/nerf.py
+    NeRF._run; the one-call form gets the same key through niw_train_desc.noise_seed)"""
+    rank = (getattr(opt, "ray_shard", None) or (0, 1))[0]
+    for tag, net in enumerate(nets):
+        net.noise_key = (noise_stream_seed(opt, rank, tag), int(draw), draw_dev)
+
+
 class FusedStep:
     """One train iteration of an INN trainer -- forward, losses, backward of every stage -- as ONE library call (niw_train_step,
     csrc/niw_step.hip) into ONE persistent workspace: no autograd tape, no torch arithmetic, no allocation inside the iteration.  It
@@ -98,15 +112,16 @@ class FusedStep:
             return "ray_sampler is not 'feistel' (draws injected through torch.randperm)"
         if opt.nerf.sample_stratified and opt.nerf.stratified_rng != "philox":
             return "stratified draws injected through torch.rand"
-        if opt.camera.ndc:
-            return "camera.ndc (the gradient through the NDC reparametrisation runs as torch algebra)"
-        if opt.nerf.density_noise_reg:
-            return "nerf.density_noise_reg"
+        vanilla = getattr(trainer, "family", None) == "vanilla"
+        if opt.camera.ndc and not vanilla:
+            return "camera.ndc with warped rays (the gradient through the NDC reparametrisation runs as torch algebra)"
+        if opt.nerf.density_noise_reg and opt.nerf.get("density_noise_rng") != "philox":
+            return "density noise injected through torch.randn"
         if opt.nerf.setbg_opaque:
             return "nerf.setbg_opaque"
-        if opt.data.dataset == "blender":
+        if opt.data.dataset == "blender" and not vanilla:
             return "blender initial poses"
-        if nerf_inn_llff.ALIGN_BACKEND is not None:
+        if nerf_inn_llff.ALIGN_BACKEND is not None and not vanilla:
             return "a test backend of the alignment term is plugged in"
         if trainer.n_views > 64:
             return "more than 64 views"
@@ -129,7 +144,8 @@ class FusedStep:
         if B != tr.n_views:
             raise NiwError(f"train_iteration: the batch holds {B} views, the trainer was built for {tr.n_views}")
         R = opt.nerf.rand_rays // B
-        win = g.view_window(opt, B, R)
+        vanilla = tr.family == "vanilla"
+        win = None if vanilla else g.view_window(opt, B, R)
         g._last_window = win
         S = opt.nerf.sample_intvs
         Sf = (opt.nerf.sample_intvs_fine or 0) if opt.nerf.fine_sampling else 0
@@ -147,7 +163,15 @@ class FusedStep:
         d = _lib_mod.TrainDesc()
         d.image, d.intr = image.data_ptr(), intr.data_ptr()
         self._keep = [image, intr]
-        if tr.family == "dtu":
+        if vanilla:
+            # the cameras the rays come from (reference model/nerf.py:264 get_pose -> var.pose): read in place, like the images
+            pose = var.pose
+            if pose.dtype != torch.float32 or not pose.is_contiguous() or tuple(pose.shape) != (B, 3, 4):
+                raise NiwError(f"train_iteration: var.pose must be a contiguous float32 [{B},3,4] tensor (got {tuple(pose.shape)} {pose.dtype})")
+            self._keep.append(pose)
+            d.pose_init = pose.data_ptr()
+            rng = opt.nerf.depth.range
+        elif tr.family == "dtu":
             pose_init = ops._f32(tr.pose_net.initial_poses_w2c, "initial_poses_w2c")
             self._keep.append(pose_init)
             d.pose_init = pose_init.data_ptr()
@@ -180,14 +204,21 @@ class FusedStep:
         d.precision = ops.PREC[tr.nets[0]._state.precision]
         if d.precision == 0:
             d.pack_index = ops.pack_index(dev).data_ptr()
-        d.use_index_window = 1 if tr.warp_mlp.reference_exact else 0
+        d.use_index_window = 0 if vanilla else (1 if tr.warp_mlp.reference_exact else 0)
         d.w_render, d.w_render_fine, d.w_align = self._weights()
+        if vanilla:
+            d.w_align = -1.0
+        d.density_noise = float(opt.nerf.density_noise_reg or 0.0)
+        d.noise_seed = noise_stream_seed(opt, rank, 0)
+        d.ndc, d.ndc_near = (1 if opt.camera.ndc else 0), 1.0
         if not Sf:
             d.w_render_fine = -1.0
         d.always_register = 1 if tr.family == "dtu" else 0
         d.overlap = 1 if tr.overlap else 0
         d.mse_norm = float(getattr(opt, "loss_norm_elements", None) or 3 * B * R)
-        if tr.family == "dtu":
+        if vanilla:
+            table = None
+        elif tr.family == "dtu":
             table = tr.pose_net.pose_global.weight
         else:
             table = g.global_rigid.weight if hasattr(g, "global_rigid") else None
@@ -217,11 +248,12 @@ class FusedStep:
         d.nerf_params, d.d_nerf = tr.nets[0].flat_params.data_ptr(), tr.bucket.segment(0).data_ptr()
         if n_nets > 1:
             d.nerf_fine_params, d.d_nerf_fine = tr.nets[1].flat_params.data_ptr(), tr.bucket.segment(1).data_ptr()
-        d.warp_params, d.d_warp = tr.warp_mlp.flat_params.data_ptr(), tr.bucket.segment(n_nets).data_ptr()
-        latent = tr.warp_latent.weight
-        if not latent.is_contiguous():
-            raise NiwError("the latent table must be contiguous")
-        d.latent, d.d_latent = latent.data_ptr(), tr.bucket.segment(n_nets + 1).data_ptr()
+        if tr.family != "vanilla":
+            d.warp_params, d.d_warp = tr.warp_mlp.flat_params.data_ptr(), tr.bucket.segment(n_nets).data_ptr()
+            latent = tr.warp_latent.weight
+            if not latent.is_contiguous():
+                raise NiwError("the latent table must be contiguous")
+            d.latent, d.d_latent = latent.data_ptr(), tr.bucket.segment(n_nets + 1).data_ptr()
         table = self.pose_table
         d.poses = None if table is None else table.data.data_ptr()
         d.fine_grads_ready = tr.fine_ready_event()
@@ -232,7 +264,8 @@ class FusedStep:
         opt = self.tr.opt
         sig = [len(var.idx), opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0, self._weights(),
                bool(opt.nerf.sample_stratified), tuple(opt.nerf.depth.range), opt.nerf.depth.param]
-        for k in ("image", "intr", "depth_range"):
+        sig.append((bool(opt.camera.ndc), float(opt.nerf.density_noise_reg or 0.0)))
+        for k in ("image", "intr", "depth_range") + (("pose",) if self.tr.family == "vanilla" else ()):
             t = var.get(k) if hasattr(var, "get") else getattr(var, k, None)
             sig.append(None if t is None else (t.data_ptr(), tuple(t.shape), t._version if k == "depth_range" else 0))
         return sig
@@ -254,13 +287,14 @@ class FusedStep:
         net = tr.nets[0]
         consts = tr.consts if tr.hip_graph else None
         b3, bv = ops._farr(net.band_weights(opt, ops.L3D), ops.L3D), ops._farr(net.band_weights(opt, ops.LVIEW), ops.LVIEW)
-        chan_w, index_window = tr.warp_mlp._anneal(float(nvp_ndr.embedding_anneal_ratio(opt, it)))
-        cw = ops._farr(chan_w, 6)
-        iw = None if index_window is None else ops._farr(index_window, 6)
         fp = ctypes.POINTER(ctypes.c_float)
         d.band_w3d, d.band_wview = ctypes.cast(b3, fp), ctypes.cast(bv, fp)
-        d.chan_w = ctypes.cast(cw, fp)
-        d.index_window = ctypes.cast(iw, fp) if iw is not None else None
+        if tr.family != "vanilla":
+            chan_w, index_window = tr.warp_mlp._anneal(float(nvp_ndr.embedding_anneal_ratio(opt, it)))
+            cw = ops._farr(chan_w, 6)
+            iw = None if index_window is None else ops._farr(index_window, 6)
+            d.chan_w = ctypes.cast(cw, fp)
+            d.index_window = ctypes.cast(iw, fp) if iw is not None else None
         d.band_dev = None if consts is None else consts.band.data_ptr()
         d.window_dev = None if consts is None else consts.window.data_ptr()
         d.draw_dev = None if consts is None else consts.draw.data_ptr()
@@ -386,6 +420,8 @@ class INNTrainer:
         # stratified depth draws: inside the kernel (Philox) wherever the engine makes its own pixel draw; a harness that injects the
         # reference's torch.randperm / torch.rand draws (ray_sampler="randperm") keeps torch.rand
         opt.nerf.stratified_rng = opt.nerf.get("stratified_rng") or ("philox" if opt.nerf.ray_sampler == "feistel" else "torch")
+        # density noise (nerf.density_noise_reg): drawn by niw_normal_rng wherever the engine makes its own draws, torch.randn for a harness
+        opt.nerf.density_noise_rng = opt.nerf.get("density_noise_rng") or ("philox" if opt.nerf.ray_sampler == "feistel" else "torch")
         self.hip_graph = bool(hip_graph) and on_gpu
         self._captured = None
         if self.hip_graph:
@@ -467,6 +503,7 @@ class INNTrainer:
             return self.fused.run(var, it)
         self._install_grad_sinks()
         self._bind_constants(True)
+        set_noise_keys(opt, self.nets, it + 1, self.consts.draw if self.hip_graph else None)
         try:
             var = self.graph.forward(opt, var, mode="train", iter=it)
             loss = self.graph.compute_loss(opt, var, mode="train")
@@ -767,13 +804,16 @@ class INNTrainer:
 
 class NeRFTrainer:
     """One train iteration of the VANILLA model (reference model/nerf.py:77-100 train_iteration + :251-288 Graph.forward / compute_loss:
-    ground-truth poses, no warp -- BASELINE configs[0], options/nerf_llff_repr.yaml) on the engine's plumbing: the Feistel pixel draw and
-    the in-kernel stratified draw instead of torch.randperm / torch.rand, gradients written straight into a flat bucket, one Adam launch
-    over both networks with the reference's ExponentialLR.  The render itself is the reference-shaped mirror (Graph.render over ..ops:
-    rays of the given poses, field, compositing, resampling, fine field) under autograd; rays carry no gradient here, so the dX chain
-    runs without its ray-gradient tail."""
+    ground-truth poses, no warp -- BASELINE configs[0], options/nerf_llff_repr.yaml) on the engine's plumbing: the Feistel pixel draw, the
+    in-kernel stratified draw and the in-kernel density noise instead of torch.randperm / torch.rand / torch.randn, gradients written
+    straight into a flat bucket, one Adam launch over both networks with the reference's ExponentialLR.
+    fused_step (round 6): "auto" runs the iteration as ONE niw_train_step call (warp_params = NULL: rays of the cameras var.pose, NDC,
+    density noise, both passes, losses, backward without the ray-gradient tail of the dX chain) wherever that call covers the options;
+    False (or an uncovered option) = the reference-shaped mirror (Graph.render over ..ops under autograd).  Both train bit for bit alike
+    (tests/test_gpu_fused_step.py)."""
+    family, hip_graph, overlap, consts, rank, world = "vanilla", False, False, None, 0, 1
 
-    def __init__(self, opt, n_views, seed=0):
+    def __init__(self, opt, n_views, seed=0, fused_step="auto"):
         from .model import nerf as nerf_model
         torch.manual_seed(seed)
         self.opt, self.n_views, self.it = opt, n_views, 0
@@ -781,33 +821,57 @@ class NeRFTrainer:
         self.nets = [self.graph.nerf] + ([self.graph.nerf_fine] if opt.nerf.fine_sampling else [])
         dev = torch.device(opt.device)
         self.bucket = parallel.GradBucket([n.field_parameters() for n in self.nets], dev)
-        for i, net in enumerate(self.nets):
-            net.grad_sink = self.bucket.segment(i)
-        self.bucket.sunk = set(range(len(self.nets)))
+        self._install_grad_sinks()
         self.m = [torch.zeros_like(n.flat_params) for n in self.nets]
         self.v = [torch.zeros_like(n.flat_params) for n in self.nets]
         o = opt.optim
         self.lr0, self.gamma = o.lr, _sched_gamma(o.lr, o.get("lr_end"), o.get("sched", {"type": "ExponentialLR"}), opt.max_iter, "optim.sched")
-        opt.nerf.stratified_rng = opt.nerf.get("stratified_rng") or ("philox" if dev.type == "cuda" else "torch")
+        on_gpu = dev.type == "cuda"
+        opt.nerf.ray_sampler = opt.nerf.get("ray_sampler") or ("feistel" if on_gpu else "randperm")
+        opt.nerf.stratified_rng = opt.nerf.get("stratified_rng") or ("philox" if on_gpu else "torch")
+        opt.nerf.density_noise_rng = opt.nerf.get("density_noise_rng") or ("philox" if on_gpu else "torch")
         self._captured = None
         self.fused = None
+        if fused_step:
+            why = FusedStep.unsupported(self)
+            if why is None:
+                self.fused = FusedStep(self)
+            elif fused_step is True:
+                raise NiwError(f"fused_step=True: niw_train_step does not cover this configuration ({why})")
+        self.fused_fallback_reason = None if self.fused is not None else (FusedStep.unsupported(self) if fused_step else "fused_step=False")
+
+    def _install_grad_sinks(self):
+        for i, net in enumerate(self.nets):
+            net.grad_sink = self.bucket.segment(i)
+        self.bucket.sunk = set(range(len(self.nets)))
+
+    def fine_ready_event(self):
+        return None
 
     def train_iteration(self, var, replay=True):
         opt, g, it = self.opt, self.graph, self.it
-        B = len(var.idx)
-        n = opt.nerf.rand_rays // B
-        g._depth_draw, g._depth_call_in_iter = it + 1, 0
-        var.ray_idx = ops.draw_ray_idx(opt.H * opt.W, n, int(getattr(opt, "seed", 0) or 0), it + 1, opt.device)
-        var.update(g.render(opt, g.get_pose(opt, var, mode="train"), intr=var.intr, ray_idx=var.ray_idx, mode="train"))
-        loss = g.compute_loss(opt, var, mode="train")
-        keys = [k for k in loss if opt.loss_weight[k] is not None]
-        total = None
-        with torch.no_grad():
-            for k in keys:
-                w = 10 ** float(opt.loss_weight[k])
-                total = loss[k] * w if total is None else torch.add(total, loss[k], alpha=w)
-        torch.autograd.backward([loss[k] for k in keys], [torch.full_like(loss[k], 10 ** float(opt.loss_weight[k])) for k in keys])
-        loss.update(all=total)
+        if self.fused is not None:
+            why = FusedStep.unsupported(self)
+            if why is not None:
+                raise NiwError(f"train_iteration: the configuration changed after the trainer was built and niw_train_step does not cover it any more ({why})")
+            loss = self.fused.run(var, it)
+        else:
+            B = len(var.idx)
+            n = opt.nerf.rand_rays // B
+            self._install_grad_sinks()
+            g._depth_draw, g._depth_call_in_iter = it + 1, 0
+            set_noise_keys(opt, self.nets, it + 1)
+            var.ray_idx = ops.draw_ray_idx(opt.H * opt.W, n, int(getattr(opt, "seed", 0) or 0), it + 1, opt.device)
+            var.update(g.render(opt, g.get_pose(opt, var, mode="train"), intr=var.intr, ray_idx=var.ray_idx, mode="train"))
+            loss = g.compute_loss(opt, var, mode="train")
+            keys = [k for k in loss if opt.loss_weight[k] is not None]
+            total = None
+            with torch.no_grad():
+                for k in keys:
+                    w = 10 ** float(opt.loss_weight[k])
+                    total = loss[k] * w if total is None else torch.add(total, loss[k], alpha=w)
+            torch.autograd.backward([loss[k] for k in keys], [torch.full_like(loss[k], 10 ** float(opt.loss_weight[k])) for k in keys])
+            loss.update(all=total)
         lr = self.lr0 * self.gamma ** it
         ops.adam_step_multi([(n_.flat_params, self.bucket.segment(i), self.m[i], self.v[i], lr, it + 1) for i, n_ in enumerate(self.nets)])
         self.it = it + 1

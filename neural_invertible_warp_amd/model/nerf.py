@@ -172,7 +172,14 @@ class NeRF(torch.nn.Module):
         self._ensure_flat()
         noise = None
         if opt.nerf.density_noise_reg and mode == "train":
-            noise = torch.randn(depth.shape, device=depth.device) * opt.nerf.density_noise_reg    # nerf.py:428-429
+            key = getattr(self, "noise_key", None)
+            if opt.nerf.get("density_noise_rng") == "philox" and key is not None:
+                # the engine's draw (niw_normal_rng): a pure function of (stream key of this network, number of the iteration's pixel
+                # draw, sample index) -- what niw_train_step draws for the same iteration; `noise_key` = (seed, draw, draw_dev) is set by
+                # the trainer before every iteration
+                noise = ops.normal_rng(key[0], key[1], depth.numel(), opt.nerf.density_noise_reg, depth.device, draw_dev=key[2]).view(depth.shape)
+            else:
+                noise = torch.randn(depth.shape, device=depth.device) * opt.nerf.density_noise_reg    # nerf.py:428-429
         return ops.field_mlp(self._state, self.field_parameters(), center, ray, depth,
                              self.band_weights(opt, ops.L3D), self.band_weights(opt, ops.LVIEW), opt.arch.density_activ, noise,
                              band_dev=self.band_dev, grad_sink=self.grad_sink if mode == "train" else None)

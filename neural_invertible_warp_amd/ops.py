@@ -150,6 +150,14 @@ def sample_stratified_rng(seed, draw, n_rays, S, depth_range, param, device, dra
     return (out, u) if return_u else out
 
 
+def normal_rng(seed, draw, n, scale, device, draw_dev=None):
+    """niw_normal_rng: n values scale * N(0, 1) -- Box-Muller over the Philox stream keyed by `seed`, counter (i / 4, `draw`) -> [n].
+    The density noise of the train-mode field forward (reference model/nerf.py:428-429) when the engine draws it on the device."""
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    _lib.call("niw_normal_rng", int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1), _p(draw_dev), n, float(scale), _p(out), _stream())
+    return out
+
+
 _table_cache = {}
 
 

@@ -461,7 +461,7 @@ def render_rays(p: Params, center: Tensor, ray: Tensor, u, S: int, depth_range, 
     """G1: Graph.render_local, model/nerf_inn_llff.py:581-612 (== Graph.render nerf.py:304-319
     once center/ray are given)."""
     depth = sample_depth(u, S, depth_range, param)
-    rgb_s, sig_s = forward_samples(p, center, ray, depth, **mlp_kw)
+    rgb_s, sig_s = forward_samples(p, center, ray, depth, **{k: v for k, v in mlp_kw.items() if k != "density_noise_fine"})
     rgb, d, op, prob = composite(ray, rgb_s, sig_s, depth)
     out = dict(rgb=rgb, depth=d, opacity=op, prob=prob, depth_samples=depth)
     if p_fine is not None:
@@ -470,6 +470,10 @@ def render_rays(p: Params, center: Tensor, ray: Tensor, u, S: int, depth_range, 
             depth_all = merge_depth(depth, fine)
         kw = dict(mlp_kw)
         kw.pop("density_noise", None)
+        # (the reference draws a fresh randn_like in EVERY train-mode forward, model/nerf.py:428-429: the fine pass takes its own tensor)
+        noise_fine = kw.pop("density_noise_fine", None)
+        if noise_fine is not None:
+            kw["density_noise"] = noise_fine
         rgb_s, sig_s = forward_samples(p_fine, center, ray, depth_all, **kw)
         rgb_f, d_f, op_f, _ = composite(ray, rgb_s, sig_s, depth_all)
         out.update(rgb_fine=rgb_f, depth_fine=d_f, opacity_fine=op_f, depth_samples_fine=depth_all)

@@ -210,3 +210,99 @@ def test_adam_of_all_groups_in_one_launch_equals_the_per_group_launches():
     ops.adam_step_multi([(p2[k], g[k], m2[k], v2[k], 123.0, 1) for k in range(4)], hyper_dev=hyper)
     for k in range(4):
         assert torch.equal(p[k], p2[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ the vanilla model (BASELINE configs[0])
+def _vanilla_trainer(fused, ndc=False, noise=1.0, B=5, S=16):
+    """options/nerf_llff_repr.yaml at a small shape: ground-truth cameras (a few degrees / centimetres off identity, so that world and
+    camera frames differ), ReLU density with density noise, coarse + fine pass (reference model/nerf.py:251-288)"""
+    from neural_invertible_warp_amd import camera, configs, engine
+    opt = configs.cfg1_nerf_llff_repr(device=DEV)
+    opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine, opt.max_iter = B * 37, S, S, 40
+    opt.camera.ndc, opt.nerf.density_noise_reg = ndc, noise
+    var0 = engine.synthetic_scene(opt, B)
+    gen = torch.Generator().manual_seed(3)
+    var0.pose = camera.lie.se3_to_SE3(torch.randn(B, 6, generator=gen) * 0.03).to(DEV)[:, :3].contiguous()
+    tr = engine.NeRFTrainer(opt, B, seed=4, fused_step=fused)
+    assert (tr.fused is not None) == bool(fused), tr.fused_fallback_reason
+    return tr, var0
+
+
+@pytest.mark.parametrize("ndc,noise", [(False, 1.0), (True, 1.0), (False, None)])
+def test_vanilla_iteration_trains_bit_for_bit_like_the_autograd_mirror(ndc, noise):
+    """round 6: niw_train_step with warp_params = NULL -- rays of the given cameras (niw_raygen), NDC re-parametrisation, density noise
+    drawn by niw_normal_rng in both passes, no ray-gradient tail of the dX chain -- against Graph.render + compute_loss + backward of the
+    mirror (engine.NeRFTrainer(fused_step=False)), which draws its noise from the same keyed streams"""
+    runs = []
+    for fused in (False, True):
+        tr, var0 = _vanilla_trainer(fused, ndc=ndc, noise=noise)
+        losses = []
+        for _ in range(5):
+            loss = tr.train_iteration(type(var0)(var0))
+            losses.append({k: float(v.detach()) for k, v in loss.items()})
+        torch.cuda.synchronize()
+        runs.append((tr, losses))
+    (a, la), (b, lb) = runs
+    assert [sorted(x) for x in la] == [sorted(x) for x in lb] and sorted(la[0]) == ["all", "render", "render_fine"]
+    for x, y in zip(la, lb):
+        for k in x:
+            if k == "all":
+                assert abs(x[k] - y[k]) <= 1e-6 * max(abs(x[k]), 1e-6), (k, x[k], y[k])
+            else:
+                assert x[k] == y[k], (k, x[k], y[k])
+    assert la[0]["render"] != la[1]["render"]
+    assert torch.equal(a.bucket.flat, b.bucket.flat), float((a.bucket.flat - b.bucket.flat).abs().max())
+    for fa, fb in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
+        assert torch.equal(fa, fb)
+
+
+def test_vanilla_iteration_with_density_noise_vs_oracle():
+    """the same iteration against the oracle (reference model/nerf.py:251-288, 416-447): the pixel draw, the stratified draws and the
+    two noise tensors of the iteration are read back from the keyed streams (ops.draw_ray_idx / sample_stratified_rng / normal_rng) and
+    handed to the oracle as explicit tensors"""
+    from neural_invertible_warp_amd import engine, ops
+    from oracle import niw_oracle as O
+    tr, var0 = _vanilla_trainer(True, noise=0.5)
+    opt, B = tr.opt, 5
+    R, S, Sf = opt.nerf.rand_rays // B, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine
+    clone = lambda mod: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.state_dict().items() if k != "progress"}
+    pc, pf = clone(tr.graph.nerf), clone(tr.graph.nerf_fine)
+    loss = tr.train_iteration(type(var0)(var0))
+    grads = tr.bucket.flat.detach().cpu().clone()
+    # the iteration's draws (iteration 0 -> draw 1)
+    ray_idx = ops.draw_ray_idx(opt.H * opt.W, R, 0, 1, DEV).cpu()
+    seed_d = (0x5D1F) & (2 ** 64 - 1)
+    _, u = ops.sample_stratified_rng(seed_d, 1, B * R, S, opt.nerf.depth.range, opt.nerf.depth.param, DEV, return_u=True)
+    n_c = ops.normal_rng(engine.noise_stream_seed(opt, 0, 0), 1, B * R * S, 0.5, DEV).view(B, R, S).cpu()
+    n_f = ops.normal_rng(engine.noise_stream_seed(opt, 0, 1), 1, B * R * (S + Sf), 0.5, DEV).view(B, R, S + Sf).cpu()
+    # The density is a ReLU of (raw + noise): a sample whose pre-activation sits within fp32 round-off of zero switches its whole gradient
+    # path on or off, so ANY fp32 evaluation deviates from the exact gradient by a few such samples.  The yardstick is therefore the
+    # oracle in float64, and the bound what torch's own fp32 evaluation of the same function shows against it (round 4's criterion).
+    def oracle(dtype):
+        cast = lambda d: {k: v.detach().to(dtype).requires_grad_(True) for k, v in d.items()}
+        qc, qf = cast(pc), cast(pf)
+        center, ray = O.center_and_ray(opt.H, opt.W, var0.pose.cpu().to(dtype), var0.intr.cpu().to(dtype))
+        out = O.render_rays(qc, center[:, ray_idx], ray[:, ray_idx], u.view(B, R, S, 1).cpu().to(dtype), S, tuple(opt.nerf.depth.range), opt.nerf.depth.param,
+                            p_fine=qf, Sf=Sf, density_activ="relu", density_noise=n_c.to(dtype), density_noise_fine=n_f.to(dtype))
+        target = O.gather_pixels(var0.image.cpu().to(dtype), ray_idx)
+        l_c, l_f = O.mse_loss(out["rgb"], target), O.mse_loss(out["rgb_fine"], target)
+        (l_c + l_f).backward()
+        return float(l_c.detach()), float(l_f.detach()), qc, qf
+
+    l_c, l_f, pc32, pf32 = oracle(torch.float32)
+    l_c64, l_f64, pc64, pf64 = oracle(torch.float64)
+    assert abs(float(loss.render.detach()) - l_c) <= 2e-6 and abs(float(loss.render_fine.detach()) - l_f) <= 2e-6, (float(loss.render), l_c, float(loss.render_fine), l_f)
+    assert abs(float(loss.render.detach()) - l_c64) <= 2e-6 and abs(float(loss.render_fine.detach()) - l_f64) <= 2e-6
+    off, worst = 0, (0.0, 0.0, None)
+    for net, p32, p64 in ((tr.graph.nerf, pc32, pc64), (tr.graph.nerf_fine, pf32, pf64)):
+        for k, v in net.state_dict().items():
+            if k == "progress":
+                continue
+            g_hip, g64, g32 = grads[off:off + v.numel()].view(v.shape).double(), p64[k].grad, p32[k].grad.double()
+            off += v.numel()
+            scale = max(float(g64.abs().max()), 1e-12)
+            err_hip, err_t32 = float((g_hip - g64).abs().max()) / scale, float((g32 - g64).abs().max()) / scale
+            if err_hip > worst[0]:
+                worst = (err_hip, err_t32, k)
+            assert err_hip <= max(3 * err_t32, 2e-3), (k, err_hip, err_t32)
+    print(f"vanilla step with density noise: losses to 2e-6; worst gradient tensor {worst[2]}: HIP {worst[0]:.2e} of max vs float64, torch fp32 {worst[1]:.2e}")

@@ -112,3 +112,31 @@ def test_engine_uses_the_in_kernel_draw_and_resumes_its_stream():
     finally:
         ops_mod.sample_stratified_rng = orig
     assert seen == [1, 2, 3, 3]                              # draw number = iteration + 1, also after the jump
+
+
+def test_normal_rng_is_box_muller_over_the_keyed_philox_stream():
+    """niw_normal_rng (round 6; the density noise of reference model/nerf.py:428-429 drawn on the device): values 4g .. 4g+3 come from
+    the Philox words of counter (g, draw) under key seed -- r = sqrt(-2 ln u1), theta = 2 pi u2 -- so a numpy restatement reproduces them
+    to fp32 libm accuracy; moments of a million draws; the draw number may come from device memory; a pure function of its key."""
+    import math
+    import numpy as np
+    from neural_invertible_warp_amd import ops
+    seed, draw, scale = 0x1234567890ABCDEF, 7, 0.5
+    z = ops.normal_rng(seed, draw, 1003, scale, DEV).cpu().numpy()
+    ref = np.zeros(1004, dtype=np.float64)
+    for g in range(251):
+        w = _philox4x32_10((g, 0, draw & 0xffffffff, draw >> 32), (seed & 0xffffffff, seed >> 32))
+        for t in range(2):
+            u1, u2 = ((w[2 * t] >> 8) + 1) * 2.0 ** -24, (w[2 * t + 1] >> 8) * 2.0 ** -24
+            r = math.sqrt(-2.0 * math.log(u1))
+            ref[4 * g + 2 * t], ref[4 * g + 2 * t + 1] = scale * r * math.cos(2 * math.pi * u2), scale * r * math.sin(2 * math.pi * u2)
+    assert np.abs(z - ref[:1003]).max() <= 2e-6 * scale * 6
+    big = ops.normal_rng(seed, draw, 1 << 20, 1.0, DEV).double()
+    m, v = float(big.mean()), float(big.var())
+    k = float(((big - m) ** 4).mean() / v ** 2)
+    assert abs(m) < 4e-3 and abs(v - 1) < 6e-3 and abs(k - 3) < 0.05, (m, v, k)
+    assert torch.isfinite(big).all() and float(big.abs().max()) < 6.0                  # u1 >= 2^-24: |z| <= sqrt(2 * 24 ln 2) = 5.77
+    assert torch.equal(ops.normal_rng(seed, draw, 4096, 1.0, DEV), big[:4096].float())
+    dev_draw = torch.tensor([draw], dtype=torch.int64, device=DEV)
+    assert torch.equal(ops.normal_rng(seed, 99, 4096, 1.0, DEV, draw_dev=dev_draw), big[:4096].float())
+    assert not torch.equal(ops.normal_rng(seed + 1, draw, 4096, 1.0, DEV), big[:4096].float())

@@ -51,6 +51,8 @@ def analyse(buf, n_stages, waves_per_wg):
     t0 = t[:, 0].min()
     us = (t - t0) * TICK_US
     entry, end = us[:, 0], us[:, n_stages]
+    cyc = (buf[live, 14].astype(np.int64) - buf[live, 13].astype(np.int64)).astype(np.float64)
+    ghz = cyc / np.maximum((t[:, n_stages] - t[:, 0]).astype(np.float64), 1.0) * 0.1          # cycles per 10 ns tick -> GHz
     span = float(end.max())
     xcc = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64)
     cu = ((hw >> np.uint64(8)) & np.uint64(0xf)).astype(np.int64)
@@ -76,6 +78,7 @@ def analyse(buf, n_stages, waves_per_wg):
                wave_duration_us=stats(end - entry),
                wave_duration_by_xcd_us={str(x): round(float(np.median((end - entry)[xcc == x])), 2) for x in sorted(set(xcc.tolist()))},
                exposed_tail_us=stats(span - last_end),
+               shader_clock_ghz=stats(ghz), shader_clock_by_xcd_ghz={str(x): round(float(np.median(ghz[xcc == x])), 3) for x in sorted(set(xcc.tolist()))},
                stage_us={})
     first, late = rnd == 0, rnd >= 2
     for j in range(n_stages):
@@ -96,6 +99,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="252x128,2016x128")
     ap.add_argument("--train", type=int, default=6, help="launches per back-to-back train (the last one's stamps are read)")
+    ap.add_argument("--trains", default=None, help="comma-separated train lengths: every (size, kernel) is traced once per length (does a one-round "
+                                                   "launch run differently after 1.5 ms of load than after 30 ms?)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import numpy as np
@@ -139,7 +144,8 @@ def main():
             fns[f"dw[{DW_KINDS[kind]}]"] = ("dw", kind, dw)
         n_waves = 8 * 2048                      # more than any launch here has (wave index = linear block x waves per block)
         trace = torch.zeros(n_waves, SLOTS, dtype=torch.int64, device=dev)
-        for name, (unit, kind, fn) in fns.items():
+        trains = [int(x) for x in args.trains.split(",")] if args.trains else [args.train]
+        for name, (unit, kind, fn), train in [(n, f, tl) for n, f in fns.items() for tl in trains]:
             for _ in range(8):
                 fn()
             torch.cuda.synchronize()
@@ -148,19 +154,25 @@ def main():
             assert setters[unit](trace.data_ptr(), n_waves, kind) == 0
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            for _ in range(args.train):
+            for _ in range(train):
                 fn()
             b.record()
             torch.cuda.synchronize()
             assert setters[unit](None, 0, 0) == 0
-            per_launch_us = a.elapsed_time(b) / args.train * 1e3
+            per_launch_us = a.elapsed_time(b) / train * 1e3
             buf = trace.cpu().numpy().view(np.uint64)
             stages = STAGES["dw" if unit == "dw" else name]
             res = analyse(buf, len(stages), 8 if unit == "dw" else 4)
             if res is None:
                 continue                         # (this NT-GEMM shape is not launched at this size)
             res["stage_us"] = {stages[j]: v for j, v in res["stage_us"].items()}
-            line = dict(kernel=name, rays=N, samples=S, mlp_evals=M, event_us_per_launch=round(per_launch_us, 2),
+            if name == "fwd_train":
+                ok = (buf[:, 0] > 0) & (buf[:, 11] > 0)
+                res["prologue_until_inputs_loaded_us"] = stats((buf[ok, 11].astype(np.int64) - buf[ok, 0].astype(np.int64)) * TICK_US)
+                ok = ok & (buf[:, 12] > 0)
+                res["prologue_encodings_us"] = stats((buf[ok, 12].astype(np.int64) - buf[ok, 11].astype(np.int64)) * TICK_US)
+                res["prologue_encoding_stores_us"] = stats((buf[ok, 1].astype(np.int64) - buf[ok, 12].astype(np.int64)) * TICK_US)
+            line = dict(kernel=name, rays=N, samples=S, mlp_evals=M, train=train, event_us_per_launch=round(per_launch_us, 2),
                         outside_the_kernel_us=round(per_launch_us - res["span_us"], 2) if unit != "dw" else None,
                         mfma_floor_us=round(M * FLOP / 157.3e12 * 1e6, 2) if unit != "dw" else None, **res)
             results.append(line)

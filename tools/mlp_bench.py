@@ -2,7 +2,7 @@
 sample counts from one 256-workgroup round (32,768 samples = a 1/8 shard of the 2048-ray batch) to the cfg2 fine pass
 (784,512): device-event time of `iters` back-to-back launches into pre-allocated workspaces, TFLOP/s against the fp32-MFMA
 peak.  NIW_LIB_PATH selects a diagnostic build."""
-import argparse, json, os, sys
+import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FLOP = 2 * 527872
 
@@ -40,6 +40,14 @@ def main():
         line = dict(precision=args.precision, dx_precision="fp32" if bprec == 0 else args.precision, dw_precision="fp32" if wprec == 0 else args.precision, rays=N, samples=S, mlp_evals=M, workgroups=int(mpad // 128), lib=os.environ.get("NIW_LIB_PATH", "product"))
         for name, fn in fns.items():
             for _ in range(8): fn()      # (the library's second stream -- niw_mlp_bwd_dw's heads kernel -- pays one-time runtime set-up in its first few uses)
+            # ... and then at least 30 ms of back-to-back launches: after an idle period the chip runs its first milliseconds at ~2.0 GHz instead
+            # of 2.39 (in-kernel s_memtime / s_memrealtime stamps, profiles/r6_launch_trace.json: a train of 6 one-round launches 2.04 GHz, of 80
+            # 2.39 GHz), which rounds 2-5 of this tool read as a "fixed cost" of the small launches (10 x 0.29 ms measured right after a sync)
+            torch.cuda.synchronize(); t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.03:
+                for _ in range(10): fn()
+                torch.cuda.synchronize()
+            for _ in range(10): fn()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(args.iters): fn()
