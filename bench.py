@@ -330,7 +330,7 @@ def scenes_of_rank(scenes, rank, world):
 
 
 def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, precision="fp32", overlap=True, placement="shard", llff_root=None,
-                    split_exchange="auto"):
+                    split_exchange="auto", fused_step="auto"):
     """-> (list of (trainer, var0, B, R_local, S, Sf), description).  placement (cfg4, all scenes): "shard" = every rank trains every scene on
     its share of the rays (gradient all-reduce per scene and step); "replicas" = scene i trains WHOLE on rank i mod N, no exchange at all
     (/root/reference scripts/train_llff.sh:1-8: eight independent runs)."""
@@ -351,7 +351,7 @@ def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, p
         else:
             data.append("synthetic")
         kw = dict(rank=tr_rank, world=tr_world, warp_perturb=warp_perturb, hip_graph=hip_graph, overlap=overlap, collectives=not replicas,
-                  split_exchange=split_exchange)
+                  split_exchange=split_exchange, fused_step=fused_step)
         if dtu:
             var0, init = engine.synthetic_dtu_scene(opt, B)
             tr = engine.INNTrainer(opt, B, initial_poses_w2c=init, **kw)
@@ -374,10 +374,10 @@ def build_workloads(name, dev, rank, world, scaling, shard_of, hip_graph=True, p
             raise SystemExit("cfg1 (vanilla NeRF, configs[0]) is a single-GPU line")
         B = 18
         var0 = engine.synthetic_scene(opt, B)
-        tr = engine.NeRFTrainer(opt, B)
+        tr = engine.NeRFTrainer(opt, B, fused_step=fused_step)
         out.append((tr, var0, B, opt.nerf.rand_rays // B, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0))
         desc = ("cfg1: nerf_llff_repr.yaml 300x400 (configs[0]), 18 views x 56 rays x (64 coarse + 192 fine), ReLU density + noise, metric depth [0,1], "
-                "ground-truth poses (no warp, no ray gradients), fwd+bwd+Adam")
+                "ground-truth poses (no warp, no ray gradients), fwd+bwd+Adam; one niw_train_step call (warp_params = NULL) unless --fused-step off")
     elif name == "cfg2":
         mk(configs.cfg2_nerf_inn_llff_hier(device=dev), 18, 4096, scene="fern")
         desc = "cfg2: nerf_inn_llff.yaml fern 300x400, 18 views x 227 rays x (64 coarse + 192 fine), NVP-warped rays, fwd+bwd+Adam"
@@ -509,6 +509,8 @@ def main():
                     help="N > 1 (auto) or any live process group (on): after the headline, time the weak workload a few more steps with the split "
                          "gradient exchange forced on / off and launched vs replayed as a HIP graph -- `split_exchange: {on_ms, off_ms}`, "
                          "`hip_graph: {launched_ms, replayed_ms}` -- so that ONE hardware run answers both open questions of DESIGN section 5")
+    ap.add_argument("--fused-step", choices=["auto", "off"], default="auto",
+                    help="off: the iteration through the autograd mirror over the per-stage entry points instead of the one niw_train_step call")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the torch.distributed process group even for ONE rank, so that the gradient all-reduce really goes through RCCL "
                          "(hardware evidence of the N > 1 code path on a 1-GPU box)")
@@ -651,7 +653,8 @@ def main():
         modes = ["strong"]                                   # the total work is the eight scenes, whatever N is
         scaling = "strong"
     split = {"auto": "auto", "on": True, "off": False}[args.split_exchange]
-    wl = dict(hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on", llff_root=args.llff_root, split_exchange=split)
+    wl = dict(hip_graph=use_graph, precision=args.precision, overlap=args.overlap == "on", llff_root=args.llff_root, split_exchange=split,
+              fused_step="auto" if args.fused_step == "auto" else False)
     loads, desc = build_workloads(args.config, dev, rank, world, scaling, args.shard_of, placement=placement, **wl)
     data_label = "+".join(build_workloads.data)
     evals_local = n_evals(loads)
@@ -954,7 +957,9 @@ def main():
                comm_wire_model=f"ring all-reduce: 2 (N - 1) / N x bucket bytes over one xGMI link per neighbour at {XGMI_LINK_GBPS:.0f} GB/s; comm_ms well above it "
                                "= a latency-bound exchange (2 (N - 1) hops), not a bandwidth-bound one" if dist_backend else None,
                split_exchange=split_ab, hip_graph_ab=graph_ab, peak_memory_gb=round(peak_mem, 2),
-               launches_per_step="one niw_train_step call (22 kernel launches for a single-pass config, 29 with the fine pass) + gradient exchange + one Adam launch"
+               launches_per_step=("one niw_train_step call (vanilla model: front, noise draws, ray generation, two field passes with compositing + loss "
+                                  "+ backward, closing kernel) + one Adam launch" if args.config == "cfg1" else
+                                  "one niw_train_step call (22 kernel launches for a single-pass config, 29 with the fine pass) + gradient exchange + one Adam launch")
                if getattr(loads[0][0], "fused", None) is not None else "autograd mirror over the per-stage entry points",
                roofline=roofline, kernel_check=kernel_check, kernels=kernels)
     g, opt, var0 = loads[0][0].graph, loads[0][0].opt, loads[0][1]

@@ -1,9 +1,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r5}_lines; TAG=${1:-r5}; rm -rf $O; mkdir -p $O
+O=gpurun_out/${1:-r6}_lines; TAG=${1:-r6}; rm -rf $O; mkdir -p $O
 run() { name=$1; shift; python bench.py "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?"; }
 run cfg2 --gpus 1 --steps 20 --warmup 5
 run cfg2_launched --gpus 1 --steps 20 --warmup 5 --hip-graph off --lean
 run cfg1 --config cfg1 --steps 40 --lean
+python bench.py --config cfg1 --steps 40 --lean --fused-step off > $O/cfg1_mirror.json 2> $O/cfg1_mirror.err; echo "cfg1_mirror rc=$?"
 run cfg3 --config cfg3 --steps 50 --lean
 run cfg3_launched --config cfg3 --steps 50 --lean --hip-graph off
 run cfg3_serial --config cfg3 --steps 50 --lean --hip-graph off --overlap off
@@ -23,9 +24,12 @@ run cfg4_replicas_of8 --config cfg4 --placement replicas --shard-of 8 --steps 50
 run cfg4_shard_of8 --config cfg4 --placement shard --shard-of 8 --steps 10 --lean
 run cfg2_bf16x3 --precision bf16x3 --steps 20 --no-cpu-baseline --no-torch-baseline --no-forward-only --no-composite-scan
 run cfg2_bf16 --precision bf16 --steps 20 --no-cpu-baseline --no-torch-baseline --no-forward-only --no-composite-scan
-NIW_DIST_BACKEND=gloo python bench.py --gpus 2 --config cfg3 --lean --steps 10 > $O/n2_gloo_cfg3.json 2> $O/n2_gloo_cfg3.err; echo "n2 rc=$?"
-NIW_DIST_BACKEND=gloo python bench.py --gpus 2 --config cfg2 --lean --steps 5 > $O/n2_gloo_cfg2.json 2> $O/n2_gloo_cfg2.err; echo "n2 cfg2 rc=$?"
-NIW_DIST_BACKEND=gloo python bench.py --gpus 2 --config cfg4 --lean --steps 3 --kernel-steps 0 > $O/n2_gloo_cfg4.json 2> $O/n2_gloo_cfg4.err; echo "n2 cfg4 rc=$?"
+# the driver's N > 1 invocation rehearsed with FIVE gloo ranks on this one GPU (tools/rehearse_ranks.sh: the process guard admits no more)
+for cfg in cfg2 cfg5 cfg4; do
+  extra=""; [ $cfg = cfg4 ] && extra="--kernel-steps 0"
+  SECONDS=0
+  NIW_DIST_BACKEND=gloo timeout -k 10 900 python bench.py --gpus 5 --config $cfg --steps 5 --warmup 2 $extra > $O/n5_gloo_$cfg.json 2> $O/n5_gloo_$cfg.err; echo "n5 $cfg rc=$? wall_s=$SECONDS"
+done
 python - $O <<'PY'
 import json, sys, glob, os
 out = {}
