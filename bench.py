@@ -198,7 +198,7 @@ def rocprof_row(config, kernel):
     """The committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/r4_kernel_stats_<config>.csv, else an
     earlier round's): the row of `kernel`, so that the device-event average of this run stands next to the profiler's."""
     import csv
-    for rnd in ("r5", "r4", "r3", "r2"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{config}.csv")
         try:
             with open(path, newline="") as f:
@@ -883,7 +883,7 @@ def main():
         # HBM bytes per launch of that kernel: rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE x2 + WRITE_SIZE, bytes per
         # sample) times the samples one launch processes; a pointer to the committed measurement, not measured in this run
         traffic = None
-        for fname in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for fname in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     t = json.load(f)["bytes_per_sample"].get(dom)
@@ -910,12 +910,13 @@ def main():
             t_hbm, t_mfma = algo * n / (PEAK_HBM * 1e9), terms * FLOP_FWD * n / (PEAK_BF16_MFMA * 1e12)
             counter = None
             try:
-                with open(os.path.join(ROOT, "profiles", f"r4_fast_{args.precision}_traffic.json")) as f:
+                fast = next(p_ for p_ in (os.path.join(ROOT, "profiles", f"{r_}_fast_{args.precision}_traffic.json") for r_ in ("r6", "r5", "r4")) if os.path.exists(p_))
+                with open(fast) as f:
                     t = json.load(f)["bytes_per_sample"].get(dom)
                 if t:
                     counter = dict(value=round((t["fetch_corrected"] + t["write"]) * n / 1e9, 3), unit="GB",
-                                   source=f"profiles/r4_fast_{args.precision}_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
-            except (OSError, KeyError, ValueError):
+                                   source=f"profiles/{os.path.basename(fast)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)")
+            except (OSError, KeyError, ValueError, StopIteration):
                 pass
             roofline = dict(bound="hbm" if t_hbm >= t_mfma else "mfma", kernel=rocprof_name[dom],
                             achieved=round(gbps, 1) if t_hbm >= t_mfma else round(issued_tf, 2), peak=PEAK_HBM if t_hbm >= t_mfma else PEAK_BF16_MFMA,

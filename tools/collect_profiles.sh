@@ -4,7 +4,7 @@
 # Kernel-trace statistics per config, the three PMC passes over the MLP kernels (separate runs, --kernel-trace only beside --pmc),
 # the two composite traffic passes, and the un-profiled microbenchmarks.  The profiled program itself follows `--`.
 set -u
-tag=${1:-r5}
+tag=${1:-r6}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$tag
 mkdir -p $OUT
