@@ -1,5 +1,5 @@
 """The driver's N > 1 invocation rehearsed at the widest width a one-GPU box allows (round 6).  The pool's process guard admits six GPU
-processes at a time -- this test process is one of them and torch.distributed.run's agent another -- so the rehearsal here runs FOUR gloo ranks time-slicing this GPU (the driver's
+processes at a time and this test process is one of them, so the rehearsal here runs FOUR gloo ranks time-slicing this GPU (the driver's
 own N = 4 command line); tools/rehearse_ranks.sh runs five outside pytest and keeps the lines (profiles/r6_bench_lines.json).  Checked: every
 rank is seen, the ranks' parameters agree after the timed steps (bench.py exits non-zero otherwise), losses are finite, the line carries
 the self-diagnosing fields (split_exchange on / off, launched vs replayed, wire time of the bucket) and the run stays far inside the
@@ -18,19 +18,37 @@ RANKS = 4
 
 
 def _driver_line(extra, port, timeout=900):
+    """bench.py as the four ranks torch.distributed.run would start (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), started
+    directly: the agent process would be a sixth GPU process beside this one and the four ranks -- exactly the pool's limit, and a run
+    that crosses it is killed whole.  The ranks' program is the same either way (bench.py reads the environment the agent would set);
+    the agent itself is exercised by tests/test_gpu_sharding.py::test_bench_line_under_torchrun_with_two_ranks."""
     import torch
     torch.cuda.empty_cache()          # this process's cached blocks (earlier full-size tests) go back to the device the four ranks share
-    env = dict(os.environ, NIW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(RANKS), "--master-addr", "127.0.0.1", "--master-port",
-           str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(RANKS), "--steps", "3", "--warmup", "2"] + extra
+    base = dict(os.environ, NIW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(RANKS),
+                OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(RANKS), "--steps", "3", "--warmup", "2"] + extra
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    import tempfile
+    files = [(tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")) for _ in range(RANKS)]       # (no pipe can fill while a peer is waited for)
+    procs = [subprocess.Popen(cmd, cwd=ROOT, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=files[r][0], stderr=files[r][1], text=True)
+             for r in range(RANKS)]
+    try:
+        for p in procs:
+            p.wait(timeout=timeout)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     wall = time.perf_counter() - t0
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines
+    outs = []
+    for fo, fe in files:
+        fo.seek(0); fe.seek(0)
+        outs.append((fo.read(), fe.read()))
+        fo.close(); fe.close()
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    lines = [l for out, _ in outs for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 alone prints
     line = json.loads(lines[0])
     assert line["n_gpus"] == RANKS and line["ranks_seen"] == RANKS and line["backend"] == "gloo"
     assert wall < 600, f"{wall:.0f} s: the driver allows 600"
