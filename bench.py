@@ -620,6 +620,8 @@ def main():
             def guarded(var, it, _orig=tr._capture, _tag=f"{tag}/{j}"):
                 err = None
                 try:
+                    if os.environ.get("NIW_TEST_FAIL_CAPTURE_RANK") == str(rank):      # (tests: the abort protocol without a broken device)
+                        raise engine.CaptureError("injected by NIW_TEST_FAIL_CAPTURE_RANK")
                     ok = _orig(var, it)
                 except engine.CaptureError as e:
                     ok, err = False, e

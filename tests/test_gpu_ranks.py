@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RANKS = 4
 
 
-def _driver_line(extra, port, timeout=900):
+def _driver_line(extra, port, timeout=900, env_extra=None):
     """bench.py as the four ranks torch.distributed.run would start (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), started
     directly: the agent process would be a sixth GPU process beside this one and the four ranks -- exactly the pool's limit, and a run
     that crosses it is killed whole.  The ranks' program is the same either way (bench.py reads the environment the agent would set);
@@ -25,7 +25,7 @@ def _driver_line(extra, port, timeout=900):
     import torch
     torch.cuda.empty_cache()          # this process's cached blocks (earlier full-size tests) go back to the device the four ranks share
     base = dict(os.environ, NIW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(RANKS),
-                OMP_NUM_THREADS="4")
+                OMP_NUM_THREADS="4", **(env_extra or {}))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(RANKS), "--steps", "3", "--warmup", "2"] + extra
     t0 = time.perf_counter()
     import tempfile
@@ -95,3 +95,14 @@ def test_four_ranks_all_eight_scenes_both_placements():
     assert {r["scene"]: r["rank"] for r in rep["scenes"]} == {sc: i % RANKS for i, sc in enumerate(configs.LLFF_TRAIN_VIEWS)}
     assert line["comm_bucket_bytes"] == 8 * 4 * (698256 - 18 * 128) + 4 * 128 * sum(configs.LLFF_TRAIN_VIEWS.values())
     print(f"4 gloo ranks, cfg4: {wall:.0f} s wall; shard {line['ms_per_step']:.1f} ms, replicas {rep['ms_per_step']:.1f} ms")
+
+
+def test_a_failed_capture_on_one_rank_costs_the_field_not_the_line():
+    """the replayed A/B leg: rank 2's capture "fails" (injected; a real failure leaves that rank's HIP state unusable).  Every rank must learn
+    of it host-side BEFORE any rank replays -- a replay's all-reduce would wait for rank 2 for ever -- skip the leg, and leave with exit
+    code 0 after rank 0 has printed the complete line, whose hip_graph_ab says what happened"""
+    line, wall = _driver_line(["--config", "cfg3", "--kernel-steps", "0"], 29737, env_extra={"NIW_TEST_FAIL_CAPTURE_RANK": "2"})
+    hg = line["hip_graph_ab"]
+    assert hg["replayed_ms"] is None and hg["launched_ms"] > 0 and "rank(s) [2]" in hg["capture_failed"], hg
+    assert line["strong"] is not None and line["split_exchange"]["off_ms"] > 0 and line["value"] > 0
+    print(f"4 gloo ranks, cfg3, capture failure injected on rank 2: {wall:.0f} s wall; line complete, hip_graph_ab = {hg}")
