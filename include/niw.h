@@ -229,6 +229,12 @@ int niw_draw_ray_idx(int64_t n_pixels, int64_t n, uint64_t seed, uint64_t draw, 
 int niw_convert_ndc(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view,
                     float near, float* center_ndc, float* ray_ndc, niw_stream_t stream);
 
+/* Reverse pass of niw_convert_ndc (round 6): gradients of the camera-frame centre / ray from those of the NDC centre / ray (either may be
+ * NULL = zero) -- autograd of camera.py:523-540 for rays that carry a gradient (warped rays in training, a refined pose at test time).
+ * center, ray: the FORWARD's inputs.  d_center / d_ray [n_views,n_rays_per_view,3] are overwritten. */
+int niw_convert_ndc_bwd(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view, float near,
+                        const float* d_center_ndc, const float* d_ray_ndc, float* d_center, float* d_ray, niw_stream_t stream);
+
 /* ------------------------------------------------------------------ gradient-free render of a pixel range, one call
  * Graph.render under torch.no_grad() (model/nerf.py:293-319): rays of the pixels first_pixel .. first_pixel+n_pixels-1 of every
  * view (camera.get_center_and_ray, camera.py:419-443) -> convert_NDC when `ndc` (camera.py:523-540) -> sample_depth
@@ -484,8 +490,9 @@ typedef struct niw_train_desc {
      * ground-truth poses; BASELINE configs[0], options/nerf_llff_repr.yaml).  warp_params == NULL selects it: rays of the cameras
      * `pose_init` (then REQUIRED: world->camera [n_views,3,4]; niw_raygen mode 1), no warp, no registration / alignment term
      * (w_align must be negative), no ray gradients (the dX chain stops above layer 0, SURVEY section 8(a) "Gradient routes");
-     * latent / d_warp / d_latent / poses are not touched and may be NULL.  With a warp, `density_noise` applies likewise and `ndc`
-     * is refused (the NDC gradient into the warp exists only on the autograd mirror). */
+     * latent / d_warp / d_latent / poses are not touched and may be NULL.  With a warp, `density_noise` and `ndc` apply likewise:
+     * the warped rays are re-parametrised behind the warp and the summed gradient routes go back through niw_convert_ndc_bwd before
+     * they reach the warp (model/nerf_inn_llff.py:627-641 under autograd). */
     float density_noise;        /* opt.nerf.density_noise_reg: N(0, density_noise^2) added to the raw density of every sample in BOTH passes
                                    (model/nerf.py:428-429), drawn by niw_normal_rng(noise_seed [+ 1 for the fine pass], draw); 0: none */
     int32_t ndc;                /* opt.camera.ndc: rays re-parametrised by niw_convert_ndc (camera.py:523-540) */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "niw_raygen": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "niw_draw_ray_idx": (_i, [_i64, _i64, _u64, _u64, _vp, _i64, _i64, _vp, _vp]),
     "niw_convert_ndc": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
+    "niw_convert_ndc_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp, _vp]),
     "niw_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "niw_warp_bwd_workspace_floats": (_i64, [_i, _i64]),
     "niw_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

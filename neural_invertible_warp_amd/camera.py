@@ -195,10 +195,11 @@ def get_3D_points_from_depth(opt, center, ray, depth, multi_samples=False):
 
 def convert_NDC(opt, center, ray, intr, near=1):
     """reference camera.py:523-540: rays re-parametrised in normalised device coordinates (near plane at z = `near`, +z forward).
-    Gradient-free inputs go through niw_convert_ndc; when a gradient can flow into `center` / `ray` (warped rays in training, a
-    refined pose at test time) the same formulas run as torch algebra so that autograd reaches the warp / the pose -- the kernel
-    has no backward, and dropping that gradient silently would stop the poses from training."""
-    if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad):
+    One launch (niw_convert_ndc); when a gradient can flow into `center` / `ray` (warped rays in training, a refined pose at test time)
+    its reverse pass is niw_convert_ndc_bwd (round 6; rounds 1-5 ran the formulas as torch algebra there) -- autograd reaches the warp /
+    the pose either way.  Inputs that are not float32 device tensors, or intrinsics that want a gradient, keep the torch algebra."""
+    on_device = center.is_cuda and center.dtype == torch.float32 and ray.dtype == torch.float32 and not intr.requires_grad
+    if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad) and not on_device:
         sx = (intr[:, 0, 0] / intr[:, 0, 2])[:, None]                   # focal / principal point, per view
         sy = (intr[:, 1, 1] / intr[:, 1, 2])[:, None]
         cx, cy, cz = center.unbind(dim=-1)

@@ -201,6 +201,37 @@ __global__ void ndc_kernel(const float* __restrict__ center, const float* __rest
     orr[i * 3] = sx * (rx / rz - cx / cz); orr[i * 3 + 1] = sy * (ry / rz - cy / cz); orr[i * 3 + 2] = 2.f * near / cz;
 }
 
+// The reverse pass of ndc_kernel (round 6): d(centre), d(ray) of the camera-frame rays from the gradients of the NDC centre and ray --
+// what autograd does to the reference's formulas (camera.py:523-540) when warped rays are re-parametrised in training.  With
+// t = (near - c_z) / r_z, p = c + t r (the origin slid onto the near plane), a = p_x / p_z, b = p_y / p_z:
+//   c' = (sx a, sy b, 1 - 2 near / p_z),   r' = (sx (r_x / r_z - a), sy (r_y / r_z - b), 2 near / p_z).
+// No gradient reaches the intrinsics (data).
+__global__ void ndc_bwd_kernel(const float* __restrict__ center, const float* __restrict__ ray, const float* __restrict__ intr, int B, long long R,
+                               float near, const float* __restrict__ g_oc, const float* __restrict__ g_or, float* __restrict__ g_c,
+                               float* __restrict__ g_r) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * R) return;
+    const int b = (int)(i / R);
+    const float rx = ray[i * 3], ry = ray[i * 3 + 1], rz = ray[i * 3 + 2];
+    const float c0 = center[i * 3], c1 = center[i * 3 + 1], c2 = center[i * 3 + 2];
+    const float t = (near - c2) / rz;
+    const float px = c0 + t * rx, py = c1 + t * ry, pz = c2 + t * rz;
+    const float sx = intr[b * 9 + 0] / intr[b * 9 + 2], sy = intr[b * 9 + 4] / intr[b * 9 + 5];
+    const float gc0 = g_oc ? g_oc[i * 3] : 0.f, gc1 = g_oc ? g_oc[i * 3 + 1] : 0.f, gc2 = g_oc ? g_oc[i * 3 + 2] : 0.f;
+    const float gr0 = g_or ? g_or[i * 3] : 0.f, gr1 = g_or ? g_or[i * 3 + 1] : 0.f, gr2 = g_or ? g_or[i * 3 + 2] : 0.f;
+    const float ipz = 1.f / pz, irz = 1.f / rz;
+    const float ga = sx * (gc0 - gr0), gb = sy * (gc1 - gr1);                       // d a, d b
+    const float gpx = ga * ipz, gpy = gb * ipz;
+    const float gpz = ((gc2 - gr2) * 2.f * near - ga * px - gb * py) * ipz * ipz;  // 1 - 2 near / p_z, 2 near / p_z, a, b
+    float drx = sx * gr0 * irz, dry = sy * gr1 * irz;
+    float drz = -(sx * gr0 * rx + sy * gr1 * ry) * irz * irz;
+    const float gt = gpx * rx + gpy * ry + gpz * rz;                                // p = c + t r
+    drx += t * gpx; dry += t * gpy; drz += t * gpz;
+    drz -= gt * t * irz;                                                             // t = (near - c_z) / r_z
+    g_c[i * 3] = gpx; g_c[i * 3 + 1] = gpy; g_c[i * 3 + 2] = gpz - gt * irz;
+    g_r[i * 3] = drx; g_r[i * 3 + 1] = dry; g_r[i * 3 + 2] = drz;
+}
+
 // ---------------------------------------------------------------- L1: MSE (base.py:209-211) + gather (nerf.py:279-281)
 // one workgroup of 1024 threads over all B*R*3 elements: fixed-order reduction, loss[0] overwritten
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ rgb, const float* __restrict__ image,
@@ -551,6 +582,16 @@ extern "C" int niw_convert_ndc(const float* center, const float* ray, const floa
     const long long n = (long long)n_views * n_rays_per_view;
     ndc_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(center, ray, intr, n_views, n_rays_per_view, near, center_ndc, ray_ndc);
     NIW_LAUNCH_CHECK("niw_convert_ndc");
+    return NIW_OK;
+}
+
+extern "C" int niw_convert_ndc_bwd(const float* center, const float* ray, const float* intr, int n_views, int64_t n_rays_per_view, float near,
+                                   const float* d_center_ndc, const float* d_ray_ndc, float* d_center, float* d_ray, niw_stream_t stream) {
+    NIW_REQUIRE(center && ray && intr && d_center && d_ray && (d_center_ndc || d_ray_ndc), "niw_convert_ndc_bwd: null pointer");
+    NIW_REQUIRE(n_views > 0 && n_rays_per_view > 0 && near > 0.f, "niw_convert_ndc_bwd: empty input or near <= 0");
+    const long long n = (long long)n_views * n_rays_per_view;
+    ndc_bwd_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(center, ray, intr, n_views, n_rays_per_view, near, d_center_ndc, d_ray_ndc, d_center, d_ray);
+    NIW_LAUNCH_CHECK("niw_convert_ndc_bwd");
     return NIW_OK;
 }
 

@@ -140,6 +140,34 @@ __global__ void combine_kernel(CombineArgs a) {
     }
 }
 
+// warp + NDC: the gradient routes into the NDC rays of the share, summed in autograd's accumulation order over the WHOLE window (zero
+// outside the share), as the two operands of niw_convert_ndc_bwd
+struct NdcRoutesArgs {
+    const float* d_ray[4];
+    const float* d_center[2];
+    float* g_ray;               // [V R 3]
+    float* g_center;
+    long long total, a3, b3;    // window floats; the share as floats [a3, b3)
+};
+__global__ void ndc_routes_kernel(NdcRoutesArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    float dr = 0.f, dc = 0.f;
+    if (i >= a.a3 && i < a.b3) {
+        const long long j = i - a.a3;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (a.d_ray[k]) { dr = first ? a.d_ray[k][j] : add_rn(dr, a.d_ray[k][j]); first = false; }
+        first = true;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (a.d_center[k]) { dc = first ? a.d_center[k][j] : add_rn(dc, a.d_center[k][j]); first = false; }
+    }
+    a.g_ray[i] = dr;
+    a.g_center[i] = dc;
+}
+
 __global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -255,6 +283,8 @@ struct Layout {
     float *packed_c, *packed_f, *save_c, *save_f, *gradws, *partial;
     float *d_rgb, *d_rgb_f, *d_rgb_s, *d_sigma_s, *comp_d_ray_c, *comp_d_ray_f, *mlp_d_c, *mlp_d_f;   // mlp_d_*: [2][n][3] = {d_center, d_ray}
     float *noise_c, *noise_f;        // density noise of the two passes (density_noise > 0)
+    float *ray_cam, *center_cam;     // warp + NDC: the camera-frame rays the warp produced (L.ray / L.center then hold their NDC form)
+    float *ndc_g;                    // warp + NDC: [4][V R 3] summed gradient routes of the NDC rays {d ray', d centre'}, then {d ray, d centre}
     float *resid_c, *resid_f, *d_rgb_s_c, *d_sigma_s_c;   // one-launch compositing + loss + backward: residuals [n,3]; the coarse pass's own sample gradients
     float *mom, *poses, *d_target, *d_warped, *warp_ws, *d_w_emb, *d_view_b, *d_w_head, *prep_bwd_ws;
     long long total;
@@ -266,7 +296,7 @@ int check_desc(const niw_train_desc* d) {
     NIW_REQUIRE(d->loss && d->d_nerf, "niw_train_step: loss and gradient outputs are required");
     if (d->warp_params) {
         NIW_REQUIRE(d->latent && d->d_warp && d->d_latent, "niw_train_step: the warp needs its latent table and the two gradient outputs");
-        NIW_REQUIRE(!d->ndc, "niw_train_step: camera.ndc with warped rays runs on the autograd mirror (the NDC gradient into the warp)");
+        NIW_REQUIRE(!d->ndc || d->ndc_near > 0.f, "niw_train_step: ndc_near=%g", (double)d->ndc_near);
     } else {
         // the vanilla model (model/nerf.py:251-288): rays of the given cameras, nothing pose-related is trained
         NIW_REQUIRE(d->pose_init, "niw_train_step: without a warp the rays come from the cameras `pose_init` (world->camera, required)");
@@ -337,6 +367,7 @@ Layout make_layout(const niw_train_desc* d, float* base) {
     L.d_rgb_s_c = L.d_rgb_s; L.d_sigma_s_c = L.d_sigma_s;
     if (T) { L.resid_f = ws.take(3 * n); L.d_rgb_s_c = ws.take(3 * n * S); L.d_sigma_s_c = ws.take(n * S); }
     if (d->density_noise > 0.f) { L.noise_c = ws.take(n * S); if (T) L.noise_f = ws.take(n * T); }
+    if (d->warp_params && d->ndc) { L.ray_cam = ws.take(3 * L.V * L.R); L.center_cam = ws.take(3 * L.V * L.R); L.ndc_g = ws.take(4 * 3 * L.V * L.R); }
     L.mom = ws.take(2 * 16 * L.V);                     // double [V,16]
     L.poses = ws.take(12 * L.V);
     L.d_target = ws.take(3 * P); L.d_warped = ws.take(3 * P);
@@ -437,8 +468,10 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         NIW_RUN(niw_launch_warp_prep_fwd_main(d->warp_params, (int)V, L.prep_ws, L.w_emb, L.view_b, L.w_head, st));
         NIW_RUN(niw_warp_fwd(L.w_emb, L.view_b, L.w_head, L.stacked_in, (int)V, 2 * R, d->chan_w, d->index_window, d->window_dev, d->use_index_window, nullptr,
                              nullptr, 0, L.warped, L.xin, stream));
-        split_rays_kernel<<<(unsigned)((V * R * 3 + 255) / 256), 256, 0, st>>>(L.warped, V, R, L.ray, L.center);
+        split_rays_kernel<<<(unsigned)((V * R * 3 + 255) / 256), 256, 0, st>>>(L.warped, V, R, d->ndc ? L.ray_cam : L.ray, d->ndc ? L.center_cam : L.center);
         NIW_LAUNCH_CHECK("niw_train_step (split rays)");
+        // camera.ndc: every stage below sees the NDC form of the warped rays (model/nerf_inn_llff.py:627-641 -> camera.py:523-540)
+        if (d->ndc) NIW_RUN(niw_convert_ndc(L.center_cam, L.ray_cam, d->intr + 9ll * d->view0, (int)V, R, d->ndc_near, L.center, L.ray, stream));
     }
     if (lane) {
         NIW_HIP(hipEventRecord(lane->warped, st), "warped");
@@ -538,6 +571,23 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
         c.present[0] = loss_c; c.present[1] = loss_f; c.present[2] = align && L.n_own > 0;
         c.resid[0] = one_c ? L.resid_c : nullptr; c.resid[1] = one_f ? L.resid_f : nullptr;
         c.resid_n = 3 * n; c.n_norm = d->mse_norm;
+        if (warp && d->ndc) {
+            // the routes meet at the NDC rays: their ordered sums go back through the re-parametrisation first (the launch the mirror's
+            // autograd makes, ops._ConvertNDC), and reach the combine kernel as ONE ray route and ONE centre route over the whole window
+            NdcRoutesArgs r{};
+            for (int k = 0; k < 4; ++k) r.d_ray[k] = c.d_ray[k];
+            for (int k = 0; k < 2; ++k) r.d_center[k] = c.d_center[k];
+            const long long VR3 = V * R * 3;
+            r.g_ray = L.ndc_g; r.g_center = L.ndc_g + VR3; r.total = VR3; r.a3 = 3 * a; r.b3 = 3 * (a + n);
+            ndc_routes_kernel<<<(unsigned)((VR3 + 255) / 256), 256, 0, X>>>(r);
+            NIW_LAUNCH_CHECK("niw_train_step (NDC routes)");
+            NIW_RUN(niw_convert_ndc_bwd(L.center_cam, L.ray_cam, d->intr + 9ll * d->view0, (int)V, R, d->ndc_near, r.g_center, r.g_ray, L.ndc_g + 3 * VR3,
+                                        L.ndc_g + 2 * VR3, sx));
+            for (int k = 0; k < 4; ++k) c.d_ray[k] = nullptr;
+            for (int k = 0; k < 2; ++k) c.d_center[k] = nullptr;
+            c.d_ray[0] = L.ndc_g + 2 * VR3; c.d_center[0] = L.ndc_g + 3 * VR3;
+            c.a = 0; c.b = V * R;                                  // (the whole window: zero outside the share already)
+        }
         const long long work = warp ? (V * R * 3 > c.lat_n ? V * R * 3 : c.lat_n) : 1;
         combine_kernel<<<(unsigned)((work + 255) / 256), 256, 0, X>>>(c);
         NIW_LAUNCH_CHECK("niw_train_step (combine)");

@@ -113,8 +113,6 @@ class FusedStep:
         if opt.nerf.sample_stratified and opt.nerf.stratified_rng != "philox":
             return "stratified draws injected through torch.rand"
         vanilla = getattr(trainer, "family", None) == "vanilla"
-        if opt.camera.ndc and not vanilla:
-            return "camera.ndc with warped rays (the gradient through the NDC reparametrisation runs as torch algebra)"
         if opt.nerf.density_noise_reg and opt.nerf.get("density_noise_rng") != "philox":
             return "density noise injected through torch.randn"
         if opt.nerf.setbg_opaque:

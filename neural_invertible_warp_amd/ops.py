@@ -118,12 +118,39 @@ def draw_ray_idx(n_pixels, n, seed, draw, device, first=0, stride=1, draw_dev=No
     return out
 
 
-def convert_ndc(center, ray, intr, near=1.0):
-    center, ray, intr = _f32(center, "center"), _f32(ray, "ray"), _f32(intr, "intr")
+def _convert_ndc_raw(center, ray, intr, near):
     oc, orr = torch.empty_like(center), torch.empty_like(ray)
     _lib.call("niw_convert_ndc", _p(center), _p(ray), _p(intr), center.shape[0], center.shape[1], float(near),
               _p(oc), _p(orr), _stream())
     return oc, orr
+
+
+class _ConvertNDC(torch.autograd.Function):
+    """niw_convert_ndc with niw_convert_ndc_bwd as its reverse pass (round 6): the gradient of warped rays through the NDC
+    re-parametrisation (reference camera.py:523-540 under autograd) as one launch, the same launch niw_train_step makes"""
+
+    @staticmethod
+    def forward(ctx, center, ray, intr, near):
+        ctx.save_for_backward(center, ray, intr)
+        ctx.near = float(near)
+        return _convert_ndc_raw(center, ray, intr, near)
+
+    @staticmethod
+    def backward(ctx, g_center, g_ray):
+        center, ray, intr = ctx.saved_tensors
+        gc = None if g_center is None else _f32(g_center, "d_center_ndc")
+        gr = None if g_ray is None else _f32(g_ray, "d_ray_ndc")
+        d_center, d_ray = torch.empty_like(center), torch.empty_like(ray)
+        _lib.call("niw_convert_ndc_bwd", _p(center), _p(ray), _p(intr), center.shape[0], center.shape[1], ctx.near, _p(gc), _p(gr), _p(d_center), _p(d_ray),
+                  _stream())
+        return d_center, d_ray, None, None
+
+
+def convert_ndc(center, ray, intr, near=1.0):
+    center, ray, intr = _f32(center, "center"), _f32(ray, "ray"), _f32(intr, "intr")
+    if torch.is_grad_enabled() and (center.requires_grad or ray.requires_grad):
+        return _ConvertNDC.apply(center, ray, intr, float(near))
+    return _convert_ndc_raw(center, ray, intr, near)
 
 
 def sample_stratified(u, n_rays, S, depth_range, param, device):

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=None, rays=None, S=16):
+def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=None, rays=None, S=16, ndc=False, noise=None):
     from neural_invertible_warp_amd import configs, engine
     if cfg == "dtu":
         opt = configs.cfg5_barf_inn_dtu(device=DEV)
@@ -22,6 +22,7 @@ def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=No
         B = B or 5
         var0, init = engine.synthetic_scene(opt, B), None
     opt.nerf.sample_stratified = stratified
+    opt.camera.ndc, opt.nerf.density_noise_reg = ndc, noise
     opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = rays or B * 37, S, 40
     opt.inn.real_nvp.max_pe_iter = 20                       # bands, windows and learning rates all move within the run
     if opt.nerf.fine_sampling:
@@ -182,9 +183,13 @@ def test_fused_iteration_is_refused_or_bypassed_where_it_does_not_apply():
     from neural_invertible_warp_amd import configs, engine
     from neural_invertible_warp_amd._lib import NiwError
     opt = configs.cfg3_barf_inn_llff(device=DEV)
-    opt.camera.ndc = True
+    opt.nerf.setbg_opaque = True                 # (NDC and density noise are inside the call since round 6; an opaque background is not)
     tr = engine.INNTrainer(opt, 3, fused_step="auto")
-    assert tr.fused is None and "ndc" in tr.fused_fallback_reason
+    assert tr.fused is None and "setbg_opaque" in tr.fused_fallback_reason
+    opt = configs.cfg3_barf_inn_llff(device=DEV)
+    opt.nerf.density_noise_reg, opt.nerf.density_noise_rng = 1.0, "torch"      # a harness that injects torch.randn draws
+    tr = engine.INNTrainer(opt, 3, fused_step="auto")
+    assert tr.fused is None and "torch.randn" in tr.fused_fallback_reason
     with pytest.raises(NiwError, match="does not cover"):
         engine.INNTrainer(configs.cfg3_barf_inn_llff(device=DEV), 3, ray_sampler="randperm", fused_step=True)
 
@@ -319,3 +324,62 @@ def test_vanilla_iteration_with_density_noise_vs_oracle():
     for part in (rows[:half], rows[half:]):
         assert statistics.median(e for _, e, _, _ in part) <= 3 * statistics.median(t for _, _, t, _ in part) + 2e-4
     print(f"vanilla step with density noise: losses to 2e-6; worst gradient tensor {worst[2]}: HIP {worst[0]:.2e} of max vs float64, torch fp32 {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("cfg,world,noise", [("cfg3_barf_inn_llff", 1, None), ("cfg2_nerf_inn_llff_hier", 1, 0.5), ("cfg3_barf_inn_llff", 3, None)])
+def test_fused_iteration_with_ndc_behind_the_warp_equals_the_mirror(cfg, world, noise):
+    """round 6: camera.ndc with WARPED rays inside niw_train_step -- the rays are re-parametrised behind the warp (niw_convert_ndc) and the
+    summed gradient routes go back through niw_convert_ndc_bwd before they reach the warp, the launch the mirror's autograd makes
+    (ops._ConvertNDC) -- unsharded, with the fine pass (there also with density noise in both passes, nerf.py:428-429: the INN models take
+    it from the same keyed streams as the vanilla one), and as every rank of a three-rank job"""
+    for rank in range(world):
+        runs = []
+        for fused in (False, True):
+            tr, var0 = _trainer(cfg, fused, rank=rank, world=world, ndc=True, stratified=world == 1, noise=noise)
+            if world > 1:
+                with torch.no_grad():
+                    g = torch.Generator().manual_seed(11)
+                    tr.warp_mlp.flat_params.add_(0.01 * torch.randn(tr.warp_mlp.flat_params.shape, generator=g).to(DEV))
+            losses = []
+            for _ in range(3):
+                loss = tr.train_iteration(type(var0)(var0))
+                losses.append({k: float(v.detach()) for k, v in loss.items()})
+            torch.cuda.synchronize()
+            runs.append((tr, losses))
+        (a, la), (b, lb) = runs
+        for x, y in zip(la, lb):
+            for k in x:
+                if k == "all":
+                    assert abs(x[k] - y[k]) <= 1e-6 * max(abs(x[k]), 1e-6), (k, x[k], y[k])
+                else:
+                    assert x[k] == y[k], (rank, k, x[k], y[k])
+        assert torch.equal(a.bucket.flat, b.bucket.flat), (rank, float((a.bucket.flat - b.bucket.flat).abs().max()))
+        for fa, fb in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
+            assert torch.equal(fa, fb)
+        # the warp does receive a gradient through the re-parametrisation
+        n_nets = len(a.nets)
+        assert float(a.bucket.segment(n_nets).abs().max()) > 0
+
+
+def test_ndc_reverse_pass_vs_autograd_of_the_reference_formulas():
+    """niw_convert_ndc_bwd against torch autograd of the oracle's convert_ndc (reference camera.py:523-540) in float64, on rays in front of
+    the cameras; and the forward against the same"""
+    from neural_invertible_warp_amd import ops
+    from oracle import niw_oracle as O
+    gen = torch.Generator().manual_seed(5)
+    B, R = 3, 257
+    center = (torch.randn(B, R, 3, generator=gen) * 0.2)
+    ray = torch.randn(B, R, 3, generator=gen) * 0.5
+    ray[..., 2] = ray[..., 2].abs() + 0.5                        # +z forward
+    intr = torch.tensor([[320.0, 0, 200.0], [0, 300.0, 150.0], [0, 0, 1]]).repeat(B, 1, 1) * torch.linspace(0.9, 1.1, B)[:, None, None]
+    intr[:, 2, 2] = 1.0
+    gc, gr = torch.randn(B, R, 3, generator=gen), torch.randn(B, R, 3, generator=gen)
+    c64, r64 = center.double().requires_grad_(True), ray.double().requires_grad_(True)
+    oc64, or64 = O.convert_ndc(c64, r64, intr.double())
+    ((oc64 * gc.double()).sum() + (or64 * gr.double()).sum()).backward()
+    cg, rg = center.to(DEV).requires_grad_(True), ray.to(DEV).requires_grad_(True)
+    oc, orr = ops.convert_ndc(cg, rg, intr.to(DEV))
+    ((oc * gc.to(DEV)).sum() + (orr * gr.to(DEV)).sum()).backward()
+    rel = lambda x, y: float((x.detach().cpu().double() - y.detach()).abs().max() / y.detach().abs().max())
+    assert rel(oc, oc64) < 2e-6 and rel(orr, or64) < 2e-6
+    assert rel(cg.grad, c64.grad) < 5e-6 and rel(rg.grad, r64.grad) < 5e-6, (rel(cg.grad, c64.grad), rel(rg.grad, r64.grad))
