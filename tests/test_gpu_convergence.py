@@ -22,3 +22,36 @@ def test_trains_a_consistent_scene():
     assert psnr[0] < 16 and psnr[-1] > 30 and psnr[-1] - psnr[0] > 15, psnr          # 12 dB -> ~40 dB on MI355X
     assert all(math.isfinite(h[3]) for h in hist[1:])                                # pose evaluation runs on the trained model
     assert rel[-1] < rel[0] - 0.7, rel                                               # 5.9 deg (identity poses) -> ~4 deg
+
+
+def test_vanilla_model_trains_the_scene_through_the_one_call_iteration():
+    """round 6: BASELINE configs[0] end to end -- the vanilla model (options/nerf_llff_repr.yaml: ReLU density with density noise, coarse +
+    fine pass) on the ground-truth cameras of the same analytic scene, every iteration ONE niw_train_step call (warp_params = NULL) + one
+    Adam launch.  The scene sits at depths 2..5, so the yaml's metric depth range [0, 1] is widened; nothing else changes."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import teacher_student_demo as demo
+    from neural_invertible_warp_amd import camera, configs, engine
+    from neural_invertible_warp_amd.util import edict
+    dev, B, H, W, steps = "cuda:0", 8, 40, 56, 600
+    opt = configs.cfg1_nerf_llff_repr(device=dev)
+    opt.H, opt.W, opt.data.image_size = H, W, [H, W]
+    opt.max_iter, opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine = steps, 2048, 48, 48
+    opt.nerf.depth.range = [1.0, 7.0]
+    gen = torch.Generator().manual_seed(0)
+    pose = camera.lie.se3_to_SE3(torch.randn(B, 6, generator=gen) * torch.tensor([0.06, 0.06, 0.03, 0.15, 0.15, 0.05])).to(dev)[:, :3].contiguous()
+    intr = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(B, 1, 1).to(dev)
+    image = demo.render_teacher(opt, pose, intr)
+    tr = engine.NeRFTrainer(opt, B, seed=0)
+    assert tr.fused is not None, tr.fused_fallback_reason
+    var0 = edict(idx=torch.arange(B), image=image, intr=intr, pose=pose)
+    psnr = []
+    for it in range(steps):
+        loss = tr.train_iteration(edict(var0))
+        if it % 100 == 0 or it == steps - 1:
+            psnr.append((-10 * math.log10(float(loss.render.detach())), -10 * math.log10(float(loss.render_fine.detach()))))
+    print("vanilla one-call training, PSNR (coarse, fine) every 100 steps:", [(round(a, 2), round(b, 2)) for a, b in psnr])
+    assert all(math.isfinite(a) and math.isfinite(b) for a, b in psnr)
+    assert psnr[-1][1] > psnr[0][1] + 10 and psnr[-1][1] > 25, psnr
