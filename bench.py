@@ -605,6 +605,13 @@ def main():
                 tr.comm_events = None
         value_ = float(loss_.all.detach())
         if not math.isfinite(value_):
+            # say what diverged and where: which rank, which trainer, every loss term, and whether parameters / gradients are finite
+            terms = {k: float(v.detach()) for k, v in loss_.items()}
+            state = [dict(scene=getattr(tr, "scene_name", None), it=tr.it, hip_graph=bool(getattr(tr, "hip_graph", False)),
+                          split_exchange=str(getattr(tr, "split_exchange", None)),
+                          finite_params=[bool(torch.isfinite(f).all()) for f in tr._flats()],
+                          finite_grads=bool(torch.isfinite(tr.bucket.flat).all())) for tr, *_ in loads_]
+            print(f"bench.py: rank {rank}: non-finite loss {terms}; trainers {state}", file=sys.stderr, flush=True)
             raise SystemExit(f"bench.py: the training loss is {value_} after {n_warm + args.steps} iterations -- a timing of a diverged "
                              "run is not a measurement")
         mean = lambda v: sum(v) / len(v) if v else None
@@ -850,6 +857,12 @@ def main():
         if dist.is_initialized():
             dist.destroy_process_group()
 
+    # a fingerprint of the trained state after the headline's timed steps: two runs of the same command line must print the same one (the
+    # kernels and the exchange are deterministic) -- a cheap detector of anything that corrupts a step
+    try:
+        param_checksum = repr(sum(float(f.double().sum()) for tr, *_ in loads for f in tr._flats())) if capture_abort is None else None
+    except RuntimeError:
+        param_checksum = None
     # peak device memory of the run's trainers (torch's allocator: workspaces, batch, parameters), max over ranks
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     if world > 1 and capture_abort is None:
@@ -959,7 +972,7 @@ def main():
                comm_wire_ms=round(wire_ms(bucket_bytes, world), 4) if dist_backend else None,
                comm_wire_model=f"ring all-reduce: 2 (N - 1) / N x bucket bytes over one xGMI link per neighbour at {XGMI_LINK_GBPS:.0f} GB/s; comm_ms well above it "
                                "= a latency-bound exchange (2 (N - 1) hops), not a bandwidth-bound one" if dist_backend else None,
-               split_exchange=split_ab, hip_graph_ab=graph_ab, peak_memory_gb=round(peak_mem, 2),
+               split_exchange=split_ab, hip_graph_ab=graph_ab, peak_memory_gb=round(peak_mem, 2), param_checksum=param_checksum,
                launches_per_step=("one niw_train_step call (vanilla model: front, noise draws, ray generation, two field passes with compositing + loss "
                                   "+ backward, closing kernel) + one Adam launch" if args.config == "cfg1" else
                                   "one niw_train_step call (22 kernel launches for a single-pass config, 29 with the fine pass) + gradient exchange + one Adam launch")

@@ -430,3 +430,44 @@ def test_one_launch_form_refuses_shapes_outside_the_span_kernels():
         with pytest.raises(NiwError, match="one-launch form"):
             _lib.call("niw_composite_mse_train", P(z(N, 3)), P(z(N, S, 3)), P(z(N, S)), P(z(N, S)), N, S, P(z(B, 3, hw)), None, B, R, hw, 0, 24.0, 1.0,
                       *[P(o) for o in out], ops._stream())
+
+
+@pytest.mark.parametrize("case", ["cfg3", "cfg2", "dtu", "cfg3_rank1of3", "cfg2_ndc_noise", "vanilla", "cfg3_mirror"])
+def test_train_step_never_reads_memory_it_has_not_written(case):
+    """round 6: the one-call iteration (and the mirror) with EVERY uninitialised buffer hostile -- torch.empty filled with NaN from the
+    first allocation on (torch.utils.deterministic.fill_uninitialized_memory), and the persistent workspace re-filled with NaN, then with
+    all-ones bits (NaN as float, -1 as integer), before every iteration -- must train bit for bit like the plain run: nothing reads a
+    workspace piece, a pad column, a partial tile or a loss slot before this iteration has written it.  (Fresh device memory comes zeroed
+    and recycled memory holds last iteration's benign values, so an uninitialised read would otherwise stay invisible until several
+    processes share a device.)"""
+    from tests.test_gpu_fused_step import _trainer, _vanilla_trainer
+    make = {"cfg3": lambda: _trainer("cfg3_barf_inn_llff", True), "cfg2": lambda: _trainer("cfg2_nerf_inn_llff_hier", True),
+            "dtu": lambda: _trainer("dtu", True), "cfg3_rank1of3": lambda: _trainer("cfg3_barf_inn_llff", True, rank=1, world=3, stratified=False),
+            "cfg2_ndc_noise": lambda: _trainer("cfg2_nerf_inn_llff_hier", True, ndc=True, noise=0.5), "vanilla": lambda: _vanilla_trainer(True),
+            "cfg3_mirror": lambda: _trainer("cfg3_barf_inn_llff", False)}[case]
+
+    def run(poison):
+        tr, var0 = make()
+        losses = []
+        for i in range(3):
+            ws = getattr(tr.fused, "ws", None) if tr.fused is not None else None
+            if poison and ws is not None:
+                ws.fill_(float("nan")) if i % 2 == 0 else ws.view(torch.int32).fill_(-1)
+            loss = tr.train_iteration(type(var0)(var0))
+            losses.append({k: float(v.detach()) for k, v in loss.items()})
+        torch.cuda.synchronize()
+        return tr, losses
+
+    a, la = run(False)
+    det, fill = torch.are_deterministic_algorithms_enabled(), torch.utils.deterministic.fill_uninitialized_memory
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        b, lb = run(True)
+    finally:
+        torch.use_deterministic_algorithms(det)
+        torch.utils.deterministic.fill_uninitialized_memory = fill
+    assert la == lb, (la, lb)
+    assert torch.equal(a.bucket.flat, b.bucket.flat)
+    for x, y in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
+        assert torch.equal(x, y)
