@@ -160,8 +160,22 @@ struct FwdEpilogue {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) col[c] = fmaf(cw[c * 64 + nb * 16 + r], v, col[c]);
             }
-            if (SAVE && (r & 3) == 3)      // registers r-3 .. r = four consecutive rows: one 16-byte store into the quad-row image
+            if (SAVE && (r & 3) == 3) {    // registers r-3 .. r = four consecutive rows: one 16-byte store into the quad-row image
                 buf_store4(out[nb * 16 + r - 3], out[nb * 16 + r - 2], out[nb * 16 + r - 1], v, win.rsrc(nb * 32), win.voff4, 8 * (r >> 2) * win.pitch4);
+                if (HEAD == 2) {
+                    // The colour layer's hidden values die with this store, so the compiler reuses their registers at once -- for the mask
+                    // arithmetic below (`bits(v) + 0x7fffffff`) -- and a vector write of a buffer_store_dwordx4's data registers in the very
+                    // next instruction reaches memory INSTEAD of the data whenever another wave shares the SIMD (the gfx950 store-data
+                    // hazard; LLVM pads only immediate soffsets).  Rounds 3-5 relied on this kernel's one wave per SIMD; round 6 measured
+                    // that a wave of ANOTHER kernel -- the library's own second stream, another process on the device -- triggers it just
+                    // the same (tools/store_war_hazard_foreign.hip: 2.2e5 of 5.4e8 stores; a saved +0.0 then reads 0x7fffffff = NaN, and one
+                    // did: a rank diverged to NaN while four processes shared a GPU).  One s_nop 0 between the two is enough (0 of 5.4e8)
+                    // and free beside an MFMA chain; the scheduling barriers keep it where it is.
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 0");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             if (SAVE && RELU) {
                 // v = max(x, 0) is +0.0 or positive: v > 0  <=>  bits(v) + 0x7fffffff carries into bit 31.  One add and one
                 // funnel shift per value ((mbits << 1) | bit 31 of the sum); the compare / select / or form cost three.

@@ -741,6 +741,15 @@ class INNTrainer:
         # (round 3: no collective sits inside the forward any more -- the warp and the alignment term are replicated, ..parallel --
         # so a sharded iteration is captured like any other: forward + backward + gather | all-reduce, eager | Adam)
         torch.cuda.synchronize()                    # (`var` holds the trainer's own copies of the batch: the graph reads them in place)
+        # No cyclic garbage collection while the stream is capturing (round 6): a collection that starts inside the capture window finalises
+        # whatever unreachable objects exist at that moment -- graphs, events and streams of trainers long out of use among them -- and a
+        # HIP call from such a finaliser on the capturing thread aborts the process ("Fatal Python error: Aborted ... Garbage-collecting",
+        # seen once the iteration allocated enough Python objects to cross a collection threshold inside the window).  Collect first,
+        # then keep the collector off until the capture has ended.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             # ranks with a live RCCL communicator: its watchdog thread polls events while we capture, which "global" error mode
             # would treat as a capture violation
@@ -761,6 +770,9 @@ class INNTrainer:
             # offer: fail loudly and name the switch
             raise CaptureError(f"HIP-graph capture of the train iteration failed ({type(e).__name__}: {e}); "
                                "run with hip_graph=False (bench.py --hip-graph off)") from e
+        finally:
+            if gc_was_on:
+                gc.enable()
         self._captured = (fb, adam, loss)
         self._captured_addresses = self._capture_addresses()
         return True

@@ -28,9 +28,11 @@ def test_the_checker_fires_on_the_microbenchmark_that_demonstrates_the_hazard():
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-def test_training_forward_keeps_one_wave_per_simd():
-    """mlp_fwd_kernel<true> keeps adjacent store / vector-write pairs (the descriptor form costs it 0.4 % in scalar-register spills); they
-    are safe only while its register count forbids a second wave on the SIMD: assert that occupancy at build level"""
+def test_training_forward_has_no_adjacent_store_overwrite_pair():
+    """rounds 3-5 let mlp_fwd_kernel<true> keep 12 adjacent store / vector-write pairs because its register count forbids a second wave OF
+    ITS OWN on the SIMD.  Round 6: a wave of another kernel (the library's second stream, another process) on the SIMD triggers the hazard
+    just the same (tools/store_war_hazard_foreign.hip) -- a saved +0.0 became 0x7fffffff = NaN in a run where four processes shared a GPU.
+    The pairs are gone (one s_nop 0 behind the colour layer's stores); no occupancy excuses an adjacent site any more."""
     import importlib.util
     import tempfile
     spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
@@ -41,6 +43,5 @@ def test_training_forward_keeps_one_wave_per_simd():
         found = {k: v for k, v in mod.scan(asm).items() if "mlp_fwd_kernel" in k}
         text = open(asm).read()
     assert "mlp_fwd_kernelILb1E" in text, "the training forward is not in the assembly"
-    train = {k: v for k, v in found.items() if "mlp_fwd_kernelILb1E" in k}
-    for kernel, (adjacent, windowed, occupancy) in train.items():
-        assert occupancy == 1, f"{kernel}: {adjacent} adjacent store / vector-write pairs at register occupancy {occupancy}"
+    for kernel, (adjacent, windowed, occupancy) in found.items():
+        assert adjacent == 0, f"{kernel}: {adjacent} adjacent store / vector-write pairs"

@@ -2,7 +2,8 @@
 a buffer_store_dwordx3/x4 whose soffset is an SGPR, followed IMMEDIATELY by a vector instruction that rewrites one of its data
 registers, stores the new value when two or more waves share a SIMD.  LLVM inserts the wait state only for stores with an immediate
 soffset, so hipcc can emit the pair.  This script compiles every csrc/*.hip to assembly and lists the kernels that contain it, with the
-occupancy their register count allows; kernels that can never have a second wave on their SIMD are safe.  Round 4: the scan covers
+occupancy their register count allows (rounds 3-5 took kernels that can never have a second wave of their own on a SIMD to be safe; round 6
+measured that a co-resident wave of ANOTHER kernel triggers the hazard too, so every adjacent site is now an error).  Round 4: the scan covers
 LLVM's 2-wait-state window (an `s_nop N` counts N + 1), separating ADJACENT sites (the measured failure) from sites one instruction
 further (measured safe: profiles/r4_store_hazard.jsonl, 0 of 67 M for x2 / x3 / x4), and `self_test()` proves that the scan fires on
 the microbenchmark's own assembly.
@@ -109,7 +110,9 @@ def main():
         for src, out in zip(srcs, outs):
             for kernel, (adjacent, windowed, occupancy) in scan(out).items():
                 pinned = any(name in kernel for name in ONE_WORKGROUP_PER_CU_BY_LDS)
-                safe = adjacent == 0 or occupancy == 1 or pinned
+                # round 6: one wave per SIMD of THIS kernel is no protection -- a wave of another kernel (a second stream, another process)
+                # on the SIMD triggers the hazard just the same (tools/store_war_hazard_foreign.hip): no adjacent site anywhere
+                safe = adjacent == 0
                 unsafe += 0 if safe else 1
                 print(f"{os.path.basename(src)}: {kernel[:90]}: {adjacent} adjacent site(s), {windowed} more inside the {WINDOW}-wait-state window (measured safe), "
                       f"register occupancy {occupancy}{' (one workgroup per CU by its LDS request)' if pinned and occupancy != 1 else ''}: {'ok' if safe else 'UNSAFE'}")
