@@ -162,6 +162,7 @@ struct FwdEpilogue {
             }
             if (SAVE && (r & 3) == 3) {    // registers r-3 .. r = four consecutive rows: one 16-byte store into the quad-row image
                 buf_store4(out[nb * 16 + r - 3], out[nb * 16 + r - 2], out[nb * 16 + r - 1], v, win.rsrc(nb * 32), win.voff4, 8 * (r >> 2) * win.pitch4);
+#ifndef NIW_FWD_KEEP_HAZARD      // (diagnostic build: make VARIANT=hazard EXTRA=-DNIW_FWD_KEEP_HAZARD -- the pairs as rounds 3-5 shipped them)
                 if (HEAD == 2) {
                     // The colour layer's hidden values die with this store, so the compiler reuses their registers at once -- for the mask
                     // arithmetic below (`bits(v) + 0x7fffffff`) -- and a vector write of a buffer_store_dwordx4's data registers in the very
@@ -175,6 +176,7 @@ struct FwdEpilogue {
                     asm volatile("s_nop 0");
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
             }
             if (SAVE && RELU) {
                 // v = max(x, 0) is +0.0 or positive: v > 0  <=>  bits(v) + 0x7fffffff carries into bit 31.  One add and one
