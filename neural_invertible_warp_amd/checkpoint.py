@@ -49,6 +49,10 @@ def _optimizers(trainer):
     n_nets = len(trainer.nets)
     o = opt.optim
     optim = torch.optim.Adam([dict(params=list(net.parameters()), lr=o.lr) for net in trainer.nets])
+    if getattr(trainer, "family", None) == "vanilla":
+        # the vanilla model (reference model/nerf.py:34-47): ONE optimizer, one param group per network, one scheduler
+        sched = torch.optim.lr_scheduler.ExponentialLR(optim, gamma=trainer.gammas[0])
+        return dict(optim=optim, sched=sched), dict(optim=list(range(n_nets)))
     # optim_pose: group 0 = warp network, group 1 = latent table; a group the options switch off
     # (inn.optimize.enabled / warp_latent.optimize.enabled, barf_inn_llff.py:88-93) is absent, as in the reference
     pose_modules = [(n_nets, trainer.warp_mlp), (n_nets + 1, trainer.warp_latent)]
@@ -73,7 +77,7 @@ def optimizer_state_dicts(trainer):
     """-> {optim, optim_pose, sched, sched_pose} state dicts in torch format for the trainer's current step"""
     objs, groups = _optimizers(trainer)
     it = trainer.it
-    for name in ("optim", "optim_pose"):
+    for name in [n for n in ("optim", "optim_pose") if n in objs]:
         optim = objs[name]
         for pg, gi in zip(optim.param_groups, groups[name]):
             where = _param_slices(trainer, gi)
@@ -89,8 +93,8 @@ def optimizer_state_dicts(trainer):
                 optim.state[p] = dict(step=torch.tensor(float(it)),
                                       exp_avg=trainer.m[gi][off:off + n].view(p.shape).clone(),
                                       exp_avg_sq=trainer.v[gi][off:off + n].view(p.shape).clone())
-    out = {k: objs[k].state_dict() for k in ("optim", "optim_pose")}
-    for name in ("sched", "sched_pose"):
+    out = {k: objs[k].state_dict() for k in ("optim", "optim_pose") if k in objs}
+    for name in [n for n in ("sched", "sched_pose") if n in objs]:
         s = objs[name]
         s.last_epoch, s._step_count = it, it + 1
         s._last_lr = [pg["lr"] for pg in s.optimizer.param_groups]
@@ -103,7 +107,7 @@ def load_optimizer_state_dicts(trainer, checkpoint):
     buffers (parameters without state keep zero moments)."""
     objs, groups = _optimizers(trainer)
     for name in ("optim", "optim_pose"):
-        if name not in checkpoint:
+        if name not in checkpoint or name not in objs:
             continue
         optim = objs[name]
         optim.load_state_dict(checkpoint[name])

@@ -836,6 +836,8 @@ class NeRFTrainer:
         self.v = [torch.zeros_like(n.flat_params) for n in self.nets]
         o = opt.optim
         self.lr0, self.gamma = o.lr, _sched_gamma(o.lr, o.get("lr_end"), o.get("sched", {"type": "ExponentialLR"}), opt.max_iter, "optim.sched")
+        n = len(self.nets)
+        self.lrs, self.gammas, self.trainable = [(o.lr, o.get("lr_end"))] * n, [self.gamma] * n, [True] * n          # (checkpoint.py reads these)
         on_gpu = dev.type == "cuda"
         opt.nerf.ray_sampler = opt.nerf.get("ray_sampler") or ("feistel" if on_gpu else "randperm")
         opt.nerf.stratified_rng = opt.nerf.get("stratified_rng") or ("philox" if on_gpu else "torch")

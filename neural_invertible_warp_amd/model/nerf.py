@@ -386,9 +386,12 @@ class Graph(_BaseGraph):
 
 class Model:
     """The reference's engine interface for the vanilla model (model/nerf.py:20-160, driven by train.py:21-32), ground-truth
-    poses: torch.optim.Adam with one param group per network and ExponentialLR exactly as the reference builds them
-    (the parameters are ordinary nn.Parameters, views of the flat buffers the kernels read); checkpoints are the
-    reference's model.ckpt dict.  Logging back-ends are outside the path."""
+    poses.  With Adam on a GPU the iterations run through engine.NeRFTrainer (one niw_train_step call + one fused Adam launch, the
+    reference's ExponentialLR; round 6); otherwise torch.optim with one param group per network and ExponentialLR exactly as the
+    reference builds them (the parameters are ordinary nn.Parameters, views of the flat buffers the kernels read).  Checkpoints are
+    the reference's model.ckpt dict either way (graph, optim, sched, epoch, iter).  Logging back-ends are outside the path."""
+
+    trainer = None        # engine.NeRFTrainer when build_networks chose the engine (subclasses that build their own graph keep the torch path)
 
     def __init__(self, opt):
         import os
@@ -402,10 +405,21 @@ class Model:
         self.train_data, self.test_data = data.open_splits(opt, eval_split=eval_split)
 
     def build_networks(self, opt):
+        """Adam on a GPU (the shipped options/nerf_llff_repr.yaml): the engine's trainer -- one niw_train_step call per iteration
+        (warp_params = NULL) + one fused Adam launch over both networks (engine.NeRFTrainer, round 6; rounds 1-5 ran the mirror under
+        torch.optim here).  Any other optimizer: the reference's own structure below, on the mirror."""
+        self.trainer = None
+        if opt.optim.get("algo", "Adam") == "Adam" and torch.device(opt.device).type == "cuda" and hasattr(self, "train_data"):
+            from .. import engine
+            self.trainer = engine.NeRFTrainer(opt, len(self.train_data), seed=opt.seed or 0)
+            self.graph = self.trainer.graph
+            return
         torch.manual_seed(opt.seed or 0)
         self.graph = Graph(opt).to(opt.device)
 
     def setup_optimizer(self, opt):
+        if self.trainer is not None:
+            return                                    # the trainer owns the flat Adam state and the ExponentialLR schedule
         optimizer = getattr(torch.optim, opt.optim.algo)
         self.optim = optimizer([dict(params=self.graph.nerf.parameters(), lr=opt.optim.lr)])
         if opt.nerf.fine_sampling:
@@ -419,6 +433,14 @@ class Model:
         checkpoint does not mention keep their initialisation (partial checkpoints)."""
         from .. import checkpoint
         self.epoch_start = self.iter_start = 0
+        if self.trainer is not None:
+            ep = it = None
+            if opt.resume:
+                ep, it = checkpoint.restore_checkpoint(opt, self.trainer, resume=opt.resume)
+            elif opt.load is not None:
+                ep, it = checkpoint.restore_checkpoint(opt, self.trainer, load_name=opt.load)
+            self.epoch_start, self.iter_start = ep or 0, it or 0
+            return
         path = checkpoint.checkpoint_path(opt, resume=opt.resume) if opt.resume else opt.load
         if path is None:
             return
@@ -441,9 +463,12 @@ class Model:
         self.it = self.iter_start
         if self.iter_start == 0:
             self.validate(opt, 0)
+        if self.trainer is not None:
+            self.trainer.it = self.it
         while self.it < opt.max_iter:
             loss = self.train_iteration(opt, var, None)
-            self.sched.step()
+            if self.trainer is None:
+                self.sched.step()
             if self.it % opt.freq.scalar == 0:
                 print("[train it {}] {}".format(self.it, " ".join("{}={:.5f}".format(k, float(v.detach())) for k, v in loss.items())), flush=True)
             if self.it % opt.freq.val == 0:
@@ -461,6 +486,10 @@ class Model:
         return loss
 
     def train_iteration(self, opt, var, loader=None):
+        if self.trainer is not None:
+            loss = self.trainer.train_iteration(edict(var))
+            self.it = self.trainer.it
+            return loss
         self.optim.zero_grad(set_to_none=True)
         var = self.graph.forward(opt, edict(var), mode="train")
         loss = self.summarize_loss(opt, var, self.graph.compute_loss(opt, var, mode="train"))
@@ -487,6 +516,9 @@ class Model:
     def save_checkpoint(self, opt, ep=0, it=0, latest=False):
         import os
         import shutil
+        if self.trainer is not None:
+            from .. import checkpoint
+            return checkpoint.save_checkpoint(opt, self.trainer, ep=ep, it=it, latest=latest)
         os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
         ck = dict(epoch=ep, iter=it, graph=self.graph.state_dict(), optim=self.optim.state_dict(), sched=self.sched.state_dict())
         torch.save(ck, "{0}/model.ckpt".format(opt.output_path))

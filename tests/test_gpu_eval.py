@@ -200,7 +200,9 @@ def test_train_entry_point_runs_resumes_and_evaluates(tmp_path, capsys):
 
 
 def test_train_entry_point_vanilla_nerf(tmp_path, capsys):
-    """--model=nerf --yaml=nerf_llff_repr (BASELINE configs[0] shape family: GT poses, coarse + fine networks, torch Adam)"""
+    """--model=nerf --yaml=nerf_llff_repr (BASELINE configs[0] shape family: GT poses, coarse + fine networks, density noise): since round 6
+    the Model drives engine.NeRFTrainer -- one niw_train_step call + one fused Adam launch per iteration -- and still writes / resumes the
+    reference's model.ckpt dict (graph, optim with one param group per network, sched, epoch, iter)"""
     import os
     from neural_invertible_warp_amd import train
     args = ["--model=nerf", "--yaml=nerf_llff_repr", "--data.dataset=synthetic", "--data.image_size=[24,32]", "--nerf.rand_rays=288",
@@ -208,11 +210,15 @@ def test_train_entry_point_vanilla_nerf(tmp_path, capsys):
             f"--output_root={tmp_path}", "--name=v"]
     m = train.main(args + ["--max_iter=4"])
     out = capsys.readouterr().out
+    assert m.trainer is not None and m.trainer.fused is not None, getattr(m.trainer, "fused_fallback_reason", "the Model did not choose the engine")
     assert "[val it 0]" in out and "[val it 4]" in out and "render_fine=" in out
     ck = torch.load(f"{m.opt.output_path}/model.ckpt", weights_only=False)
     assert ck["iter"] == 4 and "nerf_fine.mlp_rgb.1.bias" in ck["graph"] and len(ck["optim"]["param_groups"]) == 2
+    assert set(ck["optim"]["state"]) and ck["sched"]["last_epoch"] == 4
     m2 = train.main(args + ["--max_iter=6", "--resume"])
     assert m2.iter_start == 4 and m2.it == 6 and os.path.exists(f"{m.opt.output_path}/model/4.ckpt")
+    # the resumed run continues the SAME training: its Adam moments came from the checkpoint
+    assert float(m2.trainer.m[0].abs().sum()) > 0 and m2.trainer.it == 6
 
 
 def test_train_entry_point_dtu_with_learnable_poses(tmp_path, capsys):
