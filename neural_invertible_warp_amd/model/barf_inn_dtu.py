@@ -70,12 +70,26 @@ class Model(_nerf.Model):
         raise ValueError("pose.init={} (COLMAP / PDC-Net initialisation is outside the render path)".format(opt.pose.init))
 
     def build_networks(self, opt):
+        """Adam on a GPU (the shipped options/barf_inn_dtu.yaml): engine.INNTrainer (family "dtu": INNPoseParams + Graph as below, one
+        niw_train_step call per iteration, one fused Adam launch over the field network(s), the pose network and the latent table, both
+        ExponentialLR schedules, c2f progress; round 6 -- rounds 1-5 ran the mirror under two torch.optim.Adam here).  Any other
+        optimizer: the reference's own structure, on the mirror."""
         from .pose_models.inn import INNPoseParams
         torch.manual_seed(opt.seed or 0)
-        self.pose_net = INNPoseParams(opt, num_poses=len(self.train_data), initial_poses_w2c=self.set_initial_poses(opt), device=opt.device)
+        init = self.set_initial_poses(opt)
+        self.trainer = None
+        if opt.optim.get("algo", "Adam") == "Adam" and torch.device(opt.device).type == "cuda":
+            from .. import engine, parallel
+            rank, world, _ = parallel.init_from_env()
+            self.trainer = engine.INNTrainer(opt, len(self.train_data), rank=rank, world=world, seed=opt.seed or 0, initial_poses_w2c=init)
+            self.graph, self.pose_net = self.trainer.graph, self.trainer.pose_net
+            return
+        self.pose_net = INNPoseParams(opt, num_poses=len(self.train_data), initial_poses_w2c=init, device=opt.device)
         self.graph = Graph(opt, self.pose_net).to(opt.device)
 
     def setup_optimizer(self, opt):
+        if self.trainer is not None:
+            return                                    # the trainer owns both Adam states and both schedules
         super().setup_optimizer(opt)
         optimizer = getattr(torch.optim, opt.optim.algo)
         self.optim_pose = optimizer([dict(params=self.pose_net.pose_embedding.parameters(), lr=opt.optim.lr_pose)])
@@ -84,6 +98,10 @@ class Model(_nerf.Model):
         self.sched_pose = torch.optim.lr_scheduler.ExponentialLR(self.optim_pose, gamma=gamma)
 
     def train_iteration(self, opt, var, loader=None):
+        if self.trainer is not None:
+            loss = self.trainer.train_iteration(edict(var))
+            self.it = self.trainer.it
+            return loss
         self.optim.zero_grad(set_to_none=True)
         self.optim_pose.zero_grad(set_to_none=True)
         var = self.graph.forward(opt, edict(var), mode="train", iter=self.it)
@@ -104,6 +122,8 @@ class Model(_nerf.Model):
 
     @torch.no_grad()
     def validate(self, opt, ep=None):
+        if self.trainer is not None:
+            self.trainer.sync_state()                 # every rank: c2f progress Parameter, per-view poses of the owning ranks
         ev = self._evaluator(opt)
         stats = ev.evaluate_poses(opt)
         ev.validate(opt)                               # installs the est->gt similarity the val / eval pose branch needs
@@ -113,12 +133,20 @@ class Model(_nerf.Model):
         return out
 
     def evaluate_full(self, opt):
+        if self.trainer is not None:
+            self.trainer.sync_state()
         allv = self.test_data.all
         return self._evaluator(opt).evaluate_full(opt, [edict({k: v[i:i + 1] for k, v in allv.items()}) for i in range(len(self.test_data))])
 
     def save_checkpoint(self, opt, ep=0, it=0, latest=False):
         import os
         import shutil
+        if self.trainer is not None:
+            from .. import checkpoint
+            self.trainer.sync_state()                 # every rank (a collective under ray sharding), then the rank gate
+            if self.trainer.rank == 0:
+                checkpoint.save_checkpoint(opt, self.trainer, ep=ep, it=it, latest=latest)
+            return
         os.makedirs("{0}/model".format(opt.output_path), exist_ok=True)
         ck = dict(epoch=ep, iter=it, graph=self.graph.state_dict(), optim=self.optim.state_dict(), sched=self.sched.state_dict(),
                   optim_pose=self.optim_pose.state_dict(), sched_pose=self.sched_pose.state_dict())
@@ -127,8 +155,8 @@ class Model(_nerf.Model):
             shutil.copy("{0}/model.ckpt".format(opt.output_path), "{0}/model/{1}.ckpt".format(opt.output_path, ep or it))
 
     def restore_checkpoint(self, opt):
-        super().restore_checkpoint(opt)
-        if opt.resume:
+        super().restore_checkpoint(opt)               # (with the engine's trainer: both optimizers, both schedules, the counters)
+        if opt.resume and self.trainer is None:
             name = "{0}/model.ckpt".format(opt.output_path) if opt.resume is True else "{0}/model/{1}.ckpt".format(opt.output_path, opt.resume)
             ck = torch.load(name, map_location=opt.device, weights_only=False)
             self.optim_pose.load_state_dict(ck["optim_pose"])

@@ -223,7 +223,8 @@ def test_train_entry_point_vanilla_nerf(tmp_path, capsys):
 
 def test_train_entry_point_dtu_with_learnable_poses(tmp_path, capsys):
     """--model=barf_inn_dtu --yaml=barf_inn_dtu (BASELINE cfg 5 family): noisy initial poses, INNPoseParams, two optimizers,
-    validation through the pairwise pose alignment + back-aligned test poses, resume."""
+    validation through the pairwise pose alignment + back-aligned test poses, resume.  Since round 6 the Model drives engine.INNTrainer
+    (family "dtu": one niw_train_step call + one fused Adam launch) and writes / resumes the reference's model.ckpt dict."""
     from neural_invertible_warp_amd import train
     args = ["--model=barf_inn_dtu", "--yaml=barf_inn_dtu", "--barf_c2f=[0.1,0.5]", "--loss_weight.global_alignment=3", "--data.dataset=dtu", "--data.synthetic_fallback", "--data.image_size=[24,32]", "--nerf.rand_rays=192",
             "--nerf.sample_intvs=32", "--data.train_sub=3", "--freq.val=3", "--freq.ckpt=3", "--freq.scalar=1", "--optim.test_iter=3",
@@ -231,11 +232,13 @@ def test_train_entry_point_dtu_with_learnable_poses(tmp_path, capsys):
     m = train.main(args + ["--max_iter=3"])
     out = capsys.readouterr().out
     assert "[val it 3]" in out and "rot " in out and "global_alignment=" in out
+    assert m.trainer is not None and m.trainer.family == "dtu" and m.trainer.fused is not None, "the DTU Model did not choose the engine's one-call iteration"
     ck = torch.load(f"{m.opt.output_path}/model.ckpt", weights_only=False)
     assert "pose_net.pose_embedding.lin0_a_0.weight_g" in ck["graph"] and "optim_pose" in ck and ck["iter"] == 3
     assert hasattr(m.pose_net, "sim3_est_to_gt_c2w")
+    assert len(ck["optim_pose"]["param_groups"]) == 2 and ck["sched_pose"]["last_epoch"] == 3
     m2 = train.main(args + ["--max_iter=5", "--resume"])
-    assert m2.iter_start == 3 and m2.it == 5
+    assert m2.iter_start == 3 and m2.it == 5 and float(m2.trainer.m[-2].abs().sum()) > 0          # the pose network's Adam moments came back
     res = m2.evaluate_full(m2.opt)
     assert all(r.psnr > 0 for r in res.res)
 
