@@ -471,3 +471,37 @@ def test_train_step_never_reads_memory_it_has_not_written(case):
     assert torch.equal(a.bucket.flat, b.bucket.flat)
     for x, y in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("case", ["cfg3", "cfg2", "vanilla", "cfg3_mirror"])
+def test_training_on_a_non_default_stream_equals_the_default_stream(case):
+    """every launch of an iteration -- the library's, the wrappers' and torch's own -- must follow the CURRENT stream: the same iterations
+    issued inside `torch.cuda.stream(s)`, with the default stream kept busy by an unrelated long kernel train, train bit for bit alike
+    (a launch that slipped onto the default stream would run late or early against its neighbours)"""
+    from tests.test_gpu_fused_step import _trainer, _vanilla_trainer
+    make = {"cfg3": lambda: _trainer("cfg3_barf_inn_llff", True), "cfg2": lambda: _trainer("cfg2_nerf_inn_llff_hier", True),
+            "vanilla": lambda: _vanilla_trainer(True), "cfg3_mirror": lambda: _trainer("cfg3_barf_inn_llff", False)}[case]
+
+    def run(stream):
+        tr, var0 = make()
+        busy = torch.rand(1 << 24, device=DEV)
+        losses = []
+        for i in range(4):
+            if stream is None:
+                loss = tr.train_iteration(type(var0)(var0))
+            else:
+                for _ in range(4):
+                    busy.mul_(1.0000001)                       # the default stream is never idle
+                with torch.cuda.stream(stream):
+                    loss = tr.train_iteration(type(var0)(var0))
+            losses.append(loss)
+        torch.cuda.synchronize()
+        return tr, [{k: float(v.detach()) for k, v in l.items()} for l in losses]
+
+    a, la = run(None)
+    s = torch.cuda.Stream()
+    b, lb = run(s)
+    assert la == lb, (la, lb)
+    assert torch.equal(a.bucket.flat, b.bucket.flat)
+    for x, y in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
+        assert torch.equal(x, y)
