@@ -32,7 +32,8 @@ def compile_to_asm(src, out):
     return out
 
 
-STORE = re.compile(r"\s+buffer_store_dwordx([234]) v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\], (s\d+|m0)\b")
+# (any addressing form: a vector offset, `off`, or an index / offset pair -- the hazard is about the DATA registers and the SGPR soffset)
+STORE = re.compile(r"\s+buffer_store_dwordx([234]) v\[(\d+):(\d+)\], (?:v\d+|v\[\d+:\d+\]|off), s\[\d+:\d+\], (s\d+|m0)\b")
 WINDOW = 2          # wait states LLVM's model of the VALU-writes-store-data hazard uses on gfx940+ (an `s_nop N` counts N + 1)
 
 
