@@ -170,10 +170,10 @@ struct FwdEpilogue {
                     // hazard; LLVM pads only immediate soffsets).  Rounds 3-5 relied on this kernel's one wave per SIMD; round 6 measured
                     // that a wave of ANOTHER kernel -- the library's own second stream, another process on the device -- triggers it just
                     // the same (tools/store_war_hazard_foreign.hip: 2.2e5 of 5.4e8 stores; a saved +0.0 then reads 0x7fffffff = NaN, and one
-                    // did: a rank diverged to NaN while four processes shared a GPU).  One s_nop 0 between the two is enough (0 of 5.4e8)
+                    // did: a rank diverged to NaN while four processes shared a GPU).  One s_nop 0 between the two was enough in every measurement (0 of 5.4e8)
                     // and free beside an MFMA chain; the scheduling barriers keep it where it is.
                     __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_nop 0");
+                    asm volatile("s_nop 1");      // two wait states: what LLVM itself puts behind the store forms it knows (global stores need both: tools/store_war_hazard_global.hip)
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
