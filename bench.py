@@ -908,7 +908,10 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 pass
-        roofline = dict(bound="mfma", kernel=rocprof_name[dom], achieved=a, peak=peak_mfma, unit="TFLOP/s", frac=round(a / peak_mfma, 4), traffic=traffic,
+        # `traffic` = HBM bytes per launch (a number, or null); where it comes from sits beside it
+        roofline = dict(bound="mfma", kernel=rocprof_name[dom], achieved=a, peak=peak_mfma, unit="TFLOP/s", frac=round(a / peak_mfma, 4),
+                        traffic=None if traffic is None else round(traffic["value"] * 1e9), traffic_unit="bytes per launch (HBM, PMC counters)",
+                        traffic_source=None if traffic is None else traffic["source"],
                         avg_ms=kernels[dom]["avg_ms"], samples_per_launch=kernels[dom]["samples_per_launch"], flop_per_sample=FLOP_FWD,
                         rocprof=rocprof_row(args.config, rocprof_name[dom]))
         if not exact:
@@ -936,7 +939,9 @@ def main():
             roofline = dict(bound="hbm" if t_hbm >= t_mfma else "mfma", kernel=rocprof_name[dom],
                             achieved=round(gbps, 1) if t_hbm >= t_mfma else round(issued_tf, 2), peak=PEAK_HBM if t_hbm >= t_mfma else PEAK_BF16_MFMA,
                             unit="GB/s" if t_hbm >= t_mfma else "TFLOP/s",
-                            frac=round(max(t_hbm, t_mfma) / (ms * 1e-3), 4), traffic=counter, avg_ms=ms, samples_per_launch=n,
+                            frac=round(max(t_hbm, t_mfma) / (ms * 1e-3), 4), traffic=None if counter is None else round(counter["value"] * 1e9),
+                            traffic_unit="bytes per launch (HBM, PMC counters)", traffic_source=None if counter is None else counter["source"],
+                            avg_ms=ms, samples_per_launch=n,
                             ceilings=dict(hbm=dict(algorithmic_bytes_per_sample=algo, achieved_gbps=round(gbps, 1), peak_gbps=PEAK_HBM, frac=round(gbps / PEAK_HBM, 4),
                                                    floor_ms=round(t_hbm * 1e3, 4)),
                                           mfma=dict(terms_per_mac=terms, issued_tflops=round(issued_tf, 2), peak_tflops=PEAK_BF16_MFMA,
