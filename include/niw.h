@@ -498,7 +498,10 @@ typedef struct niw_train_desc {
     int32_t ndc;                /* opt.camera.ndc: rays re-parametrised by niw_convert_ndc (camera.py:523-540) */
     uint64_t noise_seed;
     float ndc_near;             /* near plane of the NDC re-parametrisation (the reference passes 1) */
-    int32_t reserved2;
+    int32_t has_bg;             /* opt.nerf.setbg_opaque: rgb += bg (1 - opacity) in both compositing passes (model/nerf.py:470-472); the passes
+                                   then run as niw_composite_fwd / niw_mse_fwd_bwd / niw_composite_bwd (the one-launch form has no background) */
+    float bg;                   /* opt.data.bgcolor */
+    int32_t reserved3;
 } niw_train_desc;
 
 /* Optional: create the library's own streams (niw_train_desc.overlap; niw_mlp_bwd_dw's second stream) for the current device NOW instead

@@ -45,7 +45,7 @@ class TrainDesc(ctypes.Structure):
                 ("w_render", _f), ("w_render_fine", _f), ("w_align", _f), ("always_register", _i32), ("mse_norm", _d),
                 ("loss", _vp), ("d_nerf", _vp), ("d_nerf_fine", _vp), ("d_warp", _vp), ("d_latent", _vp), ("poses", _vp),
                 ("rgb", _vp), ("rgb_fine", _vp), ("overlap", _i32), ("reserved", _i32), ("fine_grads_ready", _vp),
-                ("density_noise", _f), ("ndc", _i32), ("noise_seed", _u64), ("ndc_near", _f), ("reserved2", _i32)]
+                ("density_noise", _f), ("ndc", _i32), ("noise_seed", _u64), ("ndc_near", _f), ("has_bg", _i32), ("bg", _f), ("reserved3", _i32)]
 
 
 # train stages (enum niw_train_stage), in execution order

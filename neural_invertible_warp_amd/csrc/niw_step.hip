@@ -495,14 +495,15 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     // closing kernel of the iteration (combine_kernel) from the residuals
     static const bool one_launch_env = [] { const char* e = getenv("NIW_TRAIN_ONE_LAUNCH_LOSS"); return !e || atoi(e) != 0; }();
     const int64_t hw = (int64_t)d->H * d->W;
-    const bool one_c = one_launch_env && loss_c && S % 4 == 0 && S <= 256;
-    const bool one_f = one_launch_env && loss_f && T % 4 == 0 && T <= 256;
+    const int has_bg = d->has_bg ? 1 : 0;            // opaque background (model/nerf.py:470-472): the three-launch form carries it
+    const bool one_c = one_launch_env && !has_bg && loss_c && S % 4 == 0 && S <= 256;
+    const bool one_f = one_launch_env && !has_bg && loss_f && T % 4 == 0 && T <= 256;
     if (in(NIW_STAGE_COMPOSITE_FWD)) {
         if (one_c)
             NIW_RUN(niw_composite_mse_train(ray, L.rgb_s, L.sigma_s, L.z, n, S, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, d->mse_norm, d->w_render, rgb, L.depth,
                                             L.opacity, L.prob, L.resid_c, nullptr, L.d_rgb_s_c, L.d_sigma_s_c, L.comp_d_ray_c, stream));
         else
-            NIW_RUN(niw_composite_fwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, rgb, L.depth, L.opacity, L.prob, stream));
+            NIW_RUN(niw_composite_fwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, has_bg, d->bg, rgb, L.depth, L.opacity, L.prob, stream));
     }
     if (fine) {
         if (in(NIW_STAGE_RESAMPLE)) NIW_RUN(niw_sample_pdf_merge(L.prob, L.z, d->unif, d->bins, n, S, d->n_fine, nullptr, L.z_all, stream));
@@ -514,7 +515,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
                 NIW_RUN(niw_composite_mse_train(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, d->image, ray_idx, d->n_views, R, hw, d->ray_lo, d->mse_norm, d->w_render_fine,
                                                 rgb_fine, L.depth_fine, L.opacity_fine, nullptr, L.resid_f, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
             else
-                NIW_RUN(niw_composite_fwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, rgb_fine, L.depth_fine, L.opacity_fine, nullptr, stream));
+                NIW_RUN(niw_composite_fwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, has_bg, d->bg, rgb_fine, L.depth_fine, L.opacity_fine, nullptr, stream));
         }
     }
     if (in(NIW_STAGE_LOSS)) {
@@ -527,7 +528,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     if (fine) {
         if (loss_f) {
             if (in(NIW_STAGE_COMPOSITE_BWD_FINE) && !one_f)
-                NIW_RUN(niw_composite_bwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, 0, 0.f, L.d_rgb_f, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
+                NIW_RUN(niw_composite_bwd(ray, L.rgb_f, L.sigma_f, L.z_all, n, T, has_bg, d->bg, L.d_rgb_f, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_f, stream));
             if (in(NIW_STAGE_MLP_BWD_DX_FINE))
                 NIW_RUN(niw_mlp_bwd_dx(L.packed_f, center, ray, L.z_all, n, T, d->density_activ, d->precision, L.rgb_f, L.d_rgb_s, L.d_sigma_s, L.save_f, L.gradws,
                                        warp ? L.mlp_d_f : nullptr, warp ? L.mlp_d_f + 3 * n : nullptr, stream));
@@ -539,7 +540,7 @@ extern "C" int niw_train_step(const niw_train_desc* d, float* workspace, int sta
     }
     if (loss_c) {
         if (in(NIW_STAGE_COMPOSITE_BWD) && !one_c)
-            NIW_RUN(niw_composite_bwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, 0, 0.f, L.d_rgb, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_c, stream));
+            NIW_RUN(niw_composite_bwd(ray, L.rgb_s, L.sigma_s, L.z, n, S, has_bg, d->bg, L.d_rgb, nullptr, nullptr, nullptr, L.d_rgb_s, L.d_sigma_s, L.comp_d_ray_c, stream));
         if (in(NIW_STAGE_MLP_BWD_DX))
             NIW_RUN(niw_mlp_bwd_dx(L.packed_c, center, ray, L.z, n, S, d->density_activ, d->precision, L.rgb_s, d_rgb_s_c, d_sigma_s_c, L.save_c, L.gradws,
                                    warp ? L.mlp_d_c : nullptr, warp ? L.mlp_d_c + 3 * n : nullptr, stream));

@@ -115,8 +115,6 @@ class FusedStep:
         vanilla = getattr(trainer, "family", None) == "vanilla"
         if opt.nerf.density_noise_reg and opt.nerf.get("density_noise_rng") != "philox":
             return "density noise injected through torch.randn"
-        if opt.nerf.setbg_opaque:
-            return "nerf.setbg_opaque"
         if opt.data.dataset == "blender" and not vanilla:
             return "blender initial poses"
         if nerf_inn_llff.ALIGN_BACKEND is not None and not vanilla:
@@ -209,6 +207,7 @@ class FusedStep:
         d.density_noise = float(opt.nerf.density_noise_reg or 0.0)
         d.noise_seed = noise_stream_seed(opt, rank, 0)
         d.ndc, d.ndc_near = (1 if opt.camera.ndc else 0), 1.0
+        d.has_bg, d.bg = (1 if opt.nerf.setbg_opaque else 0), float(opt.data.get("bgcolor") or 0.0)
         if not Sf:
             d.w_render_fine = -1.0
         d.always_register = 1 if tr.family == "dtu" else 0
@@ -262,7 +261,7 @@ class FusedStep:
         opt = self.tr.opt
         sig = [len(var.idx), opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.nerf.sample_intvs_fine if opt.nerf.fine_sampling else 0, self._weights(),
                bool(opt.nerf.sample_stratified), tuple(opt.nerf.depth.range), opt.nerf.depth.param]
-        sig.append((bool(opt.camera.ndc), float(opt.nerf.density_noise_reg or 0.0)))
+        sig.append((bool(opt.camera.ndc), float(opt.nerf.density_noise_reg or 0.0), bool(opt.nerf.setbg_opaque), float(opt.data.get("bgcolor") or 0.0)))
         for k in ("image", "intr", "depth_range") + (("pose",) if self.tr.family == "vanilla" else ()):
             t = var.get(k) if hasattr(var, "get") else getattr(var, k, None)
             sig.append(None if t is None else (t.data_ptr(), tuple(t.shape), t._version if k == "depth_range" else 0))
@@ -312,6 +311,7 @@ class FusedStep:
             # composite_bwd stage is empty
             import os
             one = os.environ.get("NIW_TRAIN_ONE_LAUNCH_LOSS", "1") != "0"
+            one = one and not d.has_bg                      # (an opaque background: the three-launch form)
             fused_pass = {"": one and d.w_render >= 0 and S % 4 == 0 and S <= 256,
                           "_fine": one and Sf > 0 and d.w_render_fine >= 0 and (S + Sf) % 4 == 0 and S + Sf <= 256}
             for k, name in enumerate(_lib_mod.TRAIN_STAGES):

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=None, rays=None, S=16, ndc=False, noise=None):
+def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=None, rays=None, S=16, ndc=False, noise=None, bg=None):
     from neural_invertible_warp_amd import configs, engine
     if cfg == "dtu":
         opt = configs.cfg5_barf_inn_dtu(device=DEV)
@@ -23,6 +23,8 @@ def _trainer(cfg, fused, rank=0, world=1, hip_graph=False, stratified=True, B=No
         var0, init = engine.synthetic_scene(opt, B), None
     opt.nerf.sample_stratified = stratified
     opt.camera.ndc, opt.nerf.density_noise_reg = ndc, noise
+    if bg is not None:
+        opt.nerf.setbg_opaque, opt.data.bgcolor = True, bg
     opt.nerf.rand_rays, opt.nerf.sample_intvs, opt.max_iter = rays or B * 37, S, 40
     opt.inn.real_nvp.max_pe_iter = 20                       # bands, windows and learning rates all move within the run
     if opt.nerf.fine_sampling:
@@ -182,10 +184,7 @@ def test_captured_iteration_survives_sync_state_under_ray_sharding():
 def test_fused_iteration_is_refused_or_bypassed_where_it_does_not_apply():
     from neural_invertible_warp_amd import configs, engine
     from neural_invertible_warp_amd._lib import NiwError
-    opt = configs.cfg3_barf_inn_llff(device=DEV)
-    opt.nerf.setbg_opaque = True                 # (NDC and density noise are inside the call since round 6; an opaque background is not)
-    tr = engine.INNTrainer(opt, 3, fused_step="auto")
-    assert tr.fused is None and "setbg_opaque" in tr.fused_fallback_reason
+    # (NDC, density noise and an opaque background are inside the call since round 6; draws injected through torch are not)
     opt = configs.cfg3_barf_inn_llff(device=DEV)
     opt.nerf.density_noise_reg, opt.nerf.density_noise_rng = 1.0, "torch"      # a harness that injects torch.randn draws
     tr = engine.INNTrainer(opt, 3, fused_step="auto")
@@ -383,3 +382,30 @@ def test_ndc_reverse_pass_vs_autograd_of_the_reference_formulas():
     rel = lambda x, y: float((x.detach().cpu().double() - y.detach()).abs().max() / y.detach().abs().max())
     assert rel(oc, oc64) < 2e-6 and rel(orr, or64) < 2e-6
     assert rel(cg.grad, c64.grad) < 5e-6 and rel(rg.grad, r64.grad) < 5e-6, (rel(cg.grad, c64.grad), rel(rg.grad, r64.grad))
+
+
+@pytest.mark.parametrize("cfg", ["cfg3_barf_inn_llff", "cfg2_nerf_inn_llff_hier"])
+def test_fused_iteration_with_an_opaque_background_equals_the_mirror(cfg):
+    """nerf.setbg_opaque (reference model/nerf.py:470-472: rgb += bgcolor (1 - opacity)) inside niw_train_step: the passes then run as
+    niw_composite_fwd / niw_mse_fwd_bwd / niw_composite_bwd with the background, the launches the mirror makes"""
+    runs = []
+    for fused in (False, True):
+        tr, var0 = _trainer(cfg, fused, bg=1.0)
+        losses = []
+        for _ in range(3):
+            loss = tr.train_iteration(type(var0)(var0))
+            losses.append({k: float(v.detach()) for k, v in loss.items()})
+        torch.cuda.synchronize()
+        runs.append((tr, losses))
+    (a, la), (b, lb) = runs
+    for x, y in zip(la, lb):
+        for k in x:
+            if k == "all":
+                assert abs(x[k] - y[k]) <= 1e-6 * max(abs(x[k]), 1e-6), (k, x[k], y[k])
+            else:
+                assert x[k] == y[k], (k, x[k], y[k])
+    assert torch.equal(a.bucket.flat, b.bucket.flat), float((a.bucket.flat - b.bucket.flat).abs().max())
+    for fa, fb in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
+        assert torch.equal(fa, fb)
+    # (with the reference's last interval of 1e10 and a positive density the opacity is exactly 1 and the background term exactly 0:
+    # the check is that both forms run the background's launches and agree, not that the loss moves)
