@@ -830,13 +830,27 @@ def main():
                         ("" if on is not None else " (no fine network in this config: nothing to split)"))
         release(loads_ab)
         del loads_ab
-        loads_g, _ = build_workloads(args.config, dev, rank, world, scaling, 0, placement="shard", **dict(wl_ab, hip_graph=True))
-        guard_captures(loads_g, "ab_graph")
         try:
+            dist.distributed_c10d._get_default_store()          # (the host-side agreement on the captures needs the group's store)
+            store_ok = True
+        except Exception:  # noqa: BLE001
+            store_ok = False
+        if not store_ok:
+            graph_ab = dict(launched_ms=off["ms"], replayed_ms=None, skipped="this torch build does not expose the process group's store: the "
+                            "captures cannot be agreed on host-side, so the replayed leg is not attempted")
+            loads_g = []
+        else:
+            loads_g, _ = build_workloads(args.config, dev, rank, world, scaling, 0, placement="shard", **dict(wl_ab, hip_graph=True))
+            guard_captures(loads_g, "ab_graph")
+        try:
+            if not store_ok:
+                raise StopIteration
             rep = leg(loads_g)
             graph_ab = dict(launched_ms=off["ms"], replayed_ms=rep["ms"] if rep["hip_graph"] else None, replayed=rep, steps=args.steps,
                             workload=f"{scaling}-scaled {args.config}, flat all-reduce; replayed = two captured graphs (forward + backward | Adam) around the "
                                      "eagerly issued all-reduce")
+        except StopIteration:
+            pass
         except (CaptureAbort, engine.CaptureError) as e:
             capture_abort = str(e)[:300]
             graph_ab = dict(launched_ms=off["ms"], replayed_ms=None, capture_failed=capture_abort)
