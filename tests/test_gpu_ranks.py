@@ -81,6 +81,8 @@ def test_four_ranks_default_workload_line_is_self_diagnosing():
     assert hg["launched_ms"] > 0 and (hg["replayed_ms"] is None and "capture_failed" in hg or hg["replayed_ms"] > 0)
     assert line["comm_bucket_bytes"] == 4 * 1228308 and abs(line["comm_wire_ms"] - 2 * 3 / 4 * 4913232 / 153e9 * 1e3) < 1e-3
     assert line["comm_ms"] is not None and line["comm_exposed_ms"] is not None
+    assert 10 < line["peak_memory_gb"] < 40, line["peak_memory_gb"]            # a rank's 16.6 GB workspace (+ batch, parameters); 288 GB per GPU
+    assert line["param_checksum"] is not None
     print(f"4 gloo ranks, cfg2: {wall:.0f} s wall; weak {line['ms_per_step']:.1f} ms, strong {line['strong']['ms_per_step']:.1f} ms; split exchange on/off "
           f"{se['on_ms']}/{se['off_ms']} ms; launched/replayed {hg['launched_ms']}/{hg['replayed_ms']} ms")
 
