@@ -409,3 +409,25 @@ def test_fused_iteration_with_an_opaque_background_equals_the_mirror(cfg):
         assert torch.equal(fa, fb)
     # (with the reference's last interval of 1e10 and a positive density the opacity is exactly 1 and the background term exactly 0:
     # the check is that both forms run the background's launches and agree, not that the loss moves)
+
+
+def test_captured_iteration_with_density_noise_draws_a_fresh_stream_every_replay():
+    """density noise inside a REPLAYED graph: niw_normal_rng reads the draw number from the step constants (draw_dev), so every replay adds
+    the noise of ITS iteration -- the captured run must equal the launched one bit for bit over several replays, and two consecutive
+    iterations must not see the same noise"""
+    runs = []
+    for graph in (False, True):
+        tr, var0 = _trainer("cfg2_nerf_inn_llff_hier", True, hip_graph=graph, noise=0.5)
+        losses = []
+        for _ in range(7):
+            loss = tr.train_iteration(type(var0)(var0))
+            losses.append(float(loss.render_fine.detach()))
+        torch.cuda.synchronize()
+        if graph:
+            assert tr._captured is not None
+        runs.append((tr, losses))
+    (a, la), (b, lb) = runs
+    assert la == lb, (la, lb)
+    assert len(set(la)) == len(la)
+    for fa, fb in zip(a._flats() + a.m + a.v, b._flats() + b.m + b.v):
+        assert torch.equal(fa, fb)
