@@ -336,6 +336,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs a) {
 // one per-point factor of the parameter gradients -> row `row` of the block's feature-major workspace
 #define NIW_WS(row, v) ws[(long long)(row) * P] = (v)
 __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs a) {
+#ifdef NIW_WARP_BWD_PRIO
+    __builtin_amdgcn_s_setprio(NIW_WARP_BWD_PRIO);       // (diagnostic: wave priority of this vector-ALU kernel beside the dW launch's matrix waves)
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lw = lds;
     float* lh = lw + 3 * kWembBlock;
